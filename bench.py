@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the NS2VC denoiser hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "denoiser-steps/sec (10s@24kHz Vocos latent, bs32)",
+configs[2]): 10 s utterances (T = 938 Vocos frames), batch 32 per GPU, prompt Lp = 469,
+UniPC-bh2 order 2, hipGraph-captured loop, bf16 MFMA.  One "step" = one denoiser
+evaluation (UNet forward on the whole batch) + the fused solver update.  The timed
+region is ONE sampling job of exactly K steps: the once-per-utterance condition
+hoisting (set_condition) + K graph replays + the layout change back to (B,100,T),
+inputs already resident in HBM, and for N > 1 the all-gather of finished latents.
+Synthetic data (seeded hash), procedural weights of the production architecture.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}     # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (weak scaling)")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--prompt-frames", type=int, default=469)
+    ap.add_argument("--solver", default="unipc", choices=["unipc", "dpmsolver++"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-baseline leg")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--detail", action="store_true", help="print the per-kernel-family table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(T: int, Lp: int, B: int, iters: int):
+    """The oracle (oracle/unet_ref.py, pinned bit-exact to the reference by tests/golden) timed on the
+    host cores: a bounded sample of the same workload (same T/Lp, smaller batch)."""
+    import torch
+    from ns2vc_amd.spec import UNetConfig
+    from ns2vc_amd.weights import hash_normal, procedural_state_dict
+    from oracle import unet_ref
+    cfg = UNetConfig()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    P = {k: torch.from_numpy(v) for k, v in procedural_state_dict(cfg, 0).items()}
+    x = torch.from_numpy(hash_normal("cpu.x", (B, cfg.in_channels, T)))
+    prompt = torch.from_numpy(hash_normal("cpu.p", (B, Lp, cfg.cross_attention_dim)))
+    mask = torch.ones(B, Lp, dtype=torch.bool)
+    t = torch.full((B,), 500.0)
+    unet_ref.unet_forward(P, cfg, x, t, prompt, mask)          # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        unet_ref.unet_forward(P, cfg, x, t, prompt, mask)
+    dt = time.perf_counter() - t0
+    sample_steps = B * iters / dt
+    return {"value": sample_steps / 32.0, "unit": "denoiser-steps/s (batch 32)", "cores": cores, "kind": "port",
+            "sample_steps_per_s": sample_steps,
+            "sample": f"oracle UNet forward (torch CPU fp32, {torch.get_num_threads()} threads), B={B} T={T} Lp={Lp}, "
+                      f"{iters} forwards in {dt:.1f}s; scaled to batch 32 by samples/s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    from ns2vc_amd import engine as E
+    from ns2vc_amd.spec import PUBLISHED_GFLOP, UNetConfig, algorithmic_gflop_per_sample_step, frames_for_seconds
+    from ns2vc_amd.weights import hash_normal, procedural_state_dict
+    from ns2vc_amd.dist import gather_latents
+
+    if not torch.cuda.is_available() or E.device_count() == 0:
+        raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    E.set_device(local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
+
+    cfg = UNetConfig()
+    B, T, Lp, K = a.batch, frames_for_seconds(a.seconds), a.prompt_frames, a.steps
+    order = 2 if K >= 2 else 1
+    solver = a.solver
+
+    eng = E.Engine(cfg, precision=a.precision)
+    eng.load_state_dict(procedural_state_dict(cfg, 0))
+    eng.prepare(B, T, Lp)
+    eng.load_sampler(solver, K, order=order)
+
+    tag = f"bench.r{rank}"
+    content = torch.from_numpy(hash_normal(tag + ".content", (B, cfg.content_channels, T))).to(dev)
+    prompt = torch.from_numpy(hash_normal(tag + ".prompt", (B, Lp, cfg.cross_attention_dim))).to(dev)
+    noise = torch.from_numpy(hash_normal(tag + ".noise", (B, cfg.latent_channels, T))).to(dev)
+    mask = torch.ones((B, Lp), dtype=torch.uint8, device=dev)
+    x = torch.empty_like(noise)
+    stream = torch.cuda.Stream(device=dev)
+    use_graph = not a.no_graph
+
+    def job():
+        x.copy_(noise)                                   # x_T (untimed side effect is tiny; inside for faithfulness)
+        eng.set_condition(content, prompt, mask, stream=stream)
+        eng.sample(x, use_graph=use_graph, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.cuda.stream(stream):
+        for _ in range(max(1, math.ceil(a.warmup / max(K, 1)))):
+            job()
+        stream.synchronize()
+        barrier()
+        ev0, ev1 = E.Event(), E.Event()
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        job()
+        ev1.record(stream)
+        if world > 1:
+            full = gather_latents(x, B * world)
+        stream.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+    wall = t1 - t0
+    gpu_ms = ev0.elapsed_ms(ev1)
+    if world > 1:
+        tt = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+        assert full.shape[0] == B * world
+    finite = bool(torch.isfinite(x).all().item())
+
+    # ---- per-kernel-family roofline, measured live with HIP events around every launch (eager, same stream)
+    fam = {}
+    if rank == 0:
+        ops = eng.op_info(0)
+        ms = eng.profile_forward(stream=stream)          # warm: second call is the one we keep
+        ms = eng.profile_forward(stream=stream)
+        names = {0: "other", 1: "implicit_gemm", 2: "attention", 3: "norm_stats", 4: "copy"}
+        for (name, kind, fl, by), m in zip(ops, ms):
+            f = fam.setdefault(names[kind], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            f["launches"] += 1; f["ms"] += float(m); f["flops"] += fl; f["bytes"] += by
+    if rank == 0:
+        gflop_sample = PUBLISHED_GFLOP.get((T, Lp), algorithmic_gflop_per_sample_step(T, Lp))
+        step_ms = wall * 1e3 / K
+        peak = MFMA_PEAK_TFLOPS[a.precision]
+        g = fam.get("implicit_gemm", {"launches": 1, "ms": 1.0, "flops": 0.0, "bytes": 0.0})
+        gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        roof = {
+            "bound": "mfma", "kernel": "cgemm_kernel (implicit GEMM: conv1d k3/k1 + linear)",
+            "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": None,
+            "launches_per_step": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1),
+            "algorithmic_gflop_per_launch": g["flops"] / 1e9 / max(g["launches"], 1),
+            "algorithmic_hbm_gbs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
+            "whole_step": {"algorithmic_tflop_per_step": gflop_sample * B / 1e3, "ms_per_step": step_ms,
+                           "achieved_tflops": gflop_sample * B / 1e3 / (step_ms * 1e-3), "frac_of_mfma_peak": gflop_sample * B / 1e3 / (step_ms * 1e-3) / peak},
+            "families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 4),
+                             "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
+                             "algorithmic_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)} for k, v in fam.items()},
+        }
+        cpu = None
+        if world == 1 and not a.skip_cpu:
+            try:
+                cpu = cpu_baseline(T, Lp, a.cpu_batch, a.cpu_iters)
+            except Exception as ex:                      # the baseline leg must never take the GPU number down
+                cpu = {"value": None, "unit": "denoiser-steps/s (batch 32)", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {ex!r}"}
+        value = world * K / wall
+        out = {
+            "metric": "denoiser-steps/sec (10s@24kHz Vocos latent, bs32)", "value": value, "unit": "denoiser-steps/s (batch 32 per GPU, whole job)",
+            "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded hash inputs, procedural weights of the production UNet1DConditionModel)",
+            "config": {"workload": f"{a.seconds:g} s utterance (T={T} Vocos frames), batch {B}/GPU, prompt Lp={Lp}, {K}-step {solver} order {order}, "
+                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision}; timed job = set_condition + {K} steps"
+                                   + (" + all-gather of latents" if world > 1 else ""),
+                       "global_batch": B * world, "frames": T, "prompt_frames": Lp, "solver": solver, "parallelism": f"dp{world}"},
+            "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite,
+            "launches_per_step": eng.launches()[0], "workspace_gb": eng.workspace_bytes() / 1e9, "device": E.device_info(),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if cpu and cpu.get("value"):
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        if a.detail:
+            for k, v in roof["families"].items():
+                print(f"  {k:14s} {v}", file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/* ns2vc_hip.h — C ABI of libns2vc_hip.so, the MI355X (gfx950) denoiser engine.
+ *
+ * Drop-in boundary for ONE path of adelacvg/NS2VC (branch vc-v2): the latent
+ * diffusion denoiser `UNet1DConditionModel.forward` driven by the DPM-Solver++ /
+ * UniPC sampling loop.  The reference is pure Python/PyTorch, so there is no
+ * reference FFI to mirror; each entry point below names the reference call site
+ * (file:line under the reference tree) whose work it replaces.  INTEGRATION.md
+ * shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from ns2vc_last_error() (thread-local, valid until the next call);
+ *   - all tensor pointers are DEVICE pointers owned by the caller unless the
+ *     parameter is documented as "host or device" (copied with hipMemcpyDefault);
+ *   - `stream` is a hipStream_t passed as void*; no call blocks the host except
+ *     load/finalize/prepare (setup) and the explicitly synchronous helpers;
+ *   - API tensors use the reference's layouts: latent/content (B, C, T) "NCT"
+ *     fp32 contiguous, prompt (B, Lp, 256) fp32 contiguous, mask (B, Lp) uint8
+ *     (1 = keep), timesteps (B) fp32 (fractional values are legal,
+ *     sampler/dpm_solver.py:278).
+ */
+#ifndef NS2VC_HIP_H
+#define NS2VC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NS2VC_ABI_VERSION 1
+#define NS2VC_MAX_LEVELS 8
+#define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
+
+typedef struct ns2vc_unet ns2vc_unet; /* opaque engine handle */
+
+/* Mirrors the ctor kwargs NS2VC passes (model.py:391-400) plus the defaults of
+ * unet1d/unet_1d_condition.py:151-203 that shape the network. */
+typedef struct ns2vc_unet_cfg {
+  int32_t latent_channels;    /* 100: out_channels and the x part of in_channels  */
+  int32_t content_channels;   /* 256: in_channels - latent_channels               */
+  int32_t n_levels;           /* 4                                                */
+  int32_t block_out_channels[NS2VC_MAX_LEVELS]; /* 128,256,384,512                */
+  int32_t norm_num_groups;    /* 8                                                */
+  int32_t cross_attention_dim;/* 256                                              */
+  int32_t heads;              /* 8  (the reference's `attention_head_dim`)        */
+  int32_t layers_per_block;   /* 2                                                */
+  int32_t pool_heads;         /* 64 (addition_embed_type_num_heads)               */
+} ns2vc_unet_cfg;
+
+enum { NS2VC_PREC_F32 = 0,  /* fp32 storage, exact-fp32 MFMA: parity mode (<= 1e-3 gate) */
+       NS2VC_PREC_BF16 = 1  /* bf16 MFMA operands, fp32 accumulate / norm stats / solver state */ };
+
+/* ---- library ----------------------------------------------------------------------- */
+int ns2vc_abi_version(void);
+const char* ns2vc_last_error(void);
+int ns2vc_device_count(int* out_count);
+int ns2vc_set_device(int device);               /* one process per GPU: call with LOCAL_RANK */
+int ns2vc_device_name(char* buf, int buflen);
+
+/* ---- engine lifetime (replaces UNet1DConditionModel.__init__, unet_1d_condition.py:151-607) */
+int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out);
+int ns2vc_unet_destroy(ns2vc_unet* h);
+
+/* One call per state-dict tensor, keyed by the reference's parameter name
+ * (load_state_dict, inference/infer_tool.py:24-29; model.py:819-829).  `data` is a
+ * host or device pointer to contiguous fp32 of the given shape. */
+int ns2vc_unet_load_weight(ns2vc_unet* h, const char* key, const void* data, const int64_t* shape, int ndim);
+/* Checks that all tensors arrived, packs them for the chosen precision and uploads. */
+int ns2vc_unet_finalize_weights(ns2vc_unet* h, int precision);
+int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int buflen);
+
+/* Allocate workspace and build the launch plan for a (batch, frames, prompt frames) shape. */
+int ns2vc_unet_prepare(ns2vc_unet* h, int B, int T, int Lp);
+int ns2vc_unet_workspace_bytes(ns2vc_unet* h, size_t* out);
+
+/* Step-invariant work, once per utterance batch: add_embedding(prompt)
+ * (unet_1d_condition.py:869-870), the 32 cross-attention to_k/to_v(prompt)
+ * (attention_processor.py:1019-1020), the content half of conv_in over cat([x, content])
+ * (model.py:409, unet_1d_condition.py:943) and the mask -> bias conversion (:816-818).
+ * content (B, content_channels, T); prompt (B, Lp, cross_dim); mask (B, Lp) or NULL. */
+int ns2vc_unet_set_condition(ns2vc_unet* h, const float* content_bct, const float* prompt_blc, const uint8_t* mask_bl, void* stream);
+
+/* One denoiser evaluation = Diffusion_Encoder.forward (model.py:403-415) ->
+ * UNet1DConditionModel.forward (unet_1d_condition.py:743-1037) for the condition set above.
+ * x (B, latent_channels, T); t (B) fp32; out (B, latent_channels, T). */
+int ns2vc_unet_forward(ns2vc_unet* h, const float* x_bct, const float* t_b, float* out_bct, void* stream);
+
+/* ---- sampling loop (replaces DPM_Solver.sample sampler/dpm_solver.py:1171-1213 and
+ * UniPC.sample sampler/uni_pc.py:606-658 incl. the x_start wrapper :271-292/:170-191).
+ * `coef` = host array [steps][NS2VC_NCOEF] built by ns2vc_amd.schedule.build_table. */
+int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host);
+/* x (B, latent_channels, T): x_T in, sample out.  use_graph != 0 replays one captured
+ * hipGraph per step (no host sync inside the loop). */
+int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* stream);
+
+/* ---- introspection for tests / profiling -------------------------------------------- */
+int ns2vc_unet_set_debug(ns2vc_unet* h, int enable);  /* before prepare(): keep a copy of every block output */
+int ns2vc_unet_num_taps(ns2vc_unet* h);
+int ns2vc_unet_tap_info(ns2vc_unet* h, int idx, char* name, int buflen, int* rows, int* cols);
+int ns2vc_unet_tap_read(ns2vc_unet* h, int idx, float* host_dst);   /* synchronous, [rows][cols] channels-last */
+int ns2vc_unet_num_launches(ns2vc_unet* h, int* per_forward, int* per_condition);
+/* which: 0 = per-step forward plan, 1 = condition plan.  kind: 0 other, 1 implicit GEMM, 2 attention,
+ * 3 norm statistics, 4 copy.  flops / bytes: algorithmic work of that launch. */
+int ns2vc_unet_op_info(ns2vc_unet* h, int which, int idx, char* name, int buflen, int* kind, double* flops, double* bytes);
+/* Eager run of the per-step plan with a hipEvent pair around every launch; ms[n_ms >= launches]. Synchronous. */
+int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, void* stream);
+
+/* ---- raw device helpers so tests/bench can drive the ABI without torch ------------------ */
+int ns2vc_dev_malloc(void** out, size_t bytes);
+int ns2vc_dev_free(void* p);
+int ns2vc_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int ns2vc_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int ns2vc_dev_sync(void);
+int ns2vc_stream_create(void** out);
+int ns2vc_stream_destroy(void* stream);
+int ns2vc_stream_sync(void* stream);
+int ns2vc_event_create(void** out);
+int ns2vc_event_destroy(void* ev);
+int ns2vc_event_record(void* ev, void* stream);
+int ns2vc_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises on `stop` */
+
+/* ---- kernel-level entry points (unit-tested one by one through this ABI) -------------- */
+typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stride 2, nearest-up), linear */
+  const void* a0; const void* a1; /* channels-last fp32 sources; a1 = skip tensor of a no-copy concat or NULL */
+  int32_t lda0, lda1, c0, c1;
+  int32_t B, Tin, Tout, M;        /* M = B*Tout output rows */
+  int32_t taps, tmode;            /* taps 1|3; tmode 0 same, 1 stride-2, 2 nearest-upsample-then-conv */
+  const float* pscale; const float* pshift; /* per (batch, channel) affine prologue (GroupNorm apply) or NULL */
+  const float* rstats;            /* per-row (mean, rstd) prologue (LayerNorm apply) or NULL */
+  int32_t silu;
+  const void* w; int32_t K;       /* packed weights [N][K] from ns2vc_pack_weight */
+  int32_t N;
+  const float* bias;
+  const float* res; int32_t ldres;
+  int32_t geglu;
+  void* out; int32_t ldo;
+} ns2vc_gemm_args;
+
+typedef struct ns2vc_attn_args {
+  const void* q; const void* k; const void* v; /* fp32 rows; head h lives at columns [h*hd, (h+1)*hd) */
+  int32_t ldq, ldk, ldv;
+  int32_t B, H, Lq, Lk;
+  const float* bias;              /* additive [B][Lk] or NULL */
+  float scale;
+  void* out; int32_t ldo;
+} ns2vc_attn_args;
+
+int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
+int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
+int ns2vc_debug_set_gemm_tile(int bm, int bn); /* force the GEMM tile (128|64 x 128|64); 0,0 = heuristic */
+int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
+int ns2vc_k_groupnorm_coef(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
+                           const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off,
+                           float* pscale, float* pshift, void* stream);
+int ns2vc_k_layernorm_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, void* stream);
+int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream);
+int ns2vc_k_btc_to_nct(const float* src, int lds, int C, int T, int B, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NS2VC_HIP_H */

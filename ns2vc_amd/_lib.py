@@ -1,0 +1,135 @@
+"""ctypes binding of libns2vc_hip.so (include/ns2vc_hip.h).
+
+The library is built in-tree (``ns2vc_amd/lib/libns2vc_hip.so``) by
+``__graft_entry__.build()`` / ``make -C ns2vc_amd/csrc``.  There is NO fallback:
+if the shared object is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
+NCOEF = 12
+MAX_LEVELS = 8
+PREC_F32, PREC_BF16 = 0, 1
+
+
+class Ns2vcError(RuntimeError):
+    pass
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [
+        ("latent_channels", C.c_int32), ("content_channels", C.c_int32), ("n_levels", C.c_int32),
+        ("block_out_channels", C.c_int32 * MAX_LEVELS), ("norm_num_groups", C.c_int32),
+        ("cross_attention_dim", C.c_int32), ("heads", C.c_int32), ("layers_per_block", C.c_int32),
+        ("pool_heads", C.c_int32),
+    ]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p),
+        ("lda0", C.c_int32), ("lda1", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
+        ("B", C.c_int32), ("Tin", C.c_int32), ("Tout", C.c_int32), ("M", C.c_int32),
+        ("taps", C.c_int32), ("tmode", C.c_int32),
+        ("pscale", C.c_void_p), ("pshift", C.c_void_p), ("rstats", C.c_void_p),
+        ("silu", C.c_int32),
+        ("w", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int32), ("geglu", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+        ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32),
+        ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
+        ("bias", C.c_void_p), ("scale", C.c_float),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol the header declares
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_I = C.c_int
+PROTOTYPES = {
+    "ns2vc_abi_version": (_I, []),
+    "ns2vc_last_error": (C.c_char_p, []),
+    "ns2vc_device_count": (_I, [C.POINTER(_I)]),
+    "ns2vc_set_device": (_I, [_I]),
+    "ns2vc_device_name": (_I, [C.c_char_p, _I]),
+    "ns2vc_unet_create": (_I, [C.POINTER(UnetCfg), _PP]),
+    "ns2vc_unet_destroy": (_I, [_P]),
+    "ns2vc_unet_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I]),
+    "ns2vc_unet_finalize_weights": (_I, [_P, _I]),
+    "ns2vc_unet_num_missing_weights": (_I, [_P, C.c_char_p, _I]),
+    "ns2vc_unet_prepare": (_I, [_P, _I, _I, _I]),
+    "ns2vc_unet_workspace_bytes": (_I, [_P, C.POINTER(C.c_size_t)]),
+    "ns2vc_unet_set_condition": (_I, [_P, _P, _P, _P, _P]),
+    "ns2vc_unet_forward": (_I, [_P, _P, _P, _P, _P]),
+    "ns2vc_sampler_load": (_I, [_P, _I, C.POINTER(C.c_float)]),
+    "ns2vc_sampler_run": (_I, [_P, _P, _I, _P]),
+    "ns2vc_unet_set_debug": (_I, [_P, _I]),
+    "ns2vc_unet_num_taps": (_I, [_P]),
+    "ns2vc_unet_tap_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "ns2vc_unet_tap_read": (_I, [_P, _I, _P]),
+    "ns2vc_unet_num_launches": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "ns2vc_unet_op_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ns2vc_unet_profile_forward": (_I, [_P, C.POINTER(C.c_float), _I, _P]),
+    "ns2vc_dev_malloc": (_I, [_PP, C.c_size_t]),
+    "ns2vc_dev_free": (_I, [_P]),
+    "ns2vc_memcpy_h2d": (_I, [_P, _P, C.c_size_t]),
+    "ns2vc_memcpy_d2h": (_I, [_P, _P, C.c_size_t]),
+    "ns2vc_dev_sync": (_I, []),
+    "ns2vc_stream_create": (_I, [_PP]),
+    "ns2vc_stream_destroy": (_I, [_P]),
+    "ns2vc_stream_sync": (_I, [_P]),
+    "ns2vc_event_create": (_I, [_PP]),
+    "ns2vc_event_destroy": (_I, [_P]),
+    "ns2vc_event_record": (_I, [_P, _P]),
+    "ns2vc_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
+    "ns2vc_pack_weight": (_I, [_P, _I, _I, _I, _PP]),
+    "ns2vc_k_gemm": (_I, [C.POINTER(GemmArgs), _I, _P]),
+    "ns2vc_debug_set_gemm_tile": (_I, [_I, _I]),
+    "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
+    "ns2vc_k_groupnorm_coef": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "ns2vc_k_layernorm_stats": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
+    "ns2vc_k_nct_to_btc": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
+    "ns2vc_k_btc_to_nct": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the engine and bind every prototype.  Raises if the .so is absent
+    (build it with ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise Ns2vcError(f"{p} not found: the HIP engine is not built. Run __graft_entry__.build() "
+                         f"(or `make -C ns2vc_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ns2vc_abi_version() != 1:
+        raise Ns2vcError(f"ABI version mismatch: library reports {lib.ns2vc_abi_version()}, binding expects 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ns2vc_last_error()
+        raise Ns2vcError(f"{what}: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,1174 @@
+// Host side of libns2vc_hip.so: weight packing, workspace, launch plan,
+// hipGraph-captured sampling loop and the C ABI declared in include/ns2vc_hip.h.
+//
+// The plan restates the op sequence of the reference forward
+// (unet1d/unet_1d_condition.py:743-1037; blocks unet1d/unet_1d_blocks.py:949-1016,
+// 1071-1097, 602-623, 2070-2131, 2182-2207; resnet.py:591-641; transformer_1d.py:256-295;
+// attention.py:130-203) as a flat list of kernel launches on channels-last tensors.
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace ns2vc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+#define HIPCHK(expr)                                                                                       \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
+};
+
+struct PackedW {     // device-resident packed GEMM weight
+  void* w = nullptr;
+  float* bias = nullptr;
+  int N = 0, K = 0;
+};
+
+struct ResnetW {
+  std::string prefix;
+  int cin = 0, cout = 0, temb_off = 0;
+  bool shortcut = false;
+  float *n1g = nullptr, *n1b = nullptr, *n2g = nullptr, *n2b = nullptr;
+  PackedW conv1, conv2, sc;
+};
+struct AttnW {
+  std::string prefix;
+  int dim = 0, kv_off = 0;
+  float *ng = nullptr, *nb = nullptr;
+  PackedW proj_in, qkv, o1, q2, o2, ff1, ff2, proj_out;
+};
+struct BlockW {
+  std::string kind;   // down | mid | up
+  int index = 0, level = 0, channels = 0;
+  std::vector<ResnetW> res;
+  std::vector<AttnW> attn;
+  int sampler = 0;    // 0 none, 1 down, 2 up
+  PackedW samp;
+};
+
+struct Op {
+  std::string name;
+  std::function<hipError_t(hipStream_t)> fn;
+  int kind = 0;          // 0 other, 1 implicit GEMM, 2 attention, 3 norm statistics, 4 copy
+  double flops = 0.0;    // algorithmic FLOPs (2*MAC) of this launch
+  double bytes = 0.0;    // algorithmic (compulsory) HBM bytes: operands read once + result written once
+};
+struct Tap {
+  std::string name;
+  float* copy = nullptr;
+  int rows = 0, cols = 0;
+};
+
+}  // namespace
+
+struct ns2vc_unet {
+  ns2vc_unet_cfg cfg{};
+  std::map<std::string, HostTensor> raw;
+  std::vector<std::pair<std::string, std::vector<int64_t>>> expected;
+  int prec = -1;
+  bool finalized = false;
+  std::vector<void*> weight_allocs;
+
+  // packed weights
+  std::vector<BlockW> blocks;
+  PackedW conv_in_x, conv_in_c, conv_out, temb_all, kv_all, pool_qkv;
+  float *t_w1t = nullptr, *t_b1 = nullptr, *t_w2t = nullptr, *t_b2 = nullptr;
+  float *p_n1g = nullptr, *p_n1b = nullptr, *p_pos = nullptr, *p_projT = nullptr, *p_projb = nullptr, *p_n2g = nullptr, *p_n2b = nullptr;
+  float *out_ng = nullptr, *out_nb = nullptr;
+  int n_temb = 0, n_kv = 0;
+  int CP = 128;       // padded latent channels in the engine's channels-last x buffers
+
+  // workspace / plan
+  int B = 0, T = 0, Lp = 0;
+  void* arena = nullptr;
+  size_t arena_bytes = 0, arena_used = 0;
+  std::vector<Op> cond_ops, fwd_ops;
+  bool debug = false;
+  std::vector<Tap> taps;
+  bool has_mask = false;
+
+  // named persistent buffers
+  float *xe = nullptr, *xbar = nullptr, *d1 = nullptr, *mprev = nullptr, *x0 = nullptr;
+  float *content_btc = nullptr, *content_conv = nullptr, *prompt = nullptr, *maskbias = nullptr;
+  float *aug = nullptr, *emb = nullptr, *emb_act = nullptr, *temb = nullptr, *kv = nullptr;
+  float *seq = nullptr, *pool_qkv_buf = nullptr, *pooled = nullptr;
+  float *t_dev = nullptr;
+  uint8_t* mask_dev = nullptr;
+  int* step_dev = nullptr;
+  float* coef_dev = nullptr;
+  int steps = 0;
+  bool use_step_table = false;
+
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t step_graph = nullptr;
+
+  ~ns2vc_unet() {
+    if (step_graph) (void)hipGraphExecDestroy(step_graph);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (arena) (void)hipFree(arena);
+    if (coef_dev) (void)hipFree(coef_dev);
+    for (void* p : weight_allocs) (void)hipFree(p);
+  }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// topology (same rules as ns2vc_amd/spec.py::topology)
+// ------------------------------------------------------------------------------------
+std::vector<BlockW> make_topology(const ns2vc_unet_cfg& c) {
+  std::vector<BlockW> out;
+  const int n = c.n_levels;
+  int out_c = c.block_out_channels[0];
+  for (int i = 0; i < n; ++i) {
+    const int in_c = out_c;
+    out_c = c.block_out_channels[i];
+    BlockW b;
+    b.kind = "down"; b.index = i; b.level = i; b.channels = out_c;
+    const bool cross = (i != n - 1);      // ("CrossAttnDownBlock2D",)*3 + ("DownBlock2D",)
+    for (int j = 0; j < c.layers_per_block; ++j) {
+      ResnetW r;
+      r.prefix = "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+      r.cin = j == 0 ? in_c : out_c; r.cout = out_c; r.shortcut = r.cin != r.cout;
+      b.res.push_back(r);
+      if (cross) {
+        AttnW a;
+        a.prefix = "down_blocks." + std::to_string(i) + ".attentions." + std::to_string(j);
+        a.dim = out_c;
+        b.attn.push_back(a);
+      }
+    }
+    b.sampler = (i != n - 1) ? 1 : 0;
+    out.push_back(b);
+  }
+  {
+    BlockW m;
+    const int mc = c.block_out_channels[n - 1];
+    m.kind = "mid"; m.index = 0; m.level = n - 1; m.channels = mc;
+    for (int j = 0; j < 2; ++j) {
+      ResnetW r;
+      r.prefix = "mid_block.resnets." + std::to_string(j);
+      r.cin = r.cout = mc; r.shortcut = false;
+      m.res.push_back(r);
+    }
+    AttnW a;
+    a.prefix = "mid_block.attentions.0"; a.dim = mc;
+    m.attn.push_back(a);
+    out.push_back(m);
+  }
+  out_c = c.block_out_channels[n - 1];
+  for (int i = 0; i < n; ++i) {
+    const int prev_c = out_c;
+    out_c = c.block_out_channels[n - 1 - i];
+    const int in_c = c.block_out_channels[std::max(n - 2 - i, 0)];
+    BlockW b;
+    b.kind = "up"; b.index = i; b.level = n - 1 - i; b.channels = out_c;
+    const bool cross = (i != 0);          // ("UpBlock2D",) + ("CrossAttnUpBlock2D",)*3
+    const int nl = c.layers_per_block + 1;
+    for (int j = 0; j < nl; ++j) {
+      ResnetW r;
+      r.prefix = "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j);
+      const int skip_c = (j == nl - 1) ? in_c : out_c;
+      r.cin = (j == 0 ? prev_c : out_c) + skip_c; r.cout = out_c; r.shortcut = true;
+      b.res.push_back(r);
+      if (cross) {
+        AttnW a;
+        a.prefix = "up_blocks." + std::to_string(i) + ".attentions." + std::to_string(j);
+        a.dim = out_c;
+        b.attn.push_back(a);
+      }
+    }
+    b.sampler = (i != n - 1) ? 2 : 0;
+    out.push_back(b);
+  }
+  return out;
+}
+
+void expect(ns2vc_unet* h, const std::string& k, std::vector<int64_t> shape) { h->expected.emplace_back(k, std::move(shape)); }
+
+void build_expected(ns2vc_unet* h) {
+  const auto& c = h->cfg;
+  const int64_t c0 = c.block_out_channels[0], temb = 4 * c0, cross = c.cross_attention_dim;
+  const int64_t cin = c.latent_channels + c.content_channels;
+  expect(h, "conv_in.weight", {c0, cin, 3}); expect(h, "conv_in.bias", {c0});
+  expect(h, "time_embedding.linear_1.weight", {temb, c0}); expect(h, "time_embedding.linear_1.bias", {temb});
+  expect(h, "time_embedding.linear_2.weight", {temb, temb}); expect(h, "time_embedding.linear_2.bias", {temb});
+  expect(h, "add_embedding.norm1.weight", {cross}); expect(h, "add_embedding.norm1.bias", {cross});
+  expect(h, "add_embedding.pool.positional_embedding", {1, cross});
+  for (const char* p : {"k_proj", "q_proj", "v_proj"}) {
+    expect(h, std::string("add_embedding.pool.") + p + ".weight", {cross, cross});
+    expect(h, std::string("add_embedding.pool.") + p + ".bias", {cross});
+  }
+  expect(h, "add_embedding.proj.weight", {temb, cross}); expect(h, "add_embedding.proj.bias", {temb});
+  expect(h, "add_embedding.norm2.weight", {temb}); expect(h, "add_embedding.norm2.bias", {temb});
+  for (const auto& b : h->blocks) {
+    for (const auto& a : b.attn) {
+      const int64_t d = a.dim;
+      const std::string t = a.prefix + ".transformer_blocks.0";
+      expect(h, a.prefix + ".norm.weight", {d}); expect(h, a.prefix + ".norm.bias", {d});
+      expect(h, a.prefix + ".proj_in.weight", {d, d, 1}); expect(h, a.prefix + ".proj_in.bias", {d});
+      for (const char* nn : {"norm1", "norm2", "norm3"}) { expect(h, t + "." + nn + ".weight", {d}); expect(h, t + "." + nn + ".bias", {d}); }
+      expect(h, t + ".attn1.to_q.weight", {d, d}); expect(h, t + ".attn1.to_k.weight", {d, d}); expect(h, t + ".attn1.to_v.weight", {d, d});
+      expect(h, t + ".attn1.to_out.0.weight", {d, d}); expect(h, t + ".attn1.to_out.0.bias", {d});
+      expect(h, t + ".attn2.to_q.weight", {d, d}); expect(h, t + ".attn2.to_k.weight", {d, cross}); expect(h, t + ".attn2.to_v.weight", {d, cross});
+      expect(h, t + ".attn2.to_out.0.weight", {d, d}); expect(h, t + ".attn2.to_out.0.bias", {d});
+      expect(h, t + ".ff.net.0.proj.weight", {8 * d, d}); expect(h, t + ".ff.net.0.proj.bias", {8 * d});
+      expect(h, t + ".ff.net.2.weight", {d, 4 * d}); expect(h, t + ".ff.net.2.bias", {d});
+      expect(h, a.prefix + ".proj_out.weight", {d, d, 1}); expect(h, a.prefix + ".proj_out.bias", {d});
+    }
+    for (const auto& r : b.res) {
+      expect(h, r.prefix + ".norm1.weight", {r.cin}); expect(h, r.prefix + ".norm1.bias", {r.cin});
+      expect(h, r.prefix + ".conv1.weight", {r.cout, r.cin, 3}); expect(h, r.prefix + ".conv1.bias", {r.cout});
+      expect(h, r.prefix + ".time_emb_proj.weight", {2 * r.cout, temb}); expect(h, r.prefix + ".time_emb_proj.bias", {2 * r.cout});
+      expect(h, r.prefix + ".norm2.weight", {r.cout}); expect(h, r.prefix + ".norm2.bias", {r.cout});
+      expect(h, r.prefix + ".conv2.weight", {r.cout, r.cout, 3}); expect(h, r.prefix + ".conv2.bias", {r.cout});
+      if (r.shortcut) { expect(h, r.prefix + ".conv_shortcut.weight", {r.cout, r.cin, 1}); expect(h, r.prefix + ".conv_shortcut.bias", {r.cout}); }
+    }
+    if (b.sampler) {
+      const std::string p = b.kind == "down" ? "down_blocks." + std::to_string(b.index) + ".downsamplers.0.conv"
+                                             : "up_blocks." + std::to_string(b.index) + ".upsamplers.0.conv";
+      expect(h, p + ".weight", {b.channels, b.channels, 3}); expect(h, p + ".bias", {b.channels});
+    }
+  }
+  expect(h, "conv_norm_out.weight", {c0}); expect(h, "conv_norm_out.bias", {c0});
+  expect(h, "conv_out.weight", {c.latent_channels, c0, 3}); expect(h, "conv_out.bias", {c.latent_channels});
+}
+
+// ------------------------------------------------------------------------------------
+// weight packing (host, fp32/double) -> device
+// ------------------------------------------------------------------------------------
+struct Packer {
+  ns2vc_unet* h;
+  int err = 0;
+
+  const HostTensor& T(const std::string& k) {
+    auto it = h->raw.find(k);
+    if (it == h->raw.end()) { err = fail("weight %s missing", k.c_str()); static HostTensor empty; return empty; }
+    return it->second;
+  }
+  float* upload_f32(const std::vector<float>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(float)) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return nullptr; }
+    h->weight_allocs.push_back(d);
+    if (hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed (weights)");
+    return (float*)d;
+  }
+  float* vec(const std::string& k) { return upload_f32(T(k).data); }
+
+  // rows: [N][K] fp32, bias: [N] or empty.  Pads N to a multiple of 128 with zero rows.
+  PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias) {
+    PackedW p;
+    const int Np = round_up(N, 128);
+    p.N = Np; p.K = K;
+    void* d = nullptr;
+    if (h->prec == PREC_BF16) {
+      std::vector<uint16_t> q((size_t)Np * K, 0);
+      for (size_t i = 0; i < (size_t)N * K; ++i) q[i] = f32_to_bf16_bits(rows[i]);
+      if (hipMalloc(&d, q.size() * 2) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return p; }
+      h->weight_allocs.push_back(d);
+      if (hipMemcpy(d, q.data(), q.size() * 2, hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed");
+    } else {
+      std::vector<float> q((size_t)Np * K, 0.f);
+      memcpy(q.data(), rows.data(), (size_t)N * K * sizeof(float));
+      if (hipMalloc(&d, q.size() * 4) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return p; }
+      h->weight_allocs.push_back(d);
+      if (hipMemcpy(d, q.data(), q.size() * 4, hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed");
+    }
+    p.w = d;
+    if (!bias.empty()) {
+      std::vector<float> bb(Np, 0.f);
+      memcpy(bb.data(), bias.data(), (size_t)N * sizeof(float));
+      p.bias = upload_f32(bb);
+    }
+    return p;
+  }
+
+  // conv weight (Cout, Cin, taps) -> rows [Cout][tap*CinP + c'], channels [c_lo, c_hi) of the input, padded to CinP
+  std::vector<float> conv_rows(const HostTensor& w, int c_lo, int c_hi, int CinP) {
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], taps = (int)w.shape[2];
+    std::vector<float> rows((size_t)Cout * taps * CinP, 0.f);
+    for (int n = 0; n < Cout; ++n)
+      for (int c = c_lo; c < c_hi; ++c)
+        for (int t = 0; t < taps; ++t) rows[((size_t)n * taps + t) * CinP + (c - c_lo)] = w.data[((size_t)n * Cin + c) * taps + t];
+    return rows;
+  }
+  PackedW conv(const std::string& prefix) {
+    const HostTensor& w = T(prefix + ".weight");
+    if (err) return {};
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], taps = (int)w.shape[2];
+    return pack(conv_rows(w, 0, Cin, Cin), Cout, taps * Cin, T(prefix + ".bias").data);
+  }
+  // Linear whose input is LayerNorm(x): fold gamma into W and beta into the bias.
+  void ln_fold(const HostTensor& w, const HostTensor* b, const HostTensor& g, const HostTensor& be, std::vector<float>& rows,
+               std::vector<float>& bias) {
+    const int N = (int)w.shape[0], K = (int)w.shape[1];
+    const size_t r0 = rows.size(), b0 = bias.size();
+    rows.resize(r0 + (size_t)N * K);
+    bias.resize(b0 + N);
+    for (int n = 0; n < N; ++n) {
+      double acc = b ? (double)b->data[n] : 0.0;
+      for (int k = 0; k < K; ++k) {
+        const float wv = w.data[(size_t)n * K + k];
+        rows[r0 + (size_t)n * K + k] = wv * g.data[k];
+        acc += (double)wv * (double)be.data[k];
+      }
+      bias[b0 + n] = (float)acc;
+    }
+  }
+};
+
+int pack_all(ns2vc_unet* h) {
+  Packer P{h};
+  const auto& c = h->cfg;
+  const int c0 = c.block_out_channels[0], temb = 4 * c0, cross = c.cross_attention_dim;
+  const int lat = c.latent_channels, CP = h->CP;
+  // conv_in split: x part (latent channels, padded to CP) per step, content part hoisted
+  {
+    const HostTensor& w = P.T("conv_in.weight");
+    if (P.err) return 1;
+    h->conv_in_x = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {});
+    h->conv_in_c = P.pack(P.conv_rows(w, lat, lat + c.content_channels, c.content_channels), c0, 3 * c.content_channels, P.T("conv_in.bias").data);
+  }
+  // time MLP, transposed to [in][out] for coalesced GEMV reads
+  auto transpose = [&](const HostTensor& w) {
+    const int N = (int)w.shape[0], K = (int)w.shape[1];
+    std::vector<float> t((size_t)N * K);
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) t[(size_t)k * N + n] = w.data[(size_t)n * K + k];
+    return t;
+  };
+  h->t_w1t = P.upload_f32(transpose(P.T("time_embedding.linear_1.weight"))); h->t_b1 = P.vec("time_embedding.linear_1.bias");
+  h->t_w2t = P.upload_f32(transpose(P.T("time_embedding.linear_2.weight"))); h->t_b2 = P.vec("time_embedding.linear_2.bias");
+  // add_embedding
+  h->p_n1g = P.vec("add_embedding.norm1.weight"); h->p_n1b = P.vec("add_embedding.norm1.bias");
+  h->p_pos = P.vec("add_embedding.pool.positional_embedding");
+  {
+    std::vector<float> rows, bias;
+    for (const char* p : {"q_proj", "k_proj", "v_proj"}) {
+      const HostTensor& w = P.T(std::string("add_embedding.pool.") + p + ".weight");
+      const HostTensor& b = P.T(std::string("add_embedding.pool.") + p + ".bias");
+      if (P.err) return 1;
+      rows.insert(rows.end(), w.data.begin(), w.data.end());
+      bias.insert(bias.end(), b.data.begin(), b.data.end());
+    }
+    h->pool_qkv = P.pack(rows, 3 * cross, cross, bias);
+  }
+  h->p_projT = P.upload_f32(transpose(P.T("add_embedding.proj.weight"))); h->p_projb = P.vec("add_embedding.proj.bias");
+  h->p_n2g = P.vec("add_embedding.norm2.weight"); h->p_n2b = P.vec("add_embedding.norm2.bias");
+  if (P.err) return 1;
+
+  std::vector<float> temb_rows, temb_bias, kv_rows;
+  int temb_off = 0, kv_off = 0;
+  for (auto& b : h->blocks) {
+    for (auto& r : b.res) {
+      r.n1g = P.vec(r.prefix + ".norm1.weight"); r.n1b = P.vec(r.prefix + ".norm1.bias");
+      r.n2g = P.vec(r.prefix + ".norm2.weight"); r.n2b = P.vec(r.prefix + ".norm2.bias");
+      r.conv1 = P.conv(r.prefix + ".conv1");
+      r.conv2 = P.conv(r.prefix + ".conv2");
+      if (r.shortcut) r.sc = P.conv(r.prefix + ".conv_shortcut");
+      const HostTensor& tw = P.T(r.prefix + ".time_emb_proj.weight");
+      const HostTensor& tb = P.T(r.prefix + ".time_emb_proj.bias");
+      if (P.err) return 1;
+      r.temb_off = temb_off;
+      temb_rows.insert(temb_rows.end(), tw.data.begin(), tw.data.end());
+      temb_bias.insert(temb_bias.end(), tb.data.begin(), tb.data.end());
+      temb_off += 2 * r.cout;
+    }
+    for (auto& a : b.attn) {
+      const std::string t = a.prefix + ".transformer_blocks.0";
+      const int d = a.dim;
+      a.ng = P.vec(a.prefix + ".norm.weight"); a.nb = P.vec(a.prefix + ".norm.bias");
+      a.proj_in = P.conv(a.prefix + ".proj_in");
+      a.proj_out = P.conv(a.prefix + ".proj_out");
+      {  // fused q|k|v of the self-attention, LayerNorm(norm1) folded in
+        std::vector<float> rows, bias;
+        for (const char* nm : {"to_q", "to_k", "to_v"}) P.ln_fold(P.T(t + ".attn1." + nm + ".weight"), nullptr, P.T(t + ".norm1.weight"), P.T(t + ".norm1.bias"), rows, bias);
+        if (P.err) return 1;
+        a.qkv = P.pack(rows, 3 * d, d, bias);
+      }
+      a.o1 = P.pack(P.T(t + ".attn1.to_out.0.weight").data, d, d, P.T(t + ".attn1.to_out.0.bias").data);
+      {
+        std::vector<float> rows, bias;
+        P.ln_fold(P.T(t + ".attn2.to_q.weight"), nullptr, P.T(t + ".norm2.weight"), P.T(t + ".norm2.bias"), rows, bias);
+        if (P.err) return 1;
+        a.q2 = P.pack(rows, d, d, bias);
+      }
+      a.o2 = P.pack(P.T(t + ".attn2.to_out.0.weight").data, d, d, P.T(t + ".attn2.to_out.0.bias").data);
+      {  // GEGLU projection: LayerNorm(norm3) folded, rows interleaved in (32 value | 32 gate) groups
+        std::vector<float> rows, bias;
+        P.ln_fold(P.T(t + ".ff.net.0.proj.weight"), &P.T(t + ".ff.net.0.proj.bias"), P.T(t + ".norm3.weight"), P.T(t + ".norm3.bias"), rows, bias);
+        if (P.err) return 1;
+        const int inner = 4 * d;
+        std::vector<float> rows2((size_t)8 * d * d), bias2(8 * d);
+        for (int gidx = 0; gidx < inner / 32; ++gidx)
+          for (int i = 0; i < 32; ++i) {
+            const int v_src = 32 * gidx + i, g_src = inner + 32 * gidx + i;
+            const int v_dst = 64 * gidx + i, g_dst = 64 * gidx + 32 + i;
+            memcpy(&rows2[(size_t)v_dst * d], &rows[(size_t)v_src * d], d * sizeof(float));
+            memcpy(&rows2[(size_t)g_dst * d], &rows[(size_t)g_src * d], d * sizeof(float));
+            bias2[v_dst] = bias[v_src];
+            bias2[g_dst] = bias[g_src];
+          }
+        a.ff1 = P.pack(rows2, 8 * d, d, bias2);
+      }
+      a.ff2 = P.pack(P.T(t + ".ff.net.2.weight").data, d, 4 * d, P.T(t + ".ff.net.2.bias").data);
+      {  // cross-attention k|v of this block into the hoisted all-blocks projection
+        const HostTensor& wk = P.T(t + ".attn2.to_k.weight");
+        const HostTensor& wv = P.T(t + ".attn2.to_v.weight");
+        if (P.err) return 1;
+        a.kv_off = kv_off;
+        kv_rows.insert(kv_rows.end(), wk.data.begin(), wk.data.end());
+        kv_rows.insert(kv_rows.end(), wv.data.begin(), wv.data.end());
+        kv_off += 2 * d;
+      }
+    }
+    if (b.sampler) {
+      const std::string p = b.kind == "down" ? "down_blocks." + std::to_string(b.index) + ".downsamplers.0.conv"
+                                             : "up_blocks." + std::to_string(b.index) + ".upsamplers.0.conv";
+      b.samp = P.conv(p);
+    }
+    if (P.err) return 1;
+  }
+  h->n_temb = temb_off;
+  h->temb_all = P.pack(temb_rows, temb_off, temb, temb_bias);
+  h->n_kv = kv_off;
+  h->kv_all = P.pack(kv_rows, kv_off, cross, {});
+  h->out_ng = P.vec("conv_norm_out.weight"); h->out_nb = P.vec("conv_norm_out.bias");
+  {
+    const HostTensor& w = P.T("conv_out.weight");
+    if (P.err) return 1;
+    h->conv_out = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data);
+  }
+  return P.err;
+}
+
+// ------------------------------------------------------------------------------------
+// plan building
+// ------------------------------------------------------------------------------------
+struct Planner {
+  ns2vc_unet* h;
+  std::vector<Op>* ops;
+  bool sizing = false;       // first pass: only measure the arena
+  size_t off = 0;
+  int B, T, Lp, G, prec;
+  // scratch shared by all layers (stream-ordered)
+  double* gn_partial = nullptr;
+  float *ps = nullptr, *ph = nullptr, *rstats = nullptr;
+  int gn_rows = 64;
+
+  template <typename Tp> Tp* alloc(size_t count) {
+    const size_t bytes = (count * sizeof(Tp) + 255) & ~(size_t)255;
+    Tp* p = sizing ? nullptr : reinterpret_cast<Tp*>(reinterpret_cast<char*>(h->arena) + off);
+    off += bytes;
+    return p;
+  }
+  void add(const std::string& name, std::function<hipError_t(hipStream_t)> fn, int kind = 0, double flops = 0.0, double bytes = 0.0) {
+    if (sizing) return;
+    Op op;
+    op.name = name; op.fn = std::move(fn); op.kind = kind; op.flops = flops; op.bytes = bytes;
+    ops->push_back(std::move(op));
+  }
+  void tap(const std::string& name, const float* src, int rows, int cols) {
+    if (!h->debug) return;
+    float* cp = alloc<float>((size_t)rows * cols);
+    if (sizing) return;
+    h->taps.push_back({name, cp, rows, cols});
+    const size_t bytes = (size_t)rows * cols * sizeof(float);
+    add("tap:" + name, [=](hipStream_t s) { return hipMemcpyAsync(cp, src, bytes, hipMemcpyDeviceToDevice, s); }, 4, 0.0, 2.0 * bytes);
+  }
+
+  void gemm(const std::string& name, GemmArgs g) {
+    const int pr = prec;
+    const double wsz = pr == PREC_BF16 ? 2.0 : 4.0;
+    const double nout = g.geglu ? g.N / 2 : g.N;
+    const double flops = 2.0 * g.M * (double)g.N * g.K;
+    const double in_rows = (double)g.B * g.Tin;
+    const double bytes = in_rows * (g.c0 + g.c1) * 4.0 + (double)g.N * g.K * wsz + g.M * nout * 4.0 + (g.res ? g.M * nout * 4.0 : 0.0);
+    add(name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes);
+  }
+  GemmArgs base(const float* a0, int lda0, int c0, int Tin, int Tout, const PackedW& w, float* out, int ldo) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a0 = a0; g.lda0 = lda0; g.c0 = c0;
+    g.B = B; g.Tin = Tin; g.Tout = Tout; g.M = B * Tout;
+    g.taps = 1; g.tmode = TMODE_SAME;
+    g.w = w.w; g.K = w.K; g.N = w.N; g.bias = w.bias;
+    g.out = out; g.ldo = ldo;
+    return g;
+  }
+  // GroupNorm statistics + per-(b,c) affine for a (possibly concatenated) input
+  void groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
+                 const float* gamma, const float* beta, const float* temb, int temb_off, int cout) {
+    const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N;
+    double* part = gn_partial; float* ps_ = ps; float* ph_ = ph;
+    add(name + ".gn_stats", [=](hipStream_t s) { return launch_gn_partial(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, part, nchunk, rows, s); },
+        3, 3.0 * Bq * Tl * (c0 + c1), 4.0 * Bq * Tl * (c0 + c1));
+    add(name + ".gn_coef", [=](hipStream_t s) {
+      return launch_gn_coef(part, nchunk, Bq, Tl, c0 + c1, Gq, eps, gamma, beta, temb, ldt, temb_off, cout, ps_, ph_, s);
+    });
+  }
+
+  void resnet(const ResnetW& r, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float* h1, float* sc,
+              float* out) {
+    const auto& c = h->cfg;
+    (void)c;
+    groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0);
+    GemmArgs g = base(a0, lda0, c0, Tl, Tl, r.conv1, h1, r.cout);
+    g.a1 = a1; g.lda1 = lda1; g.c1 = c1; g.taps = 3;
+    g.pscale = ps; g.pshift = ph; g.silu = 1;
+    gemm(r.prefix + ".conv1", g);
+    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout);
+    const float* res; int ldres;
+    if (r.shortcut) {
+      GemmArgs s = base(a0, lda0, c0, Tl, Tl, r.sc, sc, r.cout);
+      s.a1 = a1; s.lda1 = lda1; s.c1 = c1;
+      gemm(r.prefix + ".conv_shortcut", s);
+      res = sc; ldres = r.cout;
+    } else {
+      res = a0; ldres = lda0;
+    }
+    GemmArgs g2 = base(h1, r.cout, r.cout, Tl, Tl, r.conv2, out, r.cout);
+    g2.taps = 3; g2.pscale = ps; g2.pshift = ph; g2.silu = 1;
+    g2.res = res; g2.ldres = ldres;
+    gemm(r.prefix + ".conv2", g2);
+  }
+
+  void attention(const std::string& name, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int Lq, int Lk,
+                 const float* bias, int hd, float* out, int ldo) {
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.B = B; a.H = h->cfg.heads; a.Lq = Lq; a.Lk = Lk; a.bias = bias;
+    a.scale = 1.0f / std::sqrt((float)hd);
+    a.out = out; a.ldo = ldo;
+    const int pr = prec;
+    add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd,
+        4.0 * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
+  }
+
+  void transformer(const AttnW& a, const float* x, int Tl, float* y, float* qkv, float* ao, float* qb, float* ffh, float* out) {
+    const int d = a.dim, M = B * Tl, hd = d / h->cfg.heads;
+    const std::string t = a.prefix + ".transformer_blocks.0";
+    groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0);
+    GemmArgs g = base(x, d, d, Tl, Tl, a.proj_in, y, d);
+    g.pscale = ps; g.pshift = ph; g.silu = 0;
+    gemm(a.prefix + ".proj_in", g);
+    float* rs = rstats;
+    auto lnstats = [&](const std::string& nm) {
+      add(nm, [=](hipStream_t s) { return launch_ln_stats(y, d, M, d, 1e-5f, rs, s); }, 3, 4.0 * M * d, 4.0 * M * d);
+    };
+    // self attention
+    lnstats(t + ".norm1");
+    g = base(y, d, d, Tl, Tl, a.qkv, qkv, 3 * d);
+    g.rstats = rstats;
+    gemm(t + ".attn1.qkv", g);
+    attention(t + ".attn1.sdpa", qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, Tl, Tl, nullptr, hd, ao, d);
+    g = base(ao, d, d, Tl, Tl, a.o1, y, d);
+    g.res = y; g.ldres = d;
+    gemm(t + ".attn1.to_out", g);
+    // cross attention (k|v hoisted into h->kv by set_condition)
+    lnstats(t + ".norm2");
+    g = base(y, d, d, Tl, Tl, a.q2, qb, d);
+    g.rstats = rstats;
+    gemm(t + ".attn2.to_q", g);
+    const int nkv = h->kv_all.N;
+    attention(t + ".attn2.sdpa", qb, d, h->kv + a.kv_off, nkv, h->kv + a.kv_off + d, nkv, Tl, Lp, h->has_mask ? h->maskbias : nullptr, hd, ao, d);
+    g = base(ao, d, d, Tl, Tl, a.o2, y, d);
+    g.res = y; g.ldres = d;
+    gemm(t + ".attn2.to_out", g);
+    // feed-forward (GEGLU)
+    lnstats(t + ".norm3");
+    g = base(y, d, d, Tl, Tl, a.ff1, ffh, 4 * d);
+    g.rstats = rstats; g.geglu = 1;
+    gemm(t + ".ff.geglu", g);
+    g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ff2, y, d);
+    g.res = y; g.ldres = d;
+    gemm(t + ".ff.out", g);
+    g = base(y, d, d, Tl, Tl, a.proj_out, out, d);
+    g.res = x; g.ldres = d;
+    gemm(a.prefix + ".proj_out", g);
+  }
+};
+
+int build_plan(ns2vc_unet* h, bool sizing) {
+  const auto& c = h->cfg;
+  const int B = h->B, T = h->T, Lp = h->Lp, nl = c.n_levels;
+  const int c0 = c.block_out_channels[0], E = 4 * c0, cross = c.cross_attention_dim, CP = h->CP;
+  std::vector<int> Ts(nl);
+  Ts[0] = T;
+  for (int l = 1; l < nl; ++l) Ts[l] = (Ts[l - 1] + 1) / 2;
+
+  Planner P;
+  P.h = h; P.sizing = sizing; P.B = B; P.T = T; P.Lp = Lp; P.G = c.norm_num_groups; P.prec = h->prec;
+  if (!sizing) { h->cond_ops.clear(); h->fwd_ops.clear(); h->taps.clear(); }
+
+  size_t maxMC = 0;   // max over levels of B*Tl*Cl
+  int maxC = 0;
+  for (int l = 0; l < nl; ++l) {
+    maxMC = std::max(maxMC, (size_t)B * Ts[l] * c.block_out_channels[l]);
+    maxC = std::max(maxC, c.block_out_channels[l]);
+  }
+  // ---- persistent state
+  h->xe = P.alloc<float>((size_t)B * T * CP); h->xbar = P.alloc<float>((size_t)B * T * CP);
+  h->d1 = P.alloc<float>((size_t)B * T * CP); h->mprev = P.alloc<float>((size_t)B * T * CP);
+  h->x0 = P.alloc<float>((size_t)B * T * CP);
+  h->content_btc = P.alloc<float>((size_t)B * T * c.content_channels);
+  h->content_conv = P.alloc<float>((size_t)B * T * c0);
+  h->prompt = P.alloc<float>((size_t)B * Lp * cross);
+  h->maskbias = P.alloc<float>((size_t)B * Lp);
+  h->mask_dev = P.alloc<uint8_t>((size_t)B * Lp);
+  h->aug = P.alloc<float>((size_t)B * E); h->emb = P.alloc<float>((size_t)B * E); h->emb_act = P.alloc<float>((size_t)B * E);
+  h->temb = P.alloc<float>((size_t)B * h->temb_all.N);
+  h->kv = P.alloc<float>((size_t)B * Lp * h->kv_all.N);
+  h->seq = P.alloc<float>((size_t)B * (Lp + 1) * cross);
+  h->pool_qkv_buf = P.alloc<float>((size_t)B * (Lp + 1) * h->pool_qkv.N);
+  h->pooled = P.alloc<float>((size_t)B * cross);
+  h->t_dev = P.alloc<float>((size_t)B);
+  h->step_dev = P.alloc<int>(64);
+  // ---- shared scratch
+  P.gn_rows = 64;
+  P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
+  P.ps = P.alloc<float>((size_t)B * 2 * maxC); P.ph = P.alloc<float>((size_t)B * 2 * maxC);
+  P.rstats = P.alloc<float>((size_t)B * std::max(T, Lp + 1) * 2);
+  float* h1 = P.alloc<float>(maxMC);
+  float* scb = P.alloc<float>(maxMC);
+  float* y = P.alloc<float>(maxMC);
+  float* qkv = P.alloc<float>(3 * maxMC);
+  float* ao = P.alloc<float>(maxMC);
+  float* qb = P.alloc<float>(maxMC);
+  float* ffh = P.alloc<float>(4 * maxMC);
+  float* ua = P.alloc<float>(maxMC);
+  float* ub = P.alloc<float>(maxMC);
+  float* uc = P.alloc<float>(maxMC);
+
+  // ================= condition plan (once per utterance batch) =================
+  P.ops = &h->cond_ops;
+  {
+    float *prompt = h->prompt, *seq = h->seq, *pq = h->pool_qkv_buf, *pooled = h->pooled, *aug = h->aug;
+    // content half of conv_in (+ conv_in bias)
+    GemmArgs g = P.base(h->content_btc, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, c0);
+    g.taps = 3;
+    P.gemm("cond.conv_in.content", g);
+    // all cross-attention k|v projections in one GEMM: prompt [B*Lp][cross] x [n_kv][cross]^T
+    g = P.base(prompt, cross, cross, Lp, Lp, h->kv_all, h->kv, h->kv_all.N);
+    P.gemm("cond.cross_kv", g);
+    // add_embedding = TextTimeEmbedding(prompt)
+    const float *n1g = h->p_n1g, *n1b = h->p_n1b, *pos = h->p_pos, *projT = h->p_projT, *projb = h->p_projb, *n2g = h->p_n2g, *n2b = h->p_n2b;
+    const int ph_ = c.pool_heads;
+    P.add("cond.pool.ln1", [=](hipStream_t s) { return launch_ln_apply(prompt, B * Lp, cross, 1e-5f, n1g, n1b, seq, Lp, 0, s); });
+    P.add("cond.pool.cls", [=](hipStream_t s) { return launch_pool_cls(seq, B, Lp, cross, pos, s); });
+    g = P.base(seq, cross, cross, Lp + 1, Lp + 1, h->pool_qkv, pq, h->pool_qkv.N);
+    P.gemm("cond.pool.qkv", g);
+    const int ldq = h->pool_qkv.N;
+    if (ldq != 3 * cross) return fail("pool qkv width %d must equal 3*cross=%d (cross must be a multiple of 128)", ldq, 3 * cross);
+    P.add("cond.pool.attn", [=](hipStream_t s) { return launch_pool_attn(pq, B, Lp + 1, cross, ph_, pooled, s); });
+    P.add("cond.pool.proj", [=](hipStream_t s) { return launch_pool_proj(pooled, B, cross, projT, projb, E, n2g, n2b, 1e-5f, aug, s); });
+    P.tap("aug", aug, B, E);
+  }
+
+  // ================= per-step forward plan =================
+  P.ops = &h->fwd_ops;
+  {
+    ns2vc_unet* hh = h;
+    const float *w1t = h->t_w1t, *b1 = h->t_b1, *w2t = h->t_w2t, *b2 = h->t_b2, *aug = h->aug;
+    float *emb = h->emb, *emb_act = h->emb_act, *tdev = h->t_dev;
+    const int tdim = c0;
+    P.add("time_embed", [=](hipStream_t s) {
+      if (hh->use_step_table) return launch_time_embed(hh->coef_dev, 0, hh->step_dev, NS2VC_NCOEF, w1t, b1, w2t, b2, aug, emb, emb_act, B, tdim, E, s);
+      return launch_time_embed(tdev, 1, nullptr, 0, w1t, b1, w2t, b2, aug, emb, emb_act, B, tdim, E, s);
+    });
+    P.tap("emb", emb, B, E);
+    // every resnet's time_emb_proj(SiLU(emb)) in one GEMM (M = B)
+    GemmArgs g = P.base(emb_act, E, E, 1, 1, h->temb_all, h->temb, h->temb_all.N);
+    P.gemm("time_emb_proj.all", g);
+  }
+  // skip stack
+  struct Skip { float* p; int C; int l; };
+  std::vector<Skip> skips;
+  auto new_skip = [&](int l) { float* p = P.alloc<float>((size_t)B * Ts[l] * c.block_out_channels[l]); skips.push_back({p, c.block_out_channels[l], l}); return p; };
+  {
+    float* s0 = new_skip(0);
+    GemmArgs g = P.base(h->xe, CP, CP, T, T, h->conv_in_x, s0, c0);
+    g.taps = 3; g.res = h->content_conv; g.ldres = c0;
+    P.gemm("conv_in", g);
+    P.tap("conv_in", s0, B * T, c0);
+  }
+  const float* cur = skips.back().p;
+  int curC = c0;
+  for (const auto& b : h->blocks) {
+    const int l = b.level, Tl = Ts[l];
+    const std::string tag = b.kind == "mid" ? "mid" : b.kind + std::to_string(b.index);
+    if (b.kind == "down") {
+      for (size_t j = 0; j < b.res.size(); ++j) {
+        const bool has_attn = !b.attn.empty();
+        float* rout = has_attn ? ua : new_skip(l);
+        P.resnet(b.res[j], cur, curC, curC, nullptr, 0, 0, Tl, h1, scb, rout);
+        P.tap(tag + ".res" + std::to_string(j), rout, B * Tl, b.channels);
+        cur = rout; curC = b.channels;
+        if (has_attn) {
+          float* aout = new_skip(l);
+          P.transformer(b.attn[j], cur, Tl, y, qkv, ao, qb, ffh, aout);
+          P.tap(tag + ".attn" + std::to_string(j), aout, B * Tl, b.channels);
+          cur = aout;
+        }
+      }
+      if (b.sampler == 1) {
+        float* ds = new_skip(l + 1);
+        // note: skip channel count is this block's channels, at the next level's length
+        skips.back().C = b.channels;
+        GemmArgs g = P.base(cur, curC, curC, Tl, Ts[l + 1], b.samp, ds, b.channels);
+        g.taps = 3; g.tmode = TMODE_DOWN2;
+        P.gemm(tag + ".downsample", g);
+        P.tap(tag + ".ds", ds, B * Ts[l + 1], b.channels);
+        cur = ds;
+      }
+    } else if (b.kind == "mid") {
+      P.resnet(b.res[0], cur, curC, curC, nullptr, 0, 0, Tl, h1, scb, ua);
+      P.tap("mid.res0", ua, B * Tl, b.channels);
+      P.transformer(b.attn[0], ua, Tl, y, qkv, ao, qb, ffh, ub);
+      P.tap("mid.attn0", ub, B * Tl, b.channels);
+      P.resnet(b.res[1], ub, b.channels, b.channels, nullptr, 0, 0, Tl, h1, scb, uc);
+      P.tap("mid.res1", uc, B * Tl, b.channels);
+      cur = uc; curC = b.channels;
+    } else {
+      for (size_t j = 0; j < b.res.size(); ++j) {
+        const Skip sk = skips.back();
+        skips.pop_back();
+        if (sk.l != l) return fail("internal: skip level mismatch at %s", b.res[j].prefix.c_str());
+        if (curC + sk.C != b.res[j].cin) return fail("internal: concat width %d+%d != %d at %s", curC, sk.C, b.res[j].cin, b.res[j].prefix.c_str());
+        float* rout = (cur == ua) ? ub : ua;
+        if (rout == cur) rout = uc;
+        P.resnet(b.res[j], cur, curC, curC, sk.p, sk.C, sk.C, Tl, h1, scb, rout);
+        P.tap(tag + ".res" + std::to_string(j), rout, B * Tl, b.channels);
+        cur = rout; curC = b.channels;
+        if (!b.attn.empty()) {
+          float* aout = (cur == ua) ? ub : ua;
+          P.transformer(b.attn[j], cur, Tl, y, qkv, ao, qb, ffh, aout);
+          P.tap(tag + ".attn" + std::to_string(j), aout, B * Tl, b.channels);
+          cur = aout;
+        }
+      }
+      if (b.sampler == 2) {
+        float* us = (cur == uc) ? ua : uc;
+        GemmArgs g = P.base(cur, curC, curC, Tl, Ts[l - 1], b.samp, us, b.channels);
+        g.taps = 3; g.tmode = TMODE_UP2;
+        P.gemm(tag + ".upsample", g);
+        P.tap(tag + ".us", us, B * Ts[l - 1], b.channels);
+        cur = us;
+      }
+    }
+  }
+  if (!skips.empty()) return fail("internal: %zu skips left over", skips.size());
+  {
+    P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0);
+    GemmArgs g = P.base(cur, curC, curC, T, T, h->conv_out, h->x0, CP);
+    g.taps = 3; g.pscale = P.ps; g.pshift = P.ph; g.silu = 1;
+    if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
+    P.gemm("conv_out", g);
+    P.tap("out", h->x0, B * T, CP);
+  }
+  if (sizing) h->arena_bytes = P.off;
+  h->arena_used = P.off;
+  return 0;
+}
+
+int run_ops(const std::vector<Op>& ops, hipStream_t s) {
+  for (const auto& op : ops) {
+    hipError_t e = op.fn(s);
+    if (e != hipSuccess) return fail("launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
+  }
+  return 0;
+}
+
+int check_ready(ns2vc_unet* h, bool need_plan) {
+  if (!h) return fail("null engine handle");
+  if (!h->finalized) return fail("weights not finalized (call ns2vc_unet_finalize_weights)");
+  if (need_plan && !h->arena) return fail("engine not prepared (call ns2vc_unet_prepare)");
+  return 0;
+}
+
+}  // namespace
+
+// ====================================================================================
+// C ABI
+// ====================================================================================
+extern "C" {
+
+int ns2vc_abi_version(void) { return NS2VC_ABI_VERSION; }
+const char* ns2vc_last_error(void) { return g_err.c_str(); }
+
+int ns2vc_device_count(int* out_count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *out_count = 0; return fail("hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *out_count = n;
+  return 0;
+}
+int ns2vc_set_device(int device) { HIPCHK(hipSetDevice(device)); return 0; }
+int ns2vc_device_name(char* buf, int buflen) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, buflen, "%s|%s|CUs=%d|clock_khz=%d|mem_gb=%.1f", p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate,
+           (double)p.totalGlobalMem / 1e9);
+  return 0;
+}
+
+int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
+  if (!cfg || !out) return fail("null argument");
+  if (cfg->n_levels < 2 || cfg->n_levels > NS2VC_MAX_LEVELS) return fail("n_levels out of range");
+  if (cfg->latent_channels <= 0 || cfg->latent_channels > 128) return fail("latent_channels must be in 1..128");
+  if (cfg->content_channels % 64) return fail("content_channels must be a multiple of 64");
+  if (cfg->cross_attention_dim % 128) return fail("cross_attention_dim must be a multiple of 128");
+  if (cfg->block_out_channels[0] != 128) return fail("block_out_channels[0] must be 128 (padded latent width)");
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    const int c = cfg->block_out_channels[l];
+    if (c % 64 || c > 512) return fail("block_out_channels[%d]=%d must be a multiple of 64 and <= 512", l, c);
+    if (c % cfg->heads) return fail("channels %d not divisible by heads %d", c, cfg->heads);
+    const int hd = c / cfg->heads;
+    if (hd != 16 && hd != 32 && hd != 48 && hd != 64) return fail("head_dim %d unsupported (16/32/48/64)", hd);
+    if (c % cfg->norm_num_groups || (c / cfg->norm_num_groups) % 4) return fail("channels %d incompatible with %d groups", c, cfg->norm_num_groups);
+  }
+  if (cfg->cross_attention_dim % cfg->pool_heads || cfg->cross_attention_dim / cfg->pool_heads > 8) return fail("pool heads unsupported");
+  hipError_t e = init_gemm_attributes();
+  if (e == hipSuccess) e = init_attn_attributes();
+  if (e != hipSuccess) return fail("kernel attribute setup failed: %s (is a gfx950 GPU visible?)", hipGetErrorString(e));
+  auto* h = new ns2vc_unet();
+  h->cfg = *cfg;
+  h->blocks = make_topology(*cfg);
+  build_expected(h);
+  *out = h;
+  return 0;
+}
+
+int ns2vc_unet_destroy(ns2vc_unet* h) {
+  delete h;
+  return 0;
+}
+
+int ns2vc_unet_load_weight(ns2vc_unet* h, const char* key, const void* data, const int64_t* shape, int ndim) {
+  if (!h || !key || !data) return fail("null argument");
+  std::string k(key);
+  const std::vector<int64_t>* want = nullptr;
+  for (const auto& e : h->expected) if (e.first == k) { want = &e.second; break; }
+  if (!want) return fail("unexpected weight key '%s'", key);
+  if ((int)want->size() != ndim) return fail("%s: ndim %d != expected %zu", key, ndim, want->size());
+  for (int i = 0; i < ndim; ++i) if (shape[i] != (*want)[i]) return fail("%s: shape[%d]=%lld != expected %lld", key, i, (long long)shape[i], (long long)(*want)[i]);
+  HostTensor t;
+  t.shape.assign(shape, shape + ndim);
+  t.data.resize(t.numel());
+  HIPCHK(hipMemcpy(t.data.data(), data, t.numel() * sizeof(float), hipMemcpyDefault));
+  h->raw[k] = std::move(t);
+  h->finalized = false;
+  return 0;
+}
+
+int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int buflen) {
+  int n = 0;
+  for (const auto& e : h->expected)
+    if (!h->raw.count(e.first)) {
+      if (n == 0 && first_missing && buflen > 0) snprintf(first_missing, buflen, "%s", e.first.c_str());
+      ++n;
+    }
+  return n;
+}
+
+int ns2vc_unet_finalize_weights(ns2vc_unet* h, int precision) {
+  if (!h) return fail("null engine handle");
+  if (precision != NS2VC_PREC_F32 && precision != NS2VC_PREC_BF16) return fail("unknown precision %d", precision);
+  char first[256] = {0};
+  const int miss = ns2vc_unet_num_missing_weights(h, first, sizeof(first));
+  if (miss) return fail("%d weights missing, first: %s", miss, first);
+  for (void* p : h->weight_allocs) (void)hipFree(p);
+  h->weight_allocs.clear();
+  h->prec = precision;
+  if (pack_all(h)) return 1;
+  h->finalized = true;
+  // a plan built for other weights holds stale pointers
+  if (h->arena) { (void)hipFree(h->arena); h->arena = nullptr; }
+  if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+  return 0;
+}
+
+int ns2vc_unet_set_debug(ns2vc_unet* h, int enable) {
+  if (!h) return fail("null engine handle");
+  h->debug = enable != 0;
+  return 0;
+}
+
+int ns2vc_unet_prepare(ns2vc_unet* h, int B, int T, int Lp) {
+  if (check_ready(h, false)) return 1;
+  if (B <= 0 || T <= 0 || Lp <= 0) return fail("B, T, Lp must be positive");
+  const int min_t = 1 << (h->cfg.n_levels - 1);
+  if (T < min_t) return fail("T=%d too short for %d levels", T, h->cfg.n_levels);
+  if (h->arena) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(h->arena); h->arena = nullptr; }
+  if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+  h->B = B; h->T = T; h->Lp = Lp;
+  h->has_mask = false;
+  if (build_plan(h, true)) return 1;
+  HIPCHK(hipMalloc(&h->arena, h->arena_bytes));
+  HIPCHK(hipMemset(h->arena, 0, h->arena_bytes));
+  if (build_plan(h, false)) return 1;
+  return 0;
+}
+
+int ns2vc_unet_workspace_bytes(ns2vc_unet* h, size_t* out) {
+  if (!h || !out) return fail("null argument");
+  *out = h->arena_bytes;
+  return 0;
+}
+
+int ns2vc_unet_set_condition(ns2vc_unet* h, const float* content_bct, const float* prompt_blc, const uint8_t* mask_bl, void* stream) {
+  if (check_ready(h, true)) return 1;
+  if (!content_bct || !prompt_blc) return fail("null condition tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = h->cfg;
+  const bool want_mask = mask_bl != nullptr;
+  if (want_mask != h->has_mask) {
+    // the cross-attention launches bake in whether a bias is read: rebuild the (cheap) plan
+    h->has_mask = want_mask;
+    if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+    if (build_plan(h, false)) return 1;
+  }
+  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, h->content_btc, c.content_channels, c.content_channels, s));
+  HIPCHK(hipMemcpyAsync(h->prompt, prompt_blc, (size_t)h->B * h->Lp * c.cross_attention_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (want_mask) {
+    HIPCHK(hipMemcpyAsync(h->mask_dev, mask_bl, (size_t)h->B * h->Lp, hipMemcpyDeviceToDevice, s));
+    HIPCHK(launch_mask_bias(h->mask_dev, h->B * h->Lp, h->maskbias, s));
+  }
+  return run_ops(h->cond_ops, s);
+}
+
+int ns2vc_unet_forward(ns2vc_unet* h, const float* x_bct, const float* t_b, float* out_bct, void* stream) {
+  if (check_ready(h, true)) return 1;
+  if (!x_bct || !t_b || !out_bct) return fail("null tensor");
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = h->cfg;
+  h->use_step_table = false;
+  HIPCHK(launch_nct_to_btc(x_bct, c.latent_channels, h->T, h->B, h->xe, h->CP, h->CP, s));
+  HIPCHK(hipMemcpyAsync(h->t_dev, t_b, (size_t)h->B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (run_ops(h->fwd_ops, s)) return 1;
+  HIPCHK(launch_btc_to_nct(h->x0, h->CP, c.latent_channels, h->T, h->B, out_bct, s));
+  return 0;
+}
+
+int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
+  const int kMaxSteps = 1024;   // fixed capacity: the table pointer is baked into the captured graph
+  if (!h || !coef_host || steps <= 0) return fail("bad sampler table");
+  if (steps > kMaxSteps) return fail("at most %d solver steps are supported", kMaxSteps);
+  if (!h->coef_dev) HIPCHK(hipMalloc((void**)&h->coef_dev, (size_t)kMaxSteps * NS2VC_NCOEF * sizeof(float)));
+  HIPCHK(hipDeviceSynchronize());   // a previous loop may still be reading the table
+  HIPCHK(hipMemcpy(h->coef_dev, coef_host, (size_t)steps * NS2VC_NCOEF * sizeof(float), hipMemcpyHostToDevice));
+  h->steps = steps;
+  return 0;
+}
+
+static int run_step(ns2vc_unet* h, hipStream_t s) {
+  if (run_ops(h->fwd_ops, s)) return 1;
+  const size_t n = (size_t)h->B * h->T * h->CP;
+  HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xbar, h->d1, h->mprev, n, s));
+  HIPCHK(launch_step_advance(h->step_dev, s));
+  return 0;
+}
+
+int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* stream) {
+  if (check_ready(h, true)) return 1;
+  if (!x_inout_bct) return fail("null tensor");
+  if (!h->coef_dev || h->steps <= 0) return fail("no solver table loaded (call ns2vc_sampler_load)");
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = h->cfg;
+  const size_t n = (size_t)h->B * h->T * h->CP;
+  h->use_step_table = true;
+  if (use_graph && !h->step_graph) {
+    if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = run_step(h, h->cap_stream);
+    hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+    if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&h->step_graph, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) { h->step_graph = nullptr; return fail("hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  }
+  HIPCHK(launch_nct_to_btc(x_inout_bct, c.latent_channels, h->T, h->B, h->xe, h->CP, h->CP, s));
+  HIPCHK(hipMemcpyAsync(h->xbar, h->xe, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(h->d1, 0, n * sizeof(float), s));
+  HIPCHK(hipMemsetAsync(h->mprev, 0, n * sizeof(float), s));
+  HIPCHK(launch_fill_i32(h->step_dev, 0, s));
+  for (int i = 0; i < h->steps; ++i) {
+    if (use_graph) HIPCHK(hipGraphLaunch(h->step_graph, s));
+    else if (run_step(h, s)) return 1;
+  }
+  HIPCHK(launch_btc_to_nct(h->xe, h->CP, c.latent_channels, h->T, h->B, x_inout_bct, s));
+  return 0;
+}
+
+int ns2vc_unet_num_taps(ns2vc_unet* h) { return h ? (int)h->taps.size() : 0; }
+int ns2vc_unet_tap_info(ns2vc_unet* h, int idx, char* name, int buflen, int* rows, int* cols) {
+  if (!h || idx < 0 || idx >= (int)h->taps.size()) return fail("tap index out of range");
+  snprintf(name, buflen, "%s", h->taps[idx].name.c_str());
+  *rows = h->taps[idx].rows; *cols = h->taps[idx].cols;
+  return 0;
+}
+int ns2vc_unet_tap_read(ns2vc_unet* h, int idx, float* host_dst) {
+  if (!h || idx < 0 || idx >= (int)h->taps.size()) return fail("tap index out of range");
+  HIPCHK(hipDeviceSynchronize());
+  const Tap& t = h->taps[idx];
+  HIPCHK(hipMemcpy(host_dst, t.copy, (size_t)t.rows * t.cols * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+int ns2vc_unet_num_launches(ns2vc_unet* h, int* per_forward, int* per_condition) {
+  if (!h) return fail("null engine handle");
+  if (per_forward) *per_forward = (int)h->fwd_ops.size();
+  if (per_condition) *per_condition = (int)h->cond_ops.size();
+  return 0;
+}
+
+int ns2vc_unet_op_info(ns2vc_unet* h, int which, int idx, char* name, int buflen, int* kind, double* flops, double* bytes) {
+  if (!h) return fail("null engine handle");
+  const std::vector<Op>& ops = which ? h->cond_ops : h->fwd_ops;
+  if (idx < 0 || idx >= (int)ops.size()) return fail("op index out of range");
+  snprintf(name, buflen, "%s", ops[idx].name.c_str());
+  *kind = ops[idx].kind; *flops = ops[idx].flops; *bytes = ops[idx].bytes;
+  return 0;
+}
+
+// Runs the per-step forward plan EAGERLY with a hipEvent pair around every launch on `stream`
+// and returns the elapsed milliseconds per op (ms[num_launches]).  The model input is whatever
+// the last forward / sampler call left in the engine's x buffer.  Synchronous.
+int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, void* stream) {
+  if (check_ready(h, true)) return 1;
+  const size_t n = h->fwd_ops.size();
+  if ((size_t)n_ms < n) return fail("ms buffer too small: need %zu", n);
+  hipStream_t s = (hipStream_t)stream;
+  h->use_step_table = false;      // time with the (B,) timestep buffer of the plain forward
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+  int rc = 0;
+  HIPCHK(hipEventRecord(ev[0], s));
+  for (size_t i = 0; i < n && !rc; ++i) {
+    hipError_t e = h->fwd_ops[i].fn(s);
+    if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", h->fwd_ops[i].name.c_str(), hipGetErrorString(e));
+    if (!rc && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = fail("hipEventRecord failed");
+  }
+  if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+  for (size_t i = 0; i < n && !rc; ++i)
+    if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+// ---- raw helpers ----------------------------------------------------------------------
+int ns2vc_dev_malloc(void** out, size_t bytes) { HIPCHK(hipMalloc(out, bytes ? bytes : 1)); return 0; }
+int ns2vc_dev_free(void* p) { HIPCHK(hipFree(p)); return 0; }
+int ns2vc_memcpy_h2d(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return 0; }
+int ns2vc_memcpy_d2h(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
+int ns2vc_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return 0; }
+int ns2vc_stream_create(void** out) { hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *out = s; return 0; }
+int ns2vc_stream_destroy(void* s) { HIPCHK(hipStreamDestroy((hipStream_t)s)); return 0; }
+int ns2vc_stream_sync(void* s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
+int ns2vc_event_create(void** out) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); *out = e; return 0; }
+int ns2vc_event_destroy(void* e) { HIPCHK(hipEventDestroy((hipEvent_t)e)); return 0; }
+int ns2vc_event_record(void* e, void* s) { HIPCHK(hipEventRecord((hipEvent_t)e, (hipStream_t)s)); return 0; }
+int ns2vc_event_elapsed_ms(void* a, void* b, float* ms) {
+  HIPCHK(hipEventSynchronize((hipEvent_t)b));
+  HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+  return 0;
+}
+
+// ---- kernel-level entry points -----------------------------------------------------------
+int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev) {
+  if (!rows_host || !out_dev || N <= 0 || K <= 0) return fail("bad argument");
+  static bool inited = false;
+  if (!inited) {
+    hipError_t e = init_gemm_attributes();
+    if (e == hipSuccess) e = init_attn_attributes();
+    if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
+    inited = true;
+  }
+  void* d = nullptr;
+  if (precision == NS2VC_PREC_BF16) {
+    std::vector<uint16_t> q((size_t)N * K);
+    for (size_t i = 0; i < q.size(); ++i) q[i] = f32_to_bf16_bits(rows_host[i]);
+    HIPCHK(hipMalloc(&d, q.size() * 2));
+    HIPCHK(hipMemcpy(d, q.data(), q.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMalloc(&d, (size_t)N * K * 4));
+    HIPCHK(hipMemcpy(d, rows_host, (size_t)N * K * 4, hipMemcpyHostToDevice));
+  }
+  *out_dev = d;
+  return 0;
+}
+int ns2vc_debug_set_gemm_tile(int bm, int bn) { set_forced_gemm_tile(bm, bn); return 0; }
+int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
+  if (!a) return fail("null args");
+  hipError_t e = launch_gemm(*a, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_gemm: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream) {
+  if (!a) return fail("null args");
+  hipError_t e = launch_attention(*a, head_dim, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_attention: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_groupnorm_coef(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
+                           const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off, float* pscale,
+                           float* pshift, void* stream) {
+  const int rows = 64, nchunk = (T + rows - 1) / rows;
+  double* part = nullptr;
+  HIPCHK(hipMalloc((void**)&part, (size_t)B * nchunk * G * 2 * sizeof(double)));
+  hipError_t e = launch_gn_partial(a0, lda0, c0, a1, lda1, c1, B, T, G, part, nchunk, rows, (hipStream_t)stream);
+  if (e == hipSuccess) e = launch_gn_coef(part, nchunk, B, T, c0 + c1, G, eps, gamma, beta, temb, ldtemb, temb_off, c0 + c1, pscale, pshift, (hipStream_t)stream);
+  hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(part);
+  if (e != hipSuccess) return fail("groupnorm launch: %s", hipGetErrorString(e));
+  if (e2 != hipSuccess) return fail("groupnorm sync: %s", hipGetErrorString(e2));
+  return 0;
+}
+int ns2vc_k_layernorm_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, void* stream) {
+  hipError_t e = launch_ln_stats(x, ldx, M, C, eps, rstats, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("ln_stats launch: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream) {
+  hipError_t e = launch_nct_to_btc(src, C, T, B, dst, ldd, cpad, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("nct_to_btc launch: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_btc_to_nct(const float* src, int lds, int C, int T, int B, float* dst, void* stream) {
+  hipError_t e = launch_btc_to_nct(src, lds, C, T, B, dst, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("btc_to_nct launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"

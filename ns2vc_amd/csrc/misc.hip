@@ -1,0 +1,449 @@
+// Memory-bound helper kernels of the NS2VC denoiser engine (gfx950): GroupNorm /
+// LayerNorm statistics, the timestep-embedding MLP, prompt attention pooling,
+// layout changes at the API boundary and the fused solver update.  All fp32,
+// wave64, vectorised 16-B accesses on the channels-last activation layout.
+#include "common.h"
+
+namespace ns2vc {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm statistics over a (possibly concatenated) channels-last tensor.
+// Reference: nn.GroupNorm at resnet.py:536,557 / transformer_1d.py:134 /
+// unet_1d_condition.py:546; concat at unet_1d_blocks.py:2085,2187 (groups may
+// straddle the seam between the two sources).
+// grid (nchunk, B); each block reduces `rows` frames of one batch item for all
+// G groups and writes (sum, sumsq) per group in double.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ a0, int lda0, int c0,
+                                                         const float* __restrict__ a1, int lda1, int c1, int T, int G,
+                                                         double* __restrict__ partial, int rows) {
+  __shared__ float s_sum[256], s_sq[256];
+  const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int C = c0 + c1, nq = C >> 2, Cg = C / G;
+  const int rl = max(1, 256 / nq);                 // row lanes
+  const int quad = tid % nq, rlane = tid / nq;
+  float sum = 0.f, sq = 0.f;
+  const int r0 = chunk * rows, r1 = min(T, r0 + rows);
+  if (rlane < rl) {                                  // host guarantees C <= 1024, i.e. nq <= 256
+    const int c = quad * 4;
+    const float* src; int ld, cs;
+    if (c < c0) { src = a0; ld = lda0; cs = c; } else { src = a1; ld = lda1; cs = c - c0; }
+    for (int r = r0 + rlane; r < r1; r += rl) {
+      const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)(b * T + r) * ld + cs));
+      sum += (v.x + v.y) + (v.z + v.w);
+      sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  }
+  s_sum[tid] = sum; s_sq[tid] = sq;
+  __syncthreads();
+  if (tid < G) {
+    double ds = 0.0, dq = 0.0;
+    const int nact = min(256, rl * nq);
+    for (int i = 0; i < nact; ++i) {
+      const int g = ((i % nq) * 4) / Cg;
+      if (g == tid) { ds += (double)s_sum[i]; dq += (double)s_sq[i]; }
+    }
+    double* p = partial + ((size_t)(b * nchunk + chunk) * G + tid) * 2;
+    p[0] = ds; p[1] = dq;
+  }
+}
+
+// Finalise GroupNorm statistics and fold everything that is per-(batch,channel)
+// into one affine:  y = x*pscale + pshift  ==  GN(x)*gamma+beta, then optionally
+// *(1+scale)+shift with the resnet's time projection (resnet.py:625-629).
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ partial, int nchunk, int T, int C, int G,
+                                                      float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ temb, int ldtemb, int temb_off, int cout,
+                                                      float* __restrict__ pscale, float* __restrict__ pshift) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int Cg = C / G;
+  if (tid < G) {
+    double ds = 0.0, dq = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* p = partial + ((size_t)(b * nchunk + k) * G + tid) * 2;
+      ds += p[0]; dq += p[1];
+    }
+    const double n = (double)T * (double)Cg;
+    const double mean = ds / n;
+    double var = dq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / Cg;
+    float sc = s_rstd[g] * gamma[c];
+    float sh = beta[c] - s_mean[g] * sc;
+    if (temb) {
+      const float s1 = 1.0f + temb[(size_t)b * ldtemb + temb_off + c];
+      const float sf = temb[(size_t)b * ldtemb + temb_off + cout + c];
+      sc *= s1;
+      sh = sh * s1 + sf;
+    }
+    pscale[(size_t)b * C + c] = sc;
+    pshift[(size_t)b * C + c] = sh;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm row statistics (mean, rstd), one wave per row (attention.py:83,102,118).
+// gamma/beta are folded into the consumer GEMM's weights at pack time.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, int M, int C, float eps,
+                                                       float* __restrict__ rstats) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* p = x + (size_t)row * ldx;
+  float v[16];
+  float s = 0.f;
+  const int n = C >> 6;                        // elements per lane (C multiple of 64, <= 1024)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = (i < n) ? p[lane + 64 * i] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float d = (i < n) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)C;
+  if (lane == 0) {
+    rstats[2 * (size_t)row] = mean;
+    rstats[2 * (size_t)row + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+// Full LayerNorm apply (used once per utterance for the prompt pooling path,
+// embeddings.py:430).  Output row r of batch b goes to row b*(L+1)+1+t of `out`
+// (row 0 of each item is reserved for the class token).
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, int M, int C, float eps,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ out, int L) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* p = x + (size_t)row * C;
+  float v[16];
+  float s = 0.f;
+  const int n = C >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = (i < n) ? p[lane + 64 * i] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float d = (i < n) ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  const int b = row / L, t = row - b * L;
+  float* o = out + ((size_t)b * (L + 1) + 1 + t) * C;
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < n) o[lane + 64 * i] = (v[i] - mean) * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
+}
+
+// class token = mean_t(LN(prompt)) + positional_embedding  (embeddings.py:524)
+__global__ __launch_bounds__(256) void pool_cls_kernel(float* __restrict__ seq, int L, int C, const float* __restrict__ pos) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    const float* p = seq + ((size_t)b * (L + 1) + 1) * C + c;
+    for (int t = 0; t < L; ++t) s += p[(size_t)t * C];
+    seq[(size_t)b * (L + 1) * C + c] = s / (float)L + pos[c];
+  }
+}
+
+// AttentionPooling (embeddings.py:499-546): one query (the class token) per
+// (batch, head); keys/values = [cls ; LN(prompt)].  qkv rows hold (q|k|v), each
+// C wide.  One wave per head, lanes stride over keys.  dph = C/heads <= 8.
+__global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict__ qkv, int L1, int C, int heads,
+                                                        float* __restrict__ pooled) {
+  extern __shared__ float s_sc[];           // 4 waves x L1 scores
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int dph = C / heads;
+  const float inv = 1.0f / sqrtf((float)dph);   // (q*s).(k*s), s = dph^-1/4
+  float* sc = s_sc + wave * L1;
+  const float* base = qkv + (size_t)b * L1 * 3 * C;
+  for (int h = wave; h < heads; h += 4) {
+    float qv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) qv[c] = (c < dph) ? base[h * dph + c] : 0.f;      // row 0 = class token
+    float mx = -INFINITY;
+    for (int j = lane; j < L1; j += 64) {
+      const float* kp = base + (size_t)j * 3 * C + C + h * dph;
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < dph) s += qv[c] * kp[c];
+      s *= inv;
+      sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float den = 0.f;
+    for (int j = lane; j < L1; j += 64) {
+      const float w = __expf(sc[j] - mx);
+      den += w;
+      const float* vp = base + (size_t)j * 3 * C + 2 * C + h * dph;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) if (c < dph) acc[c] += w * vp[c];
+    }
+    den = wave_sum(den);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float a = wave_sum(acc[c]);
+      if (lane == 0 && c < dph) pooled[(size_t)b * C + h * dph + c] = a / den;
+    }
+  }
+}
+
+// proj (Linear C->E) + LayerNorm(E)  (embeddings.py:431-433) -> aug_emb [B][E]
+__global__ __launch_bounds__(256) void pool_proj_kernel(const float* __restrict__ pooled, int C, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, int E, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float* __restrict__ out) {
+  extern __shared__ float s_buf[];          // C inputs + E outputs + 8 scratch
+  float* s_in = s_buf;
+  float* s_y = s_buf + C;
+  float* s_red = s_y + E;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < C; i += 256) s_in[i] = pooled[(size_t)b * C + i];
+  __syncthreads();
+  float lsum = 0.f;
+  for (int o = tid; o < E; o += 256) {
+    float y = bias[o];
+    for (int i = 0; i < C; ++i) y += wt[(size_t)i * E + o] * s_in[i];
+    s_y[o] = y;
+    lsum += y;
+  }
+  lsum = wave_sum(lsum);
+  if ((tid & 63) == 0) s_red[tid >> 6] = lsum;
+  __syncthreads();
+  const float mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) / (float)E;
+  float lq = 0.f;
+  for (int o = tid; o < E; o += 256) { const float d = s_y[o] - mean; lq += d * d; }
+  lq = wave_sum(lq);
+  if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = lq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((s_red[4] + s_red[5] + s_red[6] + s_red[7]) / (float)E + eps);
+  for (int o = tid; o < E; o += 256) out[(size_t)b * E + o] = (s_y[o] - mean) * rstd * gamma[o] + beta[o];
+}
+
+// ---------------------------------------------------------------------------
+// Timestep path: sinusoid -> Linear -> SiLU -> Linear, + aug_emb; also emits
+// SiLU(emb), the input of every resnet's time_emb_proj.
+// Reference: embeddings.py:24-64 (flip_sin_to_cos=True, freq_shift=0), :157-201,
+// unet_1d_condition.py:841-848,918.  The timestep is fractional float32.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict__ t_ptr, int t_stride, const int* __restrict__ step_ptr,
+                                                         int coef_stride, const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                         const float* __restrict__ aug, float* __restrict__ emb,
+                                                         float* __restrict__ emb_act, int tdim, int edim) {
+  extern __shared__ float s_te[];           // tdim sinusoid + edim hidden
+  float* s_sin = s_te;
+  float* s_h = s_te + tdim;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float t = step_ptr ? t_ptr[(size_t)(*step_ptr) * coef_stride] : t_ptr[(size_t)b * t_stride];
+  const int half = tdim >> 1;
+  for (int i = tid; i < half; i += 256) {
+    const float expo = (-9.210340371976184f * (float)i) / (float)half;
+    const float f = (float)exp((double)expo);
+    const float ang = t * f;
+    s_sin[i] = cosf(ang);
+    s_sin[half + i] = sinf(ang);
+  }
+  __syncthreads();
+  for (int o = tid; o < edim; o += 256) {
+    float y = b1[o];
+    for (int i = 0; i < tdim; ++i) y += w1t[(size_t)i * edim + o] * s_sin[i];
+    s_h[o] = y / (1.0f + expf(-y));
+  }
+  __syncthreads();
+  for (int o = tid; o < edim; o += 256) {
+    float y = b2[o];
+    for (int i = 0; i < edim; ++i) y += w2t[(size_t)i * edim + o] * s_h[i];
+    if (aug) y += aug[(size_t)b * edim + o];
+    emb[(size_t)b * edim + o] = y;
+    emb_act[(size_t)b * edim + o] = y / (1.0f + expf(-y));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// API-boundary layout changes: reference tensors are NCT (B,C,T); the engine is
+// channels-last (B,T,Cpad).  32x32 LDS tile transpose, both directions coalesced.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nct_to_btc_kernel(const float* __restrict__ src, int C, int T, float* __restrict__ dst,
+                                                         int ldd, int cpad) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    tile[i][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    if (t < T && c < cpad) dst[((size_t)b * T + t) * ldd + c] = tile[tx][i];
+  }
+}
+__global__ __launch_bounds__(256) void btc_to_nct_kernel(const float* __restrict__ src, int lds_, int C, int T, float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, c = c0 + tx;
+    tile[i][tx] = (t < T && c < C) ? src[((size_t)b * T + t) * lds_ + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, t = t0 + tx;
+    if (c < C && t < T) dst[((size_t)b * C + c) * T + t] = tile[tx][i];
+  }
+}
+
+// encoder_attention_mask (bool, True = keep) -> additive bias (unet_1d_condition.py:816-818)
+__global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, int n, float* __restrict__ bias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) bias[i] = (1.0f - (mask[i] ? 1.0f : 0.0f)) * -10000.0f;
+}
+
+// ---------------------------------------------------------------------------
+// Fused solver update (ns2vc_amd/schedule.py documents the recurrence and cites
+// sampler/dpm_solver.py + sampler/uni_pc.py).  Scalars come from row *step of
+// the device-resident coefficient table, so the same captured graph serves
+// every step.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void solver_update_kernel(const float* __restrict__ coef, const int* __restrict__ step_ptr, int ncoef,
+                                                            const float* __restrict__ x0, float* __restrict__ xe,
+                                                            float* __restrict__ xbar, float* __restrict__ d1,
+                                                            float* __restrict__ mprev, size_t n4) {
+  const float* c = coef + (size_t)(*step_ptr) * ncoef;
+  const float alpha = c[1], sigma = c[2], g0 = c[3], g1 = c[4], A = c[5], Bc = c[6], d1c = c[7], pc = c[8];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 vx0 = reinterpret_cast<const float4*>(x0)[i];
+    const float4 vxe = reinterpret_cast<const float4*>(xe)[i];
+    const float4 vxb = reinterpret_cast<const float4*>(xbar)[i];
+    const float4 vd1 = reinterpret_cast<const float4*>(d1)[i];
+    const float4 vmp = reinterpret_cast<const float4*>(mprev)[i];
+    float4 oxe, oxb, od1, om;
+#define NS2VC_UPD(f)                                         \
+  {                                                          \
+    const float eps = (vxe.f - alpha * vx0.f) / sigma;       \
+    const float m = (vxe.f - sigma * eps) / alpha;           \
+    const float x = vxb.f - g0 * vd1.f - g1 * (m - vmp.f);   \
+    const float nb = A * x - Bc * m;                         \
+    const float nd = d1c * (vmp.f - m);                      \
+    oxb.f = nb; od1.f = nd; oxe.f = nb - pc * nd; om.f = m;  \
+  }
+    NS2VC_UPD(x) NS2VC_UPD(y) NS2VC_UPD(z) NS2VC_UPD(w)
+#undef NS2VC_UPD
+    reinterpret_cast<float4*>(xe)[i] = oxe;
+    reinterpret_cast<float4*>(xbar)[i] = oxb;
+    reinterpret_cast<float4*>(d1)[i] = od1;
+    reinterpret_cast<float4*>(mprev)[i] = om;
+  }
+}
+__global__ void step_advance_kernel(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1; }
+__global__ void fill_i32_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G,
+                             double* partial, int nchunk, int rows_per_chunk, hipStream_t s) {
+  const int C = c0 + c1;
+  if (C > 1024 || (C & 3) || (c0 & 3) || G > 64 || C % G || (C / G) % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, partial, rows_per_chunk);
+  return hipGetLastError();
+}
+hipError_t launch_gn_coef(const double* partial, int nchunk, int B, int T, int C, int G, float eps, const float* gamma,
+                          const float* beta, const float* temb, int ldtemb, int temb_off, int cout, float* pscale,
+                          float* pshift, hipStream_t s) {
+  hipLaunchKernelGGL(gn_coef_kernel, dim3(B), dim3(256), 0, s, partial, nchunk, T, C, G, eps, gamma, beta, temb, ldtemb, temb_off,
+                     cout, pscale, pshift);
+  return hipGetLastError();
+}
+hipError_t launch_ln_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, hipStream_t s) {
+  if (C % 64 || C > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, C, eps, rstats);
+  return hipGetLastError();
+}
+hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float* gamma, const float* beta, float* out, int L,
+                           int, hipStream_t s) {
+  if (C % 64 || C > 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_apply_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, M, C, eps, gamma, beta, out, L);
+  return hipGetLastError();
+}
+hipError_t launch_pool_cls(float* seq, int B, int L, int C, const float* pos, hipStream_t s) {
+  hipLaunchKernelGGL(pool_cls_kernel, dim3(B), dim3(256), 0, s, seq, L, C, pos);
+  return hipGetLastError();
+}
+hipError_t launch_pool_attn(const float* qkv, int B, int L1, int C, int heads, float* pooled, hipStream_t s) {
+  if (C % heads || C / heads > 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pool_attn_kernel, dim3(B), dim3(256), 4 * (size_t)L1 * sizeof(float), s, qkv, L1, C, heads, pooled);
+  return hipGetLastError();
+}
+hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, const float* b, int E, const float* gamma,
+                            const float* beta, float eps, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(pool_proj_kernel, dim3(B), dim3(256), (size_t)(C + E + 8) * sizeof(float), s, pooled, C, wt, b, E, gamma, beta, eps, out);
+  return hipGetLastError();
+}
+hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride, const float* w1t,
+                             const float* b1, const float* w2t, const float* b2, const float* aug, float* emb, float* emb_act,
+                             int B, int tdim, int edim, hipStream_t s) {
+  hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(256), (size_t)(tdim + edim) * sizeof(float), s, t_ptr, t_stride, step_ptr,
+                     coef_stride, w1t, b1, w2t, b2, aug, emb, emb_act, tdim, edim);
+  return hipGetLastError();
+}
+hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, hipStream_t s) {
+  hipLaunchKernelGGL(nct_to_btc_kernel, dim3((T + 31) / 32, (cpad + 31) / 32, B), dim3(256), 0, s, src, C, T, dst, ldd, cpad);
+  return hipGetLastError();
+}
+hipError_t launch_btc_to_nct(const float* src, int lds_, int C, int T, int B, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(btc_to_nct_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, src, lds_, C, T, dst);
+  return hipGetLastError();
+}
+hipError_t launch_mask_bias(const uint8_t* mask, int n, float* bias, hipStream_t s) {
+  hipLaunchKernelGGL(mask_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, n, bias);
+  return hipGetLastError();
+}
+hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0, float* xe, float* xbar,
+                                float* d1, float* mprev, size_t n, hipStream_t s) {
+  if (n & 3) return hipErrorInvalidValue;
+  const size_t n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(solver_update_kernel, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, xbar, d1, mprev, n4);
+  return hipGetLastError();
+}
+hipError_t launch_step_advance(int* step_ptr, hipStream_t s) {
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_ptr);
+  return hipGetLastError();
+}
+hipError_t launch_fill_i32(int* p, int v, hipStream_t s) {
+  hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, p, v);
+  return hipGetLastError();
+}
+
+}  // namespace ns2vc

@@ -1,0 +1,298 @@
+"""Host-side handle on the HIP denoiser engine (libns2vc_hip.so).
+
+Pure ctypes + numpy: torch is optional and used only as a source of device
+pointers / streams (plumbing).  Everything computes on the GPU through the C
+ABI; there is no CPU path here — missing library or GPU raises ``Ns2vcError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import Ns2vcError, PREC_BF16, PREC_F32, check
+from .schedule import NCOEF, SolverTable, build_table
+from .spec import UNetConfig, param_spec
+
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+
+
+class DevBuf:
+    """A raw device allocation made through the C ABI (torch-free tests / bench)."""
+
+    def __init__(self, nbytes: int):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        check(self.lib.ns2vc_dev_malloc(C.byref(p), nbytes), "ns2vc_dev_malloc")
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray) -> "DevBuf":
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        check(b.lib.ns2vc_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes), "memcpy_h2d")
+        return b
+
+    def upload(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(self.lib.ns2vc_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes), "memcpy_h2d")
+
+    def to_numpy(self, shape, dtype=np.float32) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.lib.ns2vc_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            self.lib.ns2vc_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x) -> int:
+    """Device pointer of a DevBuf / torch CUDA tensor / raw int."""
+    if x is None:
+        return 0
+    if isinstance(x, DevBuf):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):          # torch tensor
+        if not x.is_cuda:
+            raise Ns2vcError("tensor must live on the GPU: the engine has no CPU path")
+        if not x.is_contiguous():
+            raise Ns2vcError("tensor must be contiguous")
+        return x.data_ptr()
+    raise TypeError(f"cannot take a device pointer of {type(x)}")
+
+
+class Stream:
+    def __init__(self):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        check(self.lib.ns2vc_stream_create(C.byref(p)), "stream_create")
+        self.ptr = p.value
+
+    def sync(self):
+        check(self.lib.ns2vc_stream_sync(self.ptr), "stream_sync")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.ns2vc_stream_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.lib = _lib.load()
+        p = C.c_void_p()
+        check(self.lib.ns2vc_event_create(C.byref(p)), "event_create")
+        self.ptr = p.value
+
+    def record(self, stream) -> None:
+        check(self.lib.ns2vc_event_record(self.ptr, _stream_ptr(stream)), "event_record")
+
+    def elapsed_ms(self, end: "Event") -> float:
+        ms = C.c_float()
+        check(self.lib.ns2vc_event_elapsed_ms(self.ptr, end.ptr, C.byref(ms)), "event_elapsed")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.ns2vc_event_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+def _stream_ptr(s) -> int:
+    if s is None:
+        return 0
+    if isinstance(s, Stream):
+        return s.ptr
+    if isinstance(s, int):
+        return s
+    if hasattr(s, "cuda_stream"):       # torch.cuda.Stream
+        return int(s.cuda_stream)
+    raise TypeError(f"not a stream: {type(s)}")
+
+
+def device_info() -> str:
+    lib = _lib.load()
+    buf = C.create_string_buffer(256)
+    check(lib.ns2vc_device_name(buf, 256), "device_name")
+    return buf.value.decode()
+
+
+def set_device(index: int) -> None:
+    check(_lib.load().ns2vc_set_device(int(index)), "set_device")
+
+
+def device_count() -> int:
+    lib = _lib.load()
+    n = C.c_int()
+    rc = lib.ns2vc_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0
+
+
+class Engine:
+    """One denoiser instance: weights + workspace for a (B, T, Lp) shape."""
+
+    def __init__(self, cfg: UNetConfig = UNetConfig(), precision: str = "bf16"):
+        cfg.validate()
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
+        self.cfg = cfg
+        self.precision = precision
+        self.lib = _lib.load()
+        c = _lib.UnetCfg()
+        c.latent_channels = cfg.latent_channels
+        c.content_channels = cfg.content_channels
+        c.n_levels = len(cfg.block_out_channels)
+        for i, v in enumerate(cfg.block_out_channels):
+            c.block_out_channels[i] = v
+        c.norm_num_groups = cfg.norm_num_groups
+        c.cross_attention_dim = cfg.cross_attention_dim
+        c.heads = cfg.heads
+        c.layers_per_block = cfg.layers_per_block
+        c.pool_heads = cfg.addition_embed_heads
+        h = C.c_void_p()
+        check(self.lib.ns2vc_unet_create(C.byref(c), C.byref(h)), "ns2vc_unet_create")
+        self.h = h
+        self.shape: Optional[Tuple[int, int, int]] = None
+        self.table: Optional[SolverTable] = None
+        self._weights_ready = False
+
+    # -- weights ----------------------------------------------------------------
+    def load_state_dict(self, state: Dict[str, object], strict: bool = True) -> None:
+        """``state``: name -> numpy array / torch tensor (CPU or GPU), reference key names
+        (optionally prefixed ``diff_model.unet.`` as in a full NS2VC checkpoint)."""
+        spec = param_spec(self.cfg)
+        prefix = "diff_model.unet."
+        seen = set()
+        for name, shape in spec.items():
+            v = state.get(name, state.get(prefix + name))
+            if v is None:
+                if strict:
+                    raise KeyError(f"missing weight {name}")
+                continue
+            seen.add(name)
+            shp = (C.c_int64 * len(shape))(*shape)
+            if hasattr(v, "data_ptr"):      # torch
+                t = v.detach()
+                if tuple(t.shape) != tuple(shape):
+                    raise ValueError(f"{name}: shape {tuple(t.shape)} != {tuple(shape)}")
+                import torch  # plumbing only
+                t = t.to(dtype=torch.float32).contiguous()
+                check(self.lib.ns2vc_unet_load_weight(self.h, name.encode(), t.data_ptr(), shp, len(shape)), name)
+            else:
+                a = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+                if tuple(a.shape) != tuple(shape):
+                    raise ValueError(f"{name}: shape {tuple(a.shape)} != {tuple(shape)}")
+                check(self.lib.ns2vc_unet_load_weight(self.h, name.encode(), a.ctypes.data, shp, len(shape)), name)
+        if strict:
+            extra = [k for k in state if k not in spec and not (k.startswith(prefix) and k[len(prefix):] in spec)
+                     and k.startswith(("conv_", "time_embedding", "add_embedding", "down_blocks", "up_blocks", "mid_block"))]
+            if extra:
+                raise KeyError(f"unexpected denoiser keys: {extra[:4]}")
+        check(self.lib.ns2vc_unet_finalize_weights(self.h, PRECISIONS[self.precision]), "finalize_weights")
+        self._weights_ready = True
+        self.shape = None
+
+    # -- workspace ----------------------------------------------------------------
+    def set_debug(self, enable: bool) -> None:
+        check(self.lib.ns2vc_unet_set_debug(self.h, int(enable)), "set_debug")
+
+    def prepare(self, B: int, T: int, Lp: int) -> None:
+        check(self.lib.ns2vc_unet_prepare(self.h, B, T, Lp), "ns2vc_unet_prepare")
+        self.shape = (B, T, Lp)
+
+    def workspace_bytes(self) -> int:
+        n = C.c_size_t()
+        check(self.lib.ns2vc_unet_workspace_bytes(self.h, C.byref(n)), "workspace_bytes")
+        return int(n.value)
+
+    def launches(self) -> Tuple[int, int]:
+        a, b = C.c_int(), C.c_int()
+        check(self.lib.ns2vc_unet_num_launches(self.h, C.byref(a), C.byref(b)), "num_launches")
+        return int(a.value), int(b.value)
+
+    # -- compute (device pointers in, device pointers out) --------------------------
+    def set_condition(self, content, prompt, mask=None, stream=None) -> None:
+        """content (B,256,T) fp32, prompt (B,Lp,256) fp32, mask (B,Lp) uint8/bool or None — all on the GPU."""
+        check(self.lib.ns2vc_unet_set_condition(self.h, _ptr(content), _ptr(prompt), _ptr(mask), _stream_ptr(stream)), "set_condition")
+
+    def forward(self, x, t, out, stream=None) -> None:
+        """x (B,100,T), t (B,) fp32, out (B,100,T): one denoiser evaluation."""
+        check(self.lib.ns2vc_unet_forward(self.h, _ptr(x), _ptr(t), _ptr(out), _stream_ptr(stream)), "forward")
+
+    def load_sampler(self, solver: str, steps: int, betas: Optional[np.ndarray] = None, order: int = 2) -> SolverTable:
+        table = build_table(solver, steps, betas, order)
+        coef = np.ascontiguousarray(table.coef, dtype=np.float32)
+        assert coef.shape == (steps, NCOEF)
+        check(self.lib.ns2vc_sampler_load(self.h, steps, coef.ctypes.data_as(C.POINTER(C.c_float))), "sampler_load")
+        self.table = table
+        return table
+
+    def sample(self, x_inout, use_graph: bool = True, stream=None) -> None:
+        """x_inout (B,100,T): x_T in, sample out (in place).  NFE == steps of the loaded table."""
+        check(self.lib.ns2vc_sampler_run(self.h, _ptr(x_inout), int(use_graph), _stream_ptr(stream)), "sampler_run")
+
+    # -- profiling --------------------------------------------------------------------
+    def op_info(self, which: int = 0) -> List[Tuple[str, int, float, float]]:
+        """[(name, kind, algorithmic flops, algorithmic bytes)] of the per-step (0) / condition (1) plan."""
+        nf, nc = self.launches()
+        out = []
+        name = C.create_string_buffer(256)
+        kind, fl, by = C.c_int(), C.c_double(), C.c_double()
+        for i in range(nc if which else nf):
+            check(self.lib.ns2vc_unet_op_info(self.h, which, i, name, 256, C.byref(kind), C.byref(fl), C.byref(by)), "op_info")
+            out.append((name.value.decode(), int(kind.value), float(fl.value), float(by.value)))
+        return out
+
+    def profile_forward(self, stream=None) -> np.ndarray:
+        """Eager per-launch HIP-event timing of one per-step forward (ms per launch)."""
+        nf, _ = self.launches()
+        ms = (C.c_float * nf)()
+        check(self.lib.ns2vc_unet_profile_forward(self.h, ms, nf, _stream_ptr(stream)), "profile_forward")
+        return np.array(list(ms), dtype=np.float64)
+
+    # -- debug taps -----------------------------------------------------------------
+    def taps(self) -> Dict[str, np.ndarray]:
+        out: Dict[str, np.ndarray] = {}
+        n = self.lib.ns2vc_unet_num_taps(self.h)
+        name = C.create_string_buffer(256)
+        rows, cols = C.c_int(), C.c_int()
+        for i in range(n):
+            check(self.lib.ns2vc_unet_tap_info(self.h, i, name, 256, C.byref(rows), C.byref(cols)), "tap_info")
+            a = np.empty((rows.value, cols.value), dtype=np.float32)
+            check(self.lib.ns2vc_unet_tap_read(self.h, i, a.ctypes.data), "tap_read")
+            out[name.value.decode()] = a
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.ns2vc_unet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sync() -> None:
+    check(_lib.load().ns2vc_dev_sync(), "dev_sync")

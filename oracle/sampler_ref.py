@@ -38,7 +38,7 @@ class VPSchedule:
 
     def log_alpha_at(self, t: torch.Tensor) -> torch.Tensor:
         """Piecewise-linear interpolation with linear extrapolation outside the knots."""
-        t = t.reshape(-1).to(torch.float32)
+        t = t.reshape(-1).to(torch.float32).contiguous()
         K = self.N
         # segment [i, i+1] with knots[i] <= t (ties resolve to the left segment,
         # like the reference's sort-based search); clamp to the outermost segments

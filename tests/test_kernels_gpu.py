@@ -1,0 +1,338 @@
+"""GPU parity tests of the individual HIP kernels, driven through the C ABI
+(ctypes + numpy only, no torch).  References are plain numpy float64 restatements
+of the ATen ops the reference dispatches: conv1d / linear
+(+GroupNorm/LayerNorm-apply prologues, GEGLU / bias / residual epilogues),
+scaled_dot_product_attention, group_norm statistics, layer_norm statistics.
+
+Tolerances (relative L2 on the whole output):
+  fp32 "parity" kernels  : 2e-5   (exact-fp32 MFMA, only summation order differs)
+  bf16 kernels           : 6e-3 vs a float64 reference fed the SAME bf16-rounded operands
+"""
+from __future__ import annotations
+
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from util import bf16_round, gather_rows, gelu_erf, rel_l2, silu
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-5, 1: 6e-3}
+
+
+def _lib():
+    from ns2vc_amd import _lib
+    return _lib.load()
+
+
+def _dev(a):
+    from ns2vc_amd.engine import DevBuf
+    return DevBuf.from_numpy(np.ascontiguousarray(a))
+
+
+def _pack(W, prec):
+    lib = _lib()
+    from ns2vc_amd._lib import check
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    p = C.c_void_p()
+    check(lib.ns2vc_pack_weight(W.ctypes.data, W.shape[0], W.shape[1], prec, C.byref(p)), "pack_weight")
+    return p
+
+
+def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, pro, silu_on, bias_on, res_on, geglu, tile=(0, 0)):
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    Ct = c0 + c1
+    K = taps * Ct
+    M = B * Tout
+    a0 = rng.standard_normal((B, Tin, c0)).astype(np.float32)
+    a1 = rng.standard_normal((B, Tin, c1)).astype(np.float32) if c1 else None
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32) if bias_on else None
+    Nout = N // 2 if geglu else N
+    res = rng.standard_normal((M, Nout)).astype(np.float32) if res_on else None
+    A = a0 if a1 is None else np.concatenate([a0, a1], axis=-1)
+    A = A.astype(np.float64)
+    ps = ph = rs = None
+    if pro == 1:
+        ps = (1.0 + 0.3 * rng.standard_normal((B, Ct))).astype(np.float32)
+        ph = (0.3 * rng.standard_normal((B, Ct))).astype(np.float32)
+        A = A * ps[:, None, :] + ph[:, None, :]
+        if silu_on:
+            A = silu(A)
+    elif pro == 2:
+        assert Tin == Tout and taps == 1
+        mu = A.mean(-1)
+        rstd = 1.0 / np.sqrt(A.var(-1) + 1e-5)
+        rs = np.stack([mu, rstd], axis=-1).reshape(M, 2).astype(np.float32)
+        A = (A - rs[:, 0].reshape(B, Tin, 1).astype(np.float64)) * rs[:, 1].reshape(B, Tin, 1).astype(np.float64)
+    G = gather_rows(A, B, Tin, Tout, taps, tmode).reshape(M, K)
+    Wd = W.astype(np.float64)
+    if prec == 1:
+        G = bf16_round(G.astype(np.float32)).astype(np.float64)
+        Wd = bf16_round(W).astype(np.float64)
+    ref = G @ Wd.T
+    if bias is not None:
+        ref = ref + bias
+    if geglu:
+        r3 = ref.reshape(M, N // 64, 2, 32)
+        ref = (r3[:, :, 0, :] * gelu_erf(r3[:, :, 1, :])).reshape(M, N // 2)
+    if res is not None:
+        ref = ref + res
+
+    d_a0, d_a1 = _dev(a0), (_dev(a1) if a1 is not None else None)
+    d_w = _pack(W, prec)
+    d_bias = _dev(bias) if bias is not None else None
+    d_res = _dev(res) if res is not None else None
+    d_ps, d_ph = (_dev(ps), _dev(ph)) if ps is not None else (None, None)
+    d_rs = _dev(rs) if rs is not None else None
+    d_out = DevBuf(M * Nout * 4)
+    d_out.upload(np.full((M, Nout), np.nan, dtype=np.float32))
+    g = GemmArgs()
+    g.a0 = d_a0.ptr; g.lda0 = c0; g.c0 = c0
+    if d_a1 is not None:
+        g.a1 = d_a1.ptr; g.lda1 = c1; g.c1 = c1
+    g.B, g.Tin, g.Tout, g.M = B, Tin, Tout, M
+    g.taps, g.tmode = taps, tmode
+    if d_ps is not None:
+        g.pscale, g.pshift = d_ps.ptr, d_ph.ptr
+    if d_rs is not None:
+        g.rstats = d_rs.ptr
+    g.silu = int(silu_on)
+    g.w = d_w.value; g.K = K; g.N = N
+    if d_bias is not None:
+        g.bias = d_bias.ptr
+    if d_res is not None:
+        g.res = d_res.ptr; g.ldres = Nout
+    g.geglu = int(geglu)
+    g.out = d_out.ptr; g.ldo = Nout
+    check(lib.ns2vc_debug_set_gemm_tile(*tile), "set tile")
+    try:
+        check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+        sync()
+    finally:
+        lib.ns2vc_debug_set_gemm_tile(0, 0)
+    out = d_out.to_numpy((M, Nout))
+    lib.ns2vc_dev_free(d_w)
+    return out, ref
+
+
+GEMM_CASES = [
+    # name, B, Tin, Tout, c0, c1, N, taps, tmode, pro, silu, bias, res, geglu
+    ("linear_plain", 2, 75, 75, 128, 0, 128, 1, 0, 0, 0, 1, 0, 0),
+    ("linear_res_tail", 3, 41, 41, 256, 0, 192, 1, 0, 0, 0, 1, 1, 0),
+    ("conv3_gn_silu", 2, 37, 37, 128, 0, 128, 3, 0, 1, 1, 1, 0, 0),
+    ("conv3_concat_gn_silu_res", 2, 37, 37, 128, 64, 128, 3, 0, 1, 1, 1, 1, 0),
+    ("conv1_concat_shortcut", 2, 37, 37, 192, 128, 256, 1, 0, 0, 0, 1, 0, 0),
+    ("down2_odd", 2, 37, 19, 128, 0, 128, 3, 1, 0, 0, 1, 0, 0),
+    ("down2_even", 2, 38, 19, 128, 0, 128, 3, 1, 0, 0, 1, 0, 0),
+    ("up2_odd", 2, 19, 37, 128, 0, 128, 3, 2, 0, 0, 1, 0, 0),
+    ("up2_even", 2, 19, 38, 128, 0, 128, 3, 2, 0, 0, 1, 0, 0),
+    ("ln_row_qkv", 2, 50, 50, 128, 0, 384, 1, 0, 2, 0, 1, 0, 0),
+    ("ln_row_geglu", 2, 50, 50, 128, 0, 1024, 1, 0, 2, 0, 1, 0, 1),
+    ("gn_noact_proj_in", 2, 33, 33, 256, 0, 256, 1, 0, 1, 0, 1, 0, 0),
+    ("temb_m_small", 3, 1, 1, 512, 0, 640, 1, 0, 0, 0, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+def test_gemm_cases(case, prec, diag):
+    name, *args = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    out, ref = run_gemm(rng, prec, *args)
+    e = rel_l2(out, ref)
+    diag(f"gemm {name} prec={prec} rel_l2={e:.3e} nan={int(np.isnan(out).sum())}")
+    if not (e < TOL[prec]):
+        bad = np.argwhere(~(np.abs(out - ref) <= 1e-2 + 1e-2 * np.abs(ref)))
+        diag(f"  FAIL {name}: {len(bad)} bad of {out.size}; first {bad[:6].tolist()} rows_bad={sorted(set(bad[:, 0].tolist()))[:12]} cols_bad={sorted(set(bad[:, 1].tolist()))[:12]}")
+    assert e < TOL[prec], (name, e)
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("tile", [(128, 128), (64, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
+def test_gemm_every_tile(tile, prec, diag):
+    rng = np.random.default_rng(tile[0] * 1000 + tile[1])
+    # M = 3*167 = 501 rows (tail in every tile size), concat + conv3 + GN/SiLU + bias + residual
+    out, ref = run_gemm(rng, prec, 3, 167, 167, 128, 64, 256, 3, 0, 1, 1, 1, 1, 0, tile=tile)
+    e = rel_l2(out, ref)
+    diag(f"gemm tile={tile} prec={prec} rel_l2={e:.3e}")
+    assert e < TOL[prec]
+    if tile[1] == 128:
+        out, ref = run_gemm(rng, prec, 2, 90, 90, 256, 0, 512, 1, 0, 2, 0, 1, 0, 1, tile=tile)
+        e = rel_l2(out, ref)
+        diag(f"gemm geglu tile={tile} prec={prec} rel_l2={e:.3e}")
+        assert e < TOL[prec]
+
+
+def test_gemm_heuristic_large(diag):
+    """A level-0 sized problem (M = 4*938) goes through the tile heuristic."""
+    rng = np.random.default_rng(7)
+    for prec in (0, 1):
+        out, ref = run_gemm(rng, prec, 4, 938, 938, 128, 0, 128, 3, 0, 1, 1, 1, 1, 0)
+        e = rel_l2(out, ref)
+        diag(f"gemm level0 prec={prec} rel_l2={e:.3e}")
+        assert e < TOL[prec]
+
+
+# ---------------------------------------------------------------------------------------
+def ref_attention(q, k, v, bias, H, prec):
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    hd = D // H
+    qh = q.reshape(B, Lq, H, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    kh = k.reshape(B, Lk, H, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    vh = v.reshape(B, Lk, H, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    s = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(hd)
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    s = s - s.max(-1, keepdims=True)
+    p = np.exp(s)
+    p = p / p.sum(-1, keepdims=True)
+    o = p @ vh
+    return o.transpose(0, 2, 1, 3).reshape(B, Lq, D)
+
+
+ATTN_CASES = [
+    # name, B, H, hd, Lq, Lk, bias, packed_qkv
+    ("self_hd16", 2, 8, 16, 150, 150, False, True),
+    ("self_hd32", 2, 8, 32, 75, 75, False, True),
+    ("self_hd48", 1, 8, 48, 130, 130, False, True),
+    ("self_hd64", 2, 4, 64, 64, 64, False, True),
+    ("self_tiny", 1, 2, 16, 5, 5, False, True),
+    ("cross_hd16_mask", 2, 8, 16, 150, 69, True, False),
+    ("cross_hd32_mask", 2, 8, 32, 70, 130, True, False),
+    ("cross_hd48_mask", 2, 8, 48, 33, 21, True, False),
+    ("cross_hd64_mask", 2, 8, 64, 40, 469, True, False),
+]
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(case, prec, diag):
+    from ns2vc_amd._lib import AttnArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    name, B, H, hd, Lq, Lk, use_bias, packed = case
+    lib = _lib()
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    D = H * hd
+    q = rng.standard_normal((B, Lq, D)).astype(np.float32)
+    k = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    v = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    bias = None
+    if use_bias:
+        keep = rng.random((B, Lk)) > 0.3
+        keep[:, 0] = True
+        keep[0, Lk // 2:] = False          # a padded tail, like a ragged prompt batch
+        bias = np.where(keep, 0.0, -10000.0).astype(np.float32)
+    if prec == 1:
+        ref = ref_attention(bf16_round(q), bf16_round(k), bf16_round(v), bias, H, prec)
+    else:
+        ref = ref_attention(q, k, v, bias, H, prec)
+    a = AttnArgs()
+    if packed:   # q|k|v interleaved per row, as the fused QKV GEMM writes them
+        qkv = np.concatenate([q, k, v], axis=-1)
+        d_qkv = _dev(qkv)
+        a.q, a.k, a.v = d_qkv.ptr, d_qkv.ptr + D * 4, d_qkv.ptr + 2 * D * 4
+        a.ldq = a.ldk = a.ldv = 3 * D
+    else:        # k|v side by side with extra columns around, as the hoisted cross K/V buffer
+        pad = 64
+        kv = np.concatenate([np.zeros((B, Lk, pad), np.float32), k, v, np.zeros((B, Lk, pad), np.float32)], axis=-1)
+        d_q, d_kv = _dev(q), _dev(kv)
+        a.q, a.k, a.v = d_q.ptr, d_kv.ptr + pad * 4, d_kv.ptr + (pad + D) * 4
+        a.ldq, a.ldk, a.ldv = D, 2 * D + 2 * pad, 2 * D + 2 * pad
+    a.B, a.H, a.Lq, a.Lk = B, H, Lq, Lk
+    d_bias = _dev(bias) if bias is not None else None
+    if d_bias is not None:
+        a.bias = d_bias.ptr
+    a.scale = 1.0 / np.sqrt(hd)
+    d_out = DevBuf(B * Lq * D * 4)
+    d_out.upload(np.full((B, Lq, D), np.nan, dtype=np.float32))
+    a.out, a.ldo = d_out.ptr, D
+    check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
+    sync()
+    out = d_out.to_numpy((B, Lq, D))
+    e = rel_l2(out, ref)
+    diag(f"attn {name} prec={prec} rel_l2={e:.3e} nan={int(np.isnan(out).sum())}")
+    tol = 2e-5 if prec == 0 else 1.5e-2      # bf16: P is rounded to bf16 before the PV MFMA
+    if not e < tol:
+        err = np.abs(out - ref).reshape(B, Lq, H, hd)
+        diag(f"  FAIL {name}: per-head max err {err.max(axis=(0, 1, 3)).round(4).tolist()} per-d max {err.max(axis=(0, 1, 2)).round(3).tolist()[:16]}")
+        diag(f"  per-q (b0,h0) {err[0, :, 0, :].max(-1).round(3).tolist()[:40]}")
+    assert e < tol, (name, e)
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 37, 128, 0), (2, 90, 512, 384), (3, 200, 384, 256), (1, 5, 128, 128)], ids=str)
+def test_groupnorm_coef(shape, diag):
+    from ns2vc_amd._lib import check
+    from ns2vc_amd.engine import DevBuf
+    lib = _lib()
+    B, T, c0, c1 = shape
+    G = 8
+    C_ = c0 + c1
+    rng = np.random.default_rng(B * 1000 + T)
+    a0 = (rng.standard_normal((B, T, c0)) * 2 + 0.7).astype(np.float32)
+    a1 = (rng.standard_normal((B, T, c1)) - 0.4).astype(np.float32) if c1 else None
+    gamma = (1 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+    temb = rng.standard_normal((B, 2 * C_ + 64)).astype(np.float32) * 0.2
+    off = 64
+    A = (a0 if a1 is None else np.concatenate([a0, a1], -1)).astype(np.float64)
+    Ag = A.reshape(B, T, G, C_ // G)
+    mean = Ag.mean(axis=(1, 3))
+    var = Ag.var(axis=(1, 3))
+    rstd = 1 / np.sqrt(var + 1e-5)
+    sc = np.repeat(rstd, C_ // G, axis=1) * gamma
+    sh = beta - np.repeat(mean, C_ // G, axis=1) * sc
+    s1 = 1 + temb[:, off:off + C_]
+    sc_t, sh_t = sc * s1, sh * s1 + temb[:, off + C_:off + 2 * C_]
+    d_a0, d_a1 = _dev(a0), (_dev(a1) if a1 is not None else None)
+    d_g, d_b, d_t = _dev(gamma), _dev(beta), _dev(temb)
+    d_ps, d_ph = DevBuf(B * C_ * 4), DevBuf(B * C_ * 4)
+    for with_t, (rs_, rh_) in ((False, (sc, sh)), (True, (sc_t, sh_t))):
+        check(lib.ns2vc_k_groupnorm_coef(d_a0.ptr, c0, c0, d_a1.ptr if d_a1 else None, c1, c1, B, T, G, 1e-5, d_g.ptr, d_b.ptr,
+                                         d_t.ptr if with_t else None, temb.shape[1], off, d_ps.ptr, d_ph.ptr, None), "gn_coef")
+        ps, ph = d_ps.to_numpy((B, C_)), d_ph.to_numpy((B, C_))
+        e1, e2 = rel_l2(ps, rs_), rel_l2(ph, rh_)
+        diag(f"groupnorm {shape} temb={with_t} scale {e1:.2e} shift {e2:.2e}")
+        assert e1 < 1e-5 and e2 < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(77, 128), (300, 512), (5, 384), (1000, 256)], ids=str)
+def test_layernorm_stats(shape, diag):
+    from ns2vc_amd._lib import check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    M, C_ = shape
+    rng = np.random.default_rng(M)
+    x = (rng.standard_normal((M, C_)) * 1.5 + 0.3).astype(np.float32)
+    d_x, d_s = _dev(x), DevBuf(M * 2 * 4)
+    check(lib.ns2vc_k_layernorm_stats(d_x.ptr, C_, M, C_, 1e-5, d_s.ptr, None), "ln_stats")
+    sync()
+    st = d_s.to_numpy((M, 2))
+    mu = x.astype(np.float64).mean(-1)
+    rstd = 1 / np.sqrt(x.astype(np.float64).var(-1) + 1e-5)
+    assert rel_l2(st[:, 0], mu) < 1e-5 and rel_l2(st[:, 1], rstd) < 1e-5
+
+
+def test_layout_roundtrip(diag):
+    from ns2vc_amd._lib import check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(3)
+    for (B, C_, T, cpad) in [(2, 100, 37, 128), (3, 256, 188, 256), (1, 100, 938, 128)]:
+        x = rng.standard_normal((B, C_, T)).astype(np.float32)
+        d_x, d_y, d_z = _dev(x), DevBuf(B * T * cpad * 4), DevBuf(B * C_ * T * 4)
+        d_y.upload(np.full((B, T, cpad), np.nan, np.float32))
+        check(lib.ns2vc_k_nct_to_btc(d_x.ptr, C_, T, B, d_y.ptr, cpad, cpad, None), "nct_to_btc")
+        check(lib.ns2vc_k_btc_to_nct(d_y.ptr, cpad, C_, T, B, d_z.ptr, None), "btc_to_nct")
+        sync()
+        y = d_y.to_numpy((B, T, cpad))
+        assert np.array_equal(y[:, :, :C_], x.transpose(0, 2, 1))
+        assert np.all(y[:, :, C_:] == 0)
+        assert np.array_equal(d_z.to_numpy((B, C_, T)), x)
