@@ -632,7 +632,9 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   size_t maxMC = 0;   // max over levels of B*Tl*Cl
   int maxC = 0;
   for (int l = 0; l < nl; ++l) {
-    maxMC = std::max(maxMC, (size_t)B * Ts[l] * c.block_out_channels[l]);
+    // an upsampler writes the COARSER level's channel count at this level's length
+    const int cmax = std::max(c.block_out_channels[l], c.block_out_channels[std::min(l + 1, nl - 1)]);
+    maxMC = std::max(maxMC, (size_t)B * Ts[l] * cmax);
     maxC = std::max(maxC, c.block_out_channels[l]);
   }
   // ---- persistent state
