@@ -123,38 +123,45 @@ int ns2vc_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises
 
 /* ---- kernel-level entry points (unit-tested one by one through this ABI) -------------- */
 typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stride 2, nearest-up), linear */
-  const void* a0; const void* a1; /* channels-last fp32 sources; a1 = skip tensor of a no-copy concat or NULL */
+  /* "operand" tensors are stored in the engine's MFMA operand type: bf16 (precision 1) or fp32 (precision 0) */
+  const void* a0; const void* a1; /* channels-last operand-typed sources; a1 = second half of a no-copy concat or NULL */
   int32_t lda0, lda1, c0, c1;
   int32_t B, Tin, Tout, M;        /* M = B*Tout output rows */
   int32_t taps, tmode;            /* taps 1|3; tmode 0 same, 1 stride-2, 2 nearest-upsample-then-conv */
-  const float* pscale; const float* pshift; /* per (batch, channel) affine prologue (GroupNorm apply) or NULL */
-  const float* rstats;            /* per-row (mean, rstd) prologue (LayerNorm apply) or NULL */
-  int32_t silu;
   const void* w; int32_t K;       /* packed weights [N][K] from ns2vc_pack_weight */
   int32_t N;
   const float* bias;
-  const float* res; int32_t ldres;
+  const float* res; int32_t ldres;/* fp32 residual added in the epilogue, or NULL */
   int32_t geglu;
-  void* out; int32_t ldo;
+  float* out_f32; int32_t ldo_f32;/* fp32 result (residual stream), or NULL */
+  void* out_op; int32_t ldo_op;   /* operand-typed copy of the result (feeds the next GEMM / attention), or NULL */
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {
-  const void* q; const void* k; const void* v; /* fp32 rows; head h lives at columns [h*hd, (h+1)*hd) */
+  const void* q; const void* k; const void* v; /* operand-typed rows; head h lives at columns [h*hd, (h+1)*hd) */
   int32_t ldq, ldk, ldv;
   int32_t B, H, Lq, Lk;
   const float* bias;              /* additive [B][Lk] or NULL */
   float scale;
-  void* out; int32_t ldo;
+  void* out; int32_t ldo;         /* operand-typed */
 } ns2vc_attn_args;
 
+/* operand-typed conversions for tests: fp32 host [n] -> device operand buffer and back */
+int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev);
+int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);
 int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
 int ns2vc_debug_set_gemm_tile(int bm, int bn); /* force the GEMM tile (128|64 x 128|64); 0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
+/* GroupNorm statistics of a (possibly concatenated) fp32 tensor folded with gamma/beta (+ time scale/shift)
+ * into a per-(batch,channel) affine; then ns2vc_k_groupnorm_apply writes act(x*scale+shift) as an operand tensor. */
 int ns2vc_k_groupnorm_coef(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
                            const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off,
                            float* pscale, float* pshift, void* stream);
-int ns2vc_k_layernorm_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, void* stream);
+int ns2vc_k_groupnorm_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T,
+                            const float* pscale, const float* pshift, int silu, void* out_op, void* raw_op, int precision, void* stream);
+/* LayerNorm without affine (gamma/beta are folded into the consumer's weights): fp32 rows -> operand rows */
+int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream);
 int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream);
 int ns2vc_k_btc_to_nct(const float* src, int lds, int C, int T, int B, float* dst, void* stream);
 

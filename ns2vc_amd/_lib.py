@@ -36,11 +36,10 @@ class GemmArgs(C.Structure):
         ("lda0", C.c_int32), ("lda1", C.c_int32), ("c0", C.c_int32), ("c1", C.c_int32),
         ("B", C.c_int32), ("Tin", C.c_int32), ("Tout", C.c_int32), ("M", C.c_int32),
         ("taps", C.c_int32), ("tmode", C.c_int32),
-        ("pscale", C.c_void_p), ("pshift", C.c_void_p), ("rstats", C.c_void_p),
-        ("silu", C.c_int32),
         ("w", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int32), ("geglu", C.c_int32),
-        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("out_f32", C.c_void_p), ("ldo_f32", C.c_int32),
+        ("out_op", C.c_void_p), ("ldo_op", C.c_int32),
     ]
 
 
@@ -99,7 +98,10 @@ PROTOTYPES = {
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
     "ns2vc_k_groupnorm_coef": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "ns2vc_k_layernorm_stats": (_I, [_P, _I, _I, _I, C.c_float, _P, _P]),
+    "ns2vc_k_groupnorm_apply": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P, _I, _P]),
+    "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
+    "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),
+    "ns2vc_from_operand": (_I, [_P, C.c_size_t, _I, _P]),
     "ns2vc_k_nct_to_btc": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "ns2vc_k_btc_to_nct": (_I, [_P, _I, _I, _I, _I, _P, _P]),
 }

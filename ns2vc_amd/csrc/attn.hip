@@ -16,6 +16,7 @@
 //   bf16: v_mfma_f32_32x32x16_bf16, P rounded to bf16, fp32 softmax state / accumulators
 //   f32 : v_mfma_f32_32x32x2_f32 (exact fp32, parity mode)
 // head_dim in {16,32,48,64} (NS2VC: C_l/8 for C_l in {128,256,384,512}).
+// q/k/v/out are operand-typed tensors (bf16, or fp32 in parity mode): no conversions while staging.
 #include "common.h"
 
 namespace ns2vc {
@@ -23,7 +24,7 @@ namespace ns2vc {
 template <typename T> struct AMma;
 template <> struct AMma<float> {
   static constexpr int SZ = 4;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
@@ -34,8 +35,8 @@ template <> struct AMma<float> {
 };
 template <> struct AMma<bf16_t> {
   static constexpr int SZ = 2;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
-    union U { uint4 u; bf16x8_t v; };
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    union U { u32x4_t u; bf16x8_t v; };
     U ua, ub;
     ua.u = a; ub.u = b;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
@@ -45,17 +46,24 @@ template <> struct AMma<bf16_t> {
   __device__ static __forceinline__ int vpos(int key) { return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1); }
 };
 
-template <typename TM> __device__ __forceinline__ void lds_store4(char* p, const float4& v);
-template <> __device__ __forceinline__ void lds_store4<float>(char* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
-template <> __device__ __forceinline__ void lds_store4<bf16_t>(char* p, const float4& v) {
-  uint2 r;
-  r.x = (uint32_t)f32_to_bf16_bits(v.x) | ((uint32_t)f32_to_bf16_bits(v.y) << 16);
-  r.y = (uint32_t)f32_to_bf16_bits(v.z) | ((uint32_t)f32_to_bf16_bits(v.w) << 16);
-  *reinterpret_cast<uint2*>(p) = r;
+// scatter the EPC elements of one 16-B piece (one key, EPC consecutive d) down a V^T column
+template <typename TM> __device__ __forceinline__ void vt_scatter(char* vp, int rowb, const u32x4_t& v);
+template <> __device__ __forceinline__ void vt_scatter<float>(char* vp, int rowb, const u32x4_t& v) {
+  *reinterpret_cast<uint32_t*>(vp) = v.x;
+  *reinterpret_cast<uint32_t*>(vp + rowb) = v.y;
+  *reinterpret_cast<uint32_t*>(vp + 2 * rowb) = v.z;
+  *reinterpret_cast<uint32_t*>(vp + 3 * rowb) = v.w;
 }
-template <typename TM> __device__ __forceinline__ void lds_store1(char* p, float v);
-template <> __device__ __forceinline__ void lds_store1<float>(char* p, float v) { *reinterpret_cast<float*>(p) = v; }
-template <> __device__ __forceinline__ void lds_store1<bf16_t>(char* p, float v) { *reinterpret_cast<uint16_t*>(p) = f32_to_bf16_bits(v); }
+template <> __device__ __forceinline__ void vt_scatter<bf16_t>(char* vp, int rowb, const u32x4_t& v) {
+  *reinterpret_cast<uint16_t*>(vp) = (uint16_t)v.x;
+  *reinterpret_cast<uint16_t*>(vp + rowb) = (uint16_t)(v.x >> 16);
+  *reinterpret_cast<uint16_t*>(vp + 2 * rowb) = (uint16_t)v.y;
+  *reinterpret_cast<uint16_t*>(vp + 3 * rowb) = (uint16_t)(v.y >> 16);
+  *reinterpret_cast<uint16_t*>(vp + 4 * rowb) = (uint16_t)v.z;
+  *reinterpret_cast<uint16_t*>(vp + 5 * rowb) = (uint16_t)(v.z >> 16);
+  *reinterpret_cast<uint16_t*>(vp + 6 * rowb) = (uint16_t)v.w;
+  *reinterpret_cast<uint16_t*>(vp + 7 * rowb) = (uint16_t)(v.w >> 16);
+}
 
 template <typename TM, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
@@ -69,8 +77,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int NSL = SZ;                 // 32-B key-slabs per 32-key sub-tile (f32: 4x8 keys, bf16: 2x16 keys)
   constexpr int KBYTES = 64 * KROWB, VBYTES = HDP * VROWB;
   constexpr int STAGE = KBYTES + VBYTES + 64 * 4;
-  constexpr int UPT = HD / 16;            // float4 units per thread per tile (K and V each)
-  constexpr int QPR = HD / 4;             // float4 units per key row
+  constexpr int PPR = HD * SZ / 16;       // 16-B pieces per key row
+  constexpr int NPIECE = 64 * PPR;        // pieces per K (or V) tile
+  constexpr int UPT = (NPIECE + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,55 +87,43 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + l31;
   const float LOG2E = 1.4426950408889634f;
+  const float sc2 = a.scale * LOG2E;      // scores are kept in log2 units: t = s*sc2 (+ bias*log2e)
 
   // zero both stages once (V^T pad rows d >= HD must read as 0)
-  for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+  for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4_t*>(smem + i) = u32x4_t{0, 0, 0, 0};
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds d = s*2*EPC + hi*EPC .. +EPC
-  uint4 qf[NS];
+  u32x4_t qf[NS];
   {
-    const float sc = a.scale * LOG2E;
-    const float* qp = reinterpret_cast<const float*>(a.q) + ((size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldq + h * HD);
+    const TM* qp = reinterpret_cast<const TM*>(a.q) + ((size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldq + h * HD);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      float v[EPC];
-#pragma unroll
-      for (int e = 0; e < EPC; e += 4) {
-        float4 t = *reinterpret_cast<const float4*>(qp + s * 2 * EPC + hi * EPC + e);
-        if (q >= a.Lq) t = make_float4(0.f, 0.f, 0.f, 0.f);
-        v[e] = t.x * sc; v[e + 1] = t.y * sc; v[e + 2] = t.z * sc; v[e + 3] = t.w * sc;
-      }
-      if constexpr (SZ == 4) {
-        qf[s] = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-      } else {
-        qf[s].x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-        qf[s].y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-        qf[s].z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-        qf[s].w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
-      }
+      qf[s] = *reinterpret_cast<const u32x4_t*>(qp + s * 2 * EPC + hi * EPC);
+      if (q >= a.Lq) qf[s] = u32x4_t{0, 0, 0, 0};
     }
   }
 
-  const float* kbase = reinterpret_cast<const float*>(a.k) + (size_t)b * a.Lk * a.ldk + h * HD;
-  const float* vbase = reinterpret_cast<const float*>(a.v) + (size_t)b * a.Lk * a.ldv + h * HD;
+  const TM* kbase = reinterpret_cast<const TM*>(a.k) + (size_t)b * a.Lk * a.ldk + h * HD;
+  const TM* vbase = reinterpret_cast<const TM*>(a.v) + (size_t)b * a.Lk * a.ldv + h * HD;
   const float* bias = a.bias ? a.bias + (size_t)b * a.Lk : nullptr;
 
-  float4 kraw[UPT], vraw[UPT];
+  u32x4_t kraw[UPT], vraw[UPT];
   float braw = 0.f;
-  auto load_tile = [&](int t) {
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int key0 = t * 64;
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + 256 * i;
-      {  // K: row-major units, coalesced along d
-        const int key = u / QPR, dq = u - key * QPR;
+      const u32x4_t z = {0, 0, 0, 0};
+      {  // K: row-major pieces, coalesced along d
+        const int key = u / PPR, pc = u - key * PPR;
         const int kk = key0 + key;
-        kraw[i] = (kk < a.Lk) ? *reinterpret_cast<const float4*>(kbase + (size_t)kk * a.ldk + dq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        kraw[i] = (u < NPIECE && kk < a.Lk) ? *reinterpret_cast<const u32x4_t*>(kbase + (size_t)kk * a.ldk + pc * EPC) : z;
       }
-      {  // V: key-fastest units (transposed LDS write is then conflict-free)
-        const int key = u & 63, dq = u >> 6;
+      {  // V: key-fastest pieces (the transposed LDS write is then conflict-free)
+        const int key = u & 63, pc = u >> 6;
         const int kk = key0 + key;
-        vraw[i] = (kk < a.Lk) ? *reinterpret_cast<const float4*>(vbase + (size_t)kk * a.ldv + dq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vraw[i] = (u < NPIECE && kk < a.Lk) ? *reinterpret_cast<const u32x4_t*>(vbase + (size_t)kk * a.ldv + pc * EPC) : z;
       }
     }
     if (tid < 64) {
@@ -134,25 +131,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
       braw = (kk < a.Lk) ? (bias ? bias[kk] * LOG2E : 0.f) : -INFINITY;
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage) __attribute__((always_inline)) {
     char* Ks = smem + stage * STAGE;
     char* Vs = Ks + KBYTES;
     float* Bs = reinterpret_cast<float*>(Vs + VBYTES);
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + 256 * i;
-      {
-        const int key = u / QPR, dq = u - key * QPR;
-        lds_store4<TM>(Ks + key * KROWB + dq * 4 * SZ, kraw[i]);
-      }
-      {
-        const int key = u & 63, dq = u >> 6;
-        const int pos = (key & 32) + AMma<TM>::vpos(key & 31);
-        char* vp = Vs + (dq * 4) * VROWB + pos * SZ;
-        lds_store1<TM>(vp, vraw[i].x);
-        lds_store1<TM>(vp + VROWB, vraw[i].y);
-        lds_store1<TM>(vp + 2 * VROWB, vraw[i].z);
-        lds_store1<TM>(vp + 3 * VROWB, vraw[i].w);
+      if (u < NPIECE) {
+        {
+          const int key = u / PPR, pc = u - key * PPR;
+          *reinterpret_cast<u32x4_t*>(Ks + key * KROWB + pc * 16) = kraw[i];
+        }
+        {
+          const int key = u & 63, pc = u >> 6;
+          const int pos = (key & 32) + AMma<TM>::vpos(key & 31);
+          vt_scatter<TM>(Vs + (pc * EPC) * VROWB + pos * SZ, VROWB, vraw[i]);
+        }
       }
     }
     if (tid < 64) Bs[tid] = braw;
@@ -185,11 +180,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) s[k2][r] = 0.f;
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) {
-        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (k2 * 32 + l31) * KROWB + sl * 32 + hi * 16);
+        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + (k2 * 32 + l31) * KROWB + sl * 32 + hi * 16);
         AMma<TM>::mma(s[k2], kf, qf[sl]);
       }
     }
-    // ---- additive bias (mask) and tail-key masking; lane's keys: k2*32 + 8*g + 4*hi + i
+    // ---- to log2 units, additive bias (mask) and tail-key masking; lane's keys: k2*32 + 8*g + 4*hi + i
     const bool need_bias = (bias != nullptr) || (t * 64 + 64 > a.Lk);
     if (need_bias) {
 #pragma unroll
@@ -197,7 +192,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           const float4 bb = *reinterpret_cast<const float4*>(Bs + k2 * 32 + 8 * gq + 4 * hi);
-          s[k2][4 * gq + 0] += bb.x; s[k2][4 * gq + 1] += bb.y; s[k2][4 * gq + 2] += bb.z; s[k2][4 * gq + 3] += bb.w;
+          s[k2][4 * gq + 0] = fmaf(s[k2][4 * gq + 0], sc2, bb.x); s[k2][4 * gq + 1] = fmaf(s[k2][4 * gq + 1], sc2, bb.y);
+          s[k2][4 * gq + 2] = fmaf(s[k2][4 * gq + 2], sc2, bb.z); s[k2][4 * gq + 3] = fmaf(s[k2][4 * gq + 3], sc2, bb.w);
         }
     }
     // ---- online softmax (base-2), state per query = per lane (both lane halves agree on m)
@@ -206,18 +202,30 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
+    if (!need_bias) mx *= sc2;                       // sc2 > 0: max commutes with the scaling
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
+    if (need_bias) {
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+      for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(s[k2][r] - m_new);
-        s[k2][r] = p;
-        psum += p;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[k2][r] - m_new);
+          s[k2][r] = p;
+          psum += p;
+        }
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[k2][r], sc2, -m_new));
+          s[k2][r] = p;
+          psum += p;
+        }
+    }
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
@@ -230,19 +238,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) {
-        uint4 pf;
+        u32x4_t pf;
         if constexpr (SZ == 4) {
-          pf = make_uint4(__float_as_uint(s[k2][4 * sl + 0]), __float_as_uint(s[k2][4 * sl + 1]),
-                          __float_as_uint(s[k2][4 * sl + 2]), __float_as_uint(s[k2][4 * sl + 3]));
+          pf = u32x4_t{__float_as_uint(s[k2][4 * sl + 0]), __float_as_uint(s[k2][4 * sl + 1]),
+                       __float_as_uint(s[k2][4 * sl + 2]), __float_as_uint(s[k2][4 * sl + 3])};
         } else {
-          pf.x = (uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 0]) | ((uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 1]) << 16);
-          pf.y = (uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 2]) | ((uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 3]) << 16);
-          pf.z = (uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 4]) | ((uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 5]) << 16);
-          pf.w = (uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 6]) | ((uint32_t)f32_to_bf16_bits(s[k2][8 * sl + 7]) << 16);
+          pf = u32x4_t{pack_bf16x2(s[k2][8 * sl + 0], s[k2][8 * sl + 1]), pack_bf16x2(s[k2][8 * sl + 2], s[k2][8 * sl + 3]),
+                       pack_bf16x2(s[k2][8 * sl + 4], s[k2][8 * sl + 5]), pack_bf16x2(s[k2][8 * sl + 6], s[k2][8 * sl + 7])};
         }
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
-          const uint4 vf = *reinterpret_cast<const uint4*>(Vs + (d * 32 + l31) * VROWB + k2 * 32 * SZ + sl * 32 + hi * 16);
+          const u32x4_t vf = *reinterpret_cast<const u32x4_t*>(Vs + (d * 32 + l31) * VROWB + k2 * 32 * SZ + sl * 32 + hi * 16);
           AMma<TM>::mma(o[d], vf, pf);
         }
       }
@@ -255,16 +261,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.0f / l_tot;
   if (q < a.Lq) {
-    float* op = reinterpret_cast<float*>(a.out) + ((size_t)(b * a.Lq + q) * a.ldo + h * HD);
+    TM* op = reinterpret_cast<TM*>(a.out) + ((size_t)(b * a.Lq + q) * a.ldo + h * HD);
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int d0 = d * 32 + 8 * gq + 4 * hi;
-        if (d0 < HD) {
-          *reinterpret_cast<float4*>(op + d0) =
-              make_float4(o[d][4 * gq] * inv, o[d][4 * gq + 1] * inv, o[d][4 * gq + 2] * inv, o[d][4 * gq + 3] * inv);
-        }
+        if (d0 < HD) store_op4<TM>(op + d0, o[d][4 * gq] * inv, o[d][4 * gq + 1] * inv, o[d][4 * gq + 2] * inv, o[d][4 * gq + 3] * inv);
       }
   }
 }
@@ -310,7 +313,8 @@ hipError_t init_attn_attributes() {
 }
 
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s) {
-  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldq & 3) || (a.ldk & 3) || (a.ldv & 3) || (a.ldo & 3)) return hipErrorInvalidValue;
+  const int al = prec == PREC_BF16 ? 7 : 3;      // rows must start 16-B aligned
+  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldq & al) || (a.ldk & al) || (a.ldv & al) || (a.ldo & 3)) return hipErrorInvalidValue;
   return prec == PREC_BF16 ? launch_tm<bf16_t>(a, head_dim, s) : launch_tm<float>(a, head_dim, s);
 }
 

@@ -29,6 +29,35 @@ __host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
   return x.f;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// hardware round-to-nearest-even pack (v_cvt_pk_bf16_f32): lo -> bits [15:0], hi -> bits [31:16]
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  union { bf16x2_t b; uint32_t u; } r;
+  r.b = __builtin_convertvector(v, bf16x2_t);
+  return r.u;
+}
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// operand-typed scalar / 4-vector stores and loads (TM = float or bf16_t)
+template <typename TM> __device__ __forceinline__ void store_op(TM* p, float v);
+template <> __device__ __forceinline__ void store_op<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_op<bf16_t>(bf16_t* p, float v) { p->v = (uint16_t)pack_bf16x2(v, 0.f); }
+template <typename TM> __device__ __forceinline__ void store_op4(TM* p, float a, float b, float c, float d);
+template <> __device__ __forceinline__ void store_op4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> __device__ __forceinline__ void store_op4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+template <typename TM> __device__ __forceinline__ void store_op2(TM* p, float a, float b);
+template <> __device__ __forceinline__ void store_op2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+template <> __device__ __forceinline__ void store_op2<bf16_t>(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b); }
+#endif
+
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float silu_f(float v) { return v * fast_rcp(1.0f + __expf(-v)); }
 __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
@@ -54,17 +83,20 @@ hipError_t init_gemm_attributes();
 void set_forced_gemm_tile(int bm, int bn);
 hipError_t init_attn_attributes();
 
-// misc kernels (misc.hip)
+// misc kernels (misc.hip).  "op" buffers are operand-typed (bf16 when prec == PREC_BF16, else fp32)
 hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1,
                              int B, int T, int G, double* partial, int nchunk, int rows_per_chunk, hipStream_t s);
 hipError_t launch_gn_coef(const double* partial, int nchunk, int B, int T, int C, int G, float eps,
                           const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off, int cout,
                           float* pscale, float* pshift, hipStream_t s);
-hipError_t launch_ln_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, hipStream_t s);
+hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T,
+                           const float* pscale, const float* pshift, int silu, void* out_op, void* raw_op, int prec, hipStream_t s);
+hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s);
+hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s);
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride,
                              const float* w1t, const float* b1, const float* w2t, const float* b2,
-                             const float* aug, float* emb, float* emb_act, int B, int tdim, int edim, hipStream_t s);
-hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, hipStream_t s);
+                             const float* aug, float* emb, void* emb_act_op, int prec, int B, int tdim, int edim, hipStream_t s);
+hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s);
 hipError_t launch_btc_to_nct(const float* src, int lds, int C, int T, int B, float* dst, hipStream_t s);
 hipError_t launch_mask_bias(const uint8_t* mask, int n, float* bias, hipStream_t s);
 hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float* gamma, const float* beta,
@@ -74,7 +106,7 @@ hipError_t launch_pool_attn(const float* qkv, int B, int L1, int C, int heads, f
 hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, const float* b, int E,
                             const float* gamma, const float* beta, float eps, float* out, hipStream_t s);
 hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0,
-                                float* xe, float* xbar, float* d1, float* mprev, size_t n, hipStream_t s);
+                                float* xe, void* xe_op, int prec, float* xbar, float* d1, float* mprev, size_t n, hipStream_t s);
 hipError_t launch_step_advance(int* step_ptr, hipStream_t s);
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s);
 

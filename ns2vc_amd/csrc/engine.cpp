@@ -117,9 +117,10 @@ struct ns2vc_unet {
 
   // named persistent buffers
   float *xe = nullptr, *xbar = nullptr, *d1 = nullptr, *mprev = nullptr, *x0 = nullptr;
-  float *content_btc = nullptr, *content_conv = nullptr, *prompt = nullptr, *maskbias = nullptr;
-  float *aug = nullptr, *emb = nullptr, *emb_act = nullptr, *temb = nullptr, *kv = nullptr;
+  float *content_conv = nullptr, *prompt = nullptr, *maskbias = nullptr;
+  float *aug = nullptr, *emb = nullptr, *temb = nullptr;
   float *seq = nullptr, *pool_qkv_buf = nullptr, *pooled = nullptr;
+  void *xe_op = nullptr, *content_op = nullptr, *prompt_op = nullptr, *emb_act_op = nullptr, *kv = nullptr, *seq_op = nullptr;   // operand-typed
   float *t_dev = nullptr;
   uint8_t* mask_dev = nullptr;
   int* step_dev = nullptr;
@@ -470,7 +471,9 @@ int pack_all(ns2vc_unet* h) {
 }
 
 // ------------------------------------------------------------------------------------
-// plan building
+// plan building.  Two kinds of activation tensors:
+//   fp32  "stream" tensors : residual stream, skips, GroupNorm inputs (statistics stay fp32)
+//   "op"  operand tensors  : what GEMMs / attention read — bf16 (perf) or fp32 (parity)
 // ------------------------------------------------------------------------------------
 struct Planner {
   ns2vc_unet* h;
@@ -478,17 +481,23 @@ struct Planner {
   bool sizing = false;       // first pass: only measure the arena
   size_t off = 0;
   int B, T, Lp, G, prec;
+  size_t opsz = 2;
   // scratch shared by all layers (stream-ordered)
   double* gn_partial = nullptr;
-  float *ps = nullptr, *ph = nullptr, *rstats = nullptr;
+  float *ps = nullptr, *ph = nullptr;
+  void *xn = nullptr, *xr = nullptr;     // GroupNorm-applied / raw operand copies of a resnet input
   int gn_rows = 64;
 
-  template <typename Tp> Tp* alloc(size_t count) {
-    const size_t bytes = (count * sizeof(Tp) + 255) & ~(size_t)255;
-    Tp* p = sizing ? nullptr : reinterpret_cast<Tp*>(reinterpret_cast<char*>(h->arena) + off);
+  char* alloc_bytes(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    char* p = sizing ? nullptr : reinterpret_cast<char*>(h->arena) + off;
     off += bytes;
     return p;
   }
+  template <typename Tp> Tp* alloc(size_t count) { return reinterpret_cast<Tp*>(alloc_bytes(count * sizeof(Tp))); }
+  void* alloc_op(size_t count) { return alloc_bytes(count * opsz); }
+  void* op_off(void* p, size_t elems) const { return p ? static_cast<void*>(static_cast<char*>(p) + elems * opsz) : nullptr; }
+
   void add(const std::string& name, std::function<hipError_t(hipStream_t)> fn, int kind = 0, double flops = 0.0, double bytes = 0.0) {
     if (sizing) return;
     Op op;
@@ -506,62 +515,66 @@ struct Planner {
 
   void gemm(const std::string& name, GemmArgs g) {
     const int pr = prec;
-    const double wsz = pr == PREC_BF16 ? 2.0 : 4.0;
+    const double osz = (double)opsz;
     const double nout = g.geglu ? g.N / 2 : g.N;
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     const double in_rows = (double)g.B * g.Tin;
-    const double bytes = in_rows * (g.c0 + g.c1) * 4.0 + (double)g.N * g.K * wsz + g.M * nout * 4.0 + (g.res ? g.M * nout * 4.0 : 0.0);
+    const double bytes = in_rows * (g.c0 + g.c1) * osz + (double)g.N * g.K * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
+                         (g.out_op ? g.M * nout * osz : 0.0) + (g.res ? g.M * nout * 4.0 : 0.0);
     add(name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes);
   }
-  GemmArgs base(const float* a0, int lda0, int c0, int Tin, int Tout, const PackedW& w, float* out, int ldo) {
+  // A = operand tensor [B*Tin][c0]; results to out_f32 and/or out_op (row stride = logical width)
+  GemmArgs base(const void* a0, int lda0, int c0, int Tin, int Tout, const PackedW& w, float* out_f32, void* out_op, int ldo) {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.a0 = a0; g.lda0 = lda0; g.c0 = c0;
     g.B = B; g.Tin = Tin; g.Tout = Tout; g.M = B * Tout;
     g.taps = 1; g.tmode = TMODE_SAME;
     g.w = w.w; g.K = w.K; g.N = w.N; g.bias = w.bias;
-    g.out = out; g.ldo = ldo;
+    g.out_f32 = out_f32; g.ldo_f32 = ldo;
+    g.out_op = out_op; g.ldo_op = ldo;
     return g;
   }
-  // GroupNorm statistics + per-(b,c) affine for a (possibly concatenated) input
+  // GroupNorm of a (possibly concatenated) fp32 input: statistics -> per-(b,c) affine -> operand tensor `dst`
+  // (= act(GN(x)) with the concat materialised), optionally also the raw concat `raw` for a 1x1 shortcut.
   void groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
-                 const float* gamma, const float* beta, const float* temb, int temb_off, int cout) {
-    const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N;
+                 const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw) {
+    const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N, pr = prec;
     double* part = gn_partial; float* ps_ = ps; float* ph_ = ph;
+    const double n = (double)Bq * Tl * (c0 + c1);
     add(name + ".gn_stats", [=](hipStream_t s) { return launch_gn_partial(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, part, nchunk, rows, s); },
-        3, 3.0 * Bq * Tl * (c0 + c1), 4.0 * Bq * Tl * (c0 + c1));
+        3, 3.0 * n, 4.0 * n);
     add(name + ".gn_coef", [=](hipStream_t s) {
       return launch_gn_coef(part, nchunk, Bq, Tl, c0 + c1, Gq, eps, gamma, beta, temb, ldt, temb_off, cout, ps_, ph_, s);
     });
+    add(name + ".gn_apply", [=](hipStream_t s) { return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, ps_, ph_, silu, dst, raw, pr, s); },
+        3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0)));
   }
 
-  void resnet(const ResnetW& r, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float* h1, float* sc,
-              float* out) {
-    const auto& c = h->cfg;
-    (void)c;
-    groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0);
-    GemmArgs g = base(a0, lda0, c0, Tl, Tl, r.conv1, h1, r.cout);
-    g.a1 = a1; g.lda1 = lda1; g.c1 = c1; g.taps = 3;
-    g.pscale = ps; g.pshift = ph; g.silu = 1;
+  // ResnetBlock2D (resnet.py:591-641).  out (fp32) [+ out_op operand copy when a conv consumes it next]
+  void resnet(const ResnetW& r, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float* h1, void* hn,
+              float* sc, float* out, void* out_op) {
+    const int cin = c0 + c1;
+    groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
+    GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
+    g.taps = 3;
     gemm(r.prefix + ".conv1", g);
-    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout);
+    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
     const float* res; int ldres;
     if (r.shortcut) {
-      GemmArgs s = base(a0, lda0, c0, Tl, Tl, r.sc, sc, r.cout);
-      s.a1 = a1; s.lda1 = lda1; s.c1 = c1;
+      GemmArgs s = base(xr, cin, cin, Tl, Tl, r.sc, sc, nullptr, r.cout);
       gemm(r.prefix + ".conv_shortcut", s);
       res = sc; ldres = r.cout;
     } else {
       res = a0; ldres = lda0;
     }
-    GemmArgs g2 = base(h1, r.cout, r.cout, Tl, Tl, r.conv2, out, r.cout);
-    g2.taps = 3; g2.pscale = ps; g2.pshift = ph; g2.silu = 1;
-    g2.res = res; g2.ldres = ldres;
+    GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
+    g2.taps = 3; g2.res = res; g2.ldres = ldres;
     gemm(r.prefix + ".conv2", g2);
   }
 
-  void attention(const std::string& name, const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int Lq, int Lk,
-                 const float* bias, int hd, float* out, int ldo) {
+  void attention(const std::string& name, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int Lq, int Lk,
+                 const float* bias, int hd, void* out, int ldo) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -570,48 +583,47 @@ struct Planner {
     a.out = out; a.ldo = ldo;
     const int pr = prec;
     add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd,
-        4.0 * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
+        (double)opsz * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
   }
 
-  void transformer(const AttnW& a, const float* x, int Tl, float* y, float* qkv, float* ao, float* qb, float* ffh, float* out) {
-    const int d = a.dim, M = B * Tl, hd = d / h->cfg.heads;
+  // Transformer2DModel + BasicTransformerBlock (transformer_1d.py:256-295, attention.py:130-203)
+  void transformer(const AttnW& a, const float* x, int Tl, float* y, void* yn, void* qkv, void* ao, void* qb, void* ffh, float* out,
+                   void* out_op) {
+    const int d = a.dim, M = B * Tl, hd = d / h->cfg.heads, pr = prec;
     const std::string t = a.prefix + ".transformer_blocks.0";
-    groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0);
-    GemmArgs g = base(x, d, d, Tl, Tl, a.proj_in, y, d);
-    g.pscale = ps; g.pshift = ph; g.silu = 0;
+    groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
+    GemmArgs g = base(xn, d, d, Tl, Tl, a.proj_in, y, nullptr, d);
     gemm(a.prefix + ".proj_in", g);
-    float* rs = rstats;
-    auto lnstats = [&](const std::string& nm) {
-      add(nm, [=](hipStream_t s) { return launch_ln_stats(y, d, M, d, 1e-5f, rs, s); }, 3, 4.0 * M * d, 4.0 * M * d);
+    auto layernorm = [&](const std::string& nm) {
+      add(nm, [=](hipStream_t s) { return launch_ln_apply_op(y, d, M, d, 1e-5f, yn, pr, s); }, 3, 8.0 * M * d, (4.0 + opsz) * M * d);
     };
     // self attention
-    lnstats(t + ".norm1");
-    g = base(y, d, d, Tl, Tl, a.qkv, qkv, 3 * d);
-    g.rstats = rstats;
+    layernorm(t + ".norm1");
+    g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
     gemm(t + ".attn1.qkv", g);
-    attention(t + ".attn1.sdpa", qkv, 3 * d, qkv + d, 3 * d, qkv + 2 * d, 3 * d, Tl, Tl, nullptr, hd, ao, d);
-    g = base(ao, d, d, Tl, Tl, a.o1, y, d);
+    attention(t + ".attn1.sdpa", qkv, 3 * d, op_off(qkv, d), 3 * d, op_off(qkv, 2 * d), 3 * d, Tl, Tl, nullptr, hd, ao, d);
+    g = base(ao, d, d, Tl, Tl, a.o1, y, nullptr, d);
     g.res = y; g.ldres = d;
     gemm(t + ".attn1.to_out", g);
     // cross attention (k|v hoisted into h->kv by set_condition)
-    lnstats(t + ".norm2");
-    g = base(y, d, d, Tl, Tl, a.q2, qb, d);
-    g.rstats = rstats;
+    layernorm(t + ".norm2");
+    g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
     gemm(t + ".attn2.to_q", g);
     const int nkv = h->kv_all.N;
-    attention(t + ".attn2.sdpa", qb, d, h->kv + a.kv_off, nkv, h->kv + a.kv_off + d, nkv, Tl, Lp, h->has_mask ? h->maskbias : nullptr, hd, ao, d);
-    g = base(ao, d, d, Tl, Tl, a.o2, y, d);
+    attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
+              h->has_mask ? h->maskbias : nullptr, hd, ao, d);
+    g = base(ao, d, d, Tl, Tl, a.o2, y, nullptr, d);
     g.res = y; g.ldres = d;
     gemm(t + ".attn2.to_out", g);
     // feed-forward (GEGLU)
-    lnstats(t + ".norm3");
-    g = base(y, d, d, Tl, Tl, a.ff1, ffh, 4 * d);
-    g.rstats = rstats; g.geglu = 1;
+    layernorm(t + ".norm3");
+    g = base(yn, d, d, Tl, Tl, a.ff1, nullptr, ffh, 4 * d);
+    g.geglu = 1;
     gemm(t + ".ff.geglu", g);
-    g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ff2, y, d);
+    g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ff2, nullptr, yn, d);     // y_final = y + ff(...) is only consumed by proj_out: operand copy only
     g.res = y; g.ldres = d;
     gemm(t + ".ff.out", g);
-    g = base(y, d, d, Tl, Tl, a.proj_out, out, d);
+    g = base(yn, d, d, Tl, Tl, a.proj_out, out, out_op, d);
     g.res = x; g.ldres = d;
     gemm(a.prefix + ".proj_out", g);
   }
@@ -627,9 +639,11 @@ int build_plan(ns2vc_unet* h, bool sizing) {
 
   Planner P;
   P.h = h; P.sizing = sizing; P.B = B; P.T = T; P.Lp = Lp; P.G = c.norm_num_groups; P.prec = h->prec;
+  P.opsz = h->prec == PREC_BF16 ? 2 : 4;
+  const int prec = h->prec;
   if (!sizing) { h->cond_ops.clear(); h->fwd_ops.clear(); h->taps.clear(); }
 
-  size_t maxMC = 0;   // max over levels of B*Tl*Cl
+  size_t maxMC = 0, maxIn = 0;   // max over levels of B*Tl*C (outputs) / over resnets of B*Tl*Cin (concat inputs)
   int maxC = 0;
   for (int l = 0; l < nl; ++l) {
     // an upsampler writes the COARSER level's channel count at this level's length
@@ -637,19 +651,26 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     maxMC = std::max(maxMC, (size_t)B * Ts[l] * cmax);
     maxC = std::max(maxC, c.block_out_channels[l]);
   }
+  for (const auto& b : h->blocks)
+    for (const auto& r : b.res) maxIn = std::max(maxIn, (size_t)B * Ts[b.level] * r.cin);
+  maxIn = std::max(maxIn, maxMC);
   // ---- persistent state
   h->xe = P.alloc<float>((size_t)B * T * CP); h->xbar = P.alloc<float>((size_t)B * T * CP);
   h->d1 = P.alloc<float>((size_t)B * T * CP); h->mprev = P.alloc<float>((size_t)B * T * CP);
   h->x0 = P.alloc<float>((size_t)B * T * CP);
-  h->content_btc = P.alloc<float>((size_t)B * T * c.content_channels);
+  h->xe_op = P.alloc_op((size_t)B * T * CP);
+  h->content_op = P.alloc_op((size_t)B * T * c.content_channels);
   h->content_conv = P.alloc<float>((size_t)B * T * c0);
   h->prompt = P.alloc<float>((size_t)B * Lp * cross);
+  h->prompt_op = P.alloc_op((size_t)B * Lp * cross);
   h->maskbias = P.alloc<float>((size_t)B * Lp);
   h->mask_dev = P.alloc<uint8_t>((size_t)B * Lp);
-  h->aug = P.alloc<float>((size_t)B * E); h->emb = P.alloc<float>((size_t)B * E); h->emb_act = P.alloc<float>((size_t)B * E);
+  h->aug = P.alloc<float>((size_t)B * E); h->emb = P.alloc<float>((size_t)B * E);
+  h->emb_act_op = P.alloc_op((size_t)B * E);
   h->temb = P.alloc<float>((size_t)B * h->temb_all.N);
-  h->kv = P.alloc<float>((size_t)B * Lp * h->kv_all.N);
+  h->kv = P.alloc_op((size_t)B * Lp * h->kv_all.N);
   h->seq = P.alloc<float>((size_t)B * (Lp + 1) * cross);
+  h->seq_op = P.alloc_op((size_t)B * (Lp + 1) * cross);
   h->pool_qkv_buf = P.alloc<float>((size_t)B * (Lp + 1) * h->pool_qkv.N);
   h->pooled = P.alloc<float>((size_t)B * cross);
   h->t_dev = P.alloc<float>((size_t)B);
@@ -658,14 +679,17 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   P.gn_rows = 64;
   P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
   P.ps = P.alloc<float>((size_t)B * 2 * maxC); P.ph = P.alloc<float>((size_t)B * 2 * maxC);
-  P.rstats = P.alloc<float>((size_t)B * std::max(T, Lp + 1) * 2);
+  P.xn = P.alloc_op(maxIn); P.xr = P.alloc_op(maxIn);
   float* h1 = P.alloc<float>(maxMC);
+  void* hn = P.alloc_op(maxMC);
   float* scb = P.alloc<float>(maxMC);
   float* y = P.alloc<float>(maxMC);
-  float* qkv = P.alloc<float>(3 * maxMC);
-  float* ao = P.alloc<float>(maxMC);
-  float* qb = P.alloc<float>(maxMC);
-  float* ffh = P.alloc<float>(4 * maxMC);
+  void* yn = P.alloc_op(maxMC);
+  void* qkv = P.alloc_op(3 * maxMC);
+  void* ao = P.alloc_op(maxMC);
+  void* qb = P.alloc_op(maxMC);
+  void* ffh = P.alloc_op(4 * maxMC);
+  void* samp_in = P.alloc_op(maxMC);        // operand copy of a block output that a down/up-sampling conv reads
   float* ua = P.alloc<float>(maxMC);
   float* ub = P.alloc<float>(maxMC);
   float* uc = P.alloc<float>(maxMC);
@@ -674,22 +698,28 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   P.ops = &h->cond_ops;
   {
     float *prompt = h->prompt, *seq = h->seq, *pq = h->pool_qkv_buf, *pooled = h->pooled, *aug = h->aug;
+    void *prompt_op = h->prompt_op, *seq_op = h->seq_op;
     // content half of conv_in (+ conv_in bias)
-    GemmArgs g = P.base(h->content_btc, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, c0);
+    GemmArgs g = P.base(h->content_op, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, nullptr, c0);
     g.taps = 3;
     P.gemm("cond.conv_in.content", g);
-    // all cross-attention k|v projections in one GEMM: prompt [B*Lp][cross] x [n_kv][cross]^T
-    g = P.base(prompt, cross, cross, Lp, Lp, h->kv_all, h->kv, h->kv_all.N);
+    // all cross-attention k|v projections in one GEMM: prompt [B*Lp][cross] x [n_kv][cross]^T -> operand tensor
+    const size_t np = (size_t)B * Lp * cross;
+    P.add("cond.prompt.cast", [=](hipStream_t s) { return launch_cast_op(prompt, np, prompt_op, prec, s); });
+    g = P.base(prompt_op, cross, cross, Lp, Lp, h->kv_all, nullptr, h->kv, h->kv_all.N);
     P.gemm("cond.cross_kv", g);
     // add_embedding = TextTimeEmbedding(prompt)
     const float *n1g = h->p_n1g, *n1b = h->p_n1b, *pos = h->p_pos, *projT = h->p_projT, *projb = h->p_projb, *n2g = h->p_n2g, *n2b = h->p_n2b;
     const int ph_ = c.pool_heads;
+    const size_t ns = (size_t)B * (Lp + 1) * cross;
     P.add("cond.pool.ln1", [=](hipStream_t s) { return launch_ln_apply(prompt, B * Lp, cross, 1e-5f, n1g, n1b, seq, Lp, 0, s); });
     P.add("cond.pool.cls", [=](hipStream_t s) { return launch_pool_cls(seq, B, Lp, cross, pos, s); });
-    g = P.base(seq, cross, cross, Lp + 1, Lp + 1, h->pool_qkv, pq, h->pool_qkv.N);
+    P.add("cond.pool.cast", [=](hipStream_t s) { return launch_cast_op(seq, ns, seq_op, prec, s); });
+    g = P.base(seq_op, cross, cross, Lp + 1, Lp + 1, h->pool_qkv, pq, nullptr, h->pool_qkv.N);
     P.gemm("cond.pool.qkv", g);
     const int ldq = h->pool_qkv.N;
     if (ldq != 3 * cross) return fail("pool qkv width %d must equal 3*cross=%d (cross must be a multiple of 128)", ldq, 3 * cross);
+    if ((ns & 3) || (np & 3)) return fail("internal: cast sizes must be multiples of 4");
     P.add("cond.pool.attn", [=](hipStream_t s) { return launch_pool_attn(pq, B, Lp + 1, cross, ph_, pooled, s); });
     P.add("cond.pool.proj", [=](hipStream_t s) { return launch_pool_proj(pooled, B, cross, projT, projb, E, n2g, n2b, 1e-5f, aug, s); });
     P.tap("aug", aug, B, E);
@@ -700,15 +730,16 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   {
     ns2vc_unet* hh = h;
     const float *w1t = h->t_w1t, *b1 = h->t_b1, *w2t = h->t_w2t, *b2 = h->t_b2, *aug = h->aug;
-    float *emb = h->emb, *emb_act = h->emb_act, *tdev = h->t_dev;
+    float *emb = h->emb, *tdev = h->t_dev;
+    void* emb_act = h->emb_act_op;
     const int tdim = c0;
     P.add("time_embed", [=](hipStream_t s) {
-      if (hh->use_step_table) return launch_time_embed(hh->coef_dev, 0, hh->step_dev, NS2VC_NCOEF, w1t, b1, w2t, b2, aug, emb, emb_act, B, tdim, E, s);
-      return launch_time_embed(tdev, 1, nullptr, 0, w1t, b1, w2t, b2, aug, emb, emb_act, B, tdim, E, s);
+      if (hh->use_step_table) return launch_time_embed(hh->coef_dev, 0, hh->step_dev, NS2VC_NCOEF, w1t, b1, w2t, b2, aug, emb, emb_act, prec, B, tdim, E, s);
+      return launch_time_embed(tdev, 1, nullptr, 0, w1t, b1, w2t, b2, aug, emb, emb_act, prec, B, tdim, E, s);
     });
     P.tap("emb", emb, B, E);
     // every resnet's time_emb_proj(SiLU(emb)) in one GEMM (M = B)
-    GemmArgs g = P.base(emb_act, E, E, 1, 1, h->temb_all, h->temb, h->temb_all.N);
+    GemmArgs g = P.base(emb_act, E, E, 1, 1, h->temb_all, h->temb, nullptr, h->temb_all.N);
     P.gemm("time_emb_proj.all", g);
   }
   // skip stack
@@ -717,7 +748,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   auto new_skip = [&](int l) { float* p = P.alloc<float>((size_t)B * Ts[l] * c.block_out_channels[l]); skips.push_back({p, c.block_out_channels[l], l}); return p; };
   {
     float* s0 = new_skip(0);
-    GemmArgs g = P.base(h->xe, CP, CP, T, T, h->conv_in_x, s0, c0);
+    GemmArgs g = P.base(h->xe_op, CP, CP, T, T, h->conv_in_x, s0, nullptr, c0);
     g.taps = 3; g.res = h->content_conv; g.ldres = c0;
     P.gemm("conv_in", g);
     P.tap("conv_in", s0, B * T, c0);
@@ -730,56 +761,58 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     if (b.kind == "down") {
       for (size_t j = 0; j < b.res.size(); ++j) {
         const bool has_attn = !b.attn.empty();
+        const bool last = (j + 1 == b.res.size());
         float* rout = has_attn ? ua : new_skip(l);
-        P.resnet(b.res[j], cur, curC, curC, nullptr, 0, 0, Tl, h1, scb, rout);
+        P.resnet(b.res[j], cur, curC, curC, nullptr, 0, 0, Tl, h1, hn, scb, rout, (!has_attn && last && b.sampler) ? samp_in : nullptr);
         P.tap(tag + ".res" + std::to_string(j), rout, B * Tl, b.channels);
         cur = rout; curC = b.channels;
         if (has_attn) {
           float* aout = new_skip(l);
-          P.transformer(b.attn[j], cur, Tl, y, qkv, ao, qb, ffh, aout);
+          P.transformer(b.attn[j], cur, Tl, y, yn, qkv, ao, qb, ffh, aout, (last && b.sampler) ? samp_in : nullptr);
           P.tap(tag + ".attn" + std::to_string(j), aout, B * Tl, b.channels);
           cur = aout;
         }
       }
       if (b.sampler == 1) {
         float* ds = new_skip(l + 1);
-        // note: skip channel count is this block's channels, at the next level's length
-        skips.back().C = b.channels;
-        GemmArgs g = P.base(cur, curC, curC, Tl, Ts[l + 1], b.samp, ds, b.channels);
+        skips.back().C = b.channels;     // this block's channels at the next level's length
+        GemmArgs g = P.base(samp_in, curC, curC, Tl, Ts[l + 1], b.samp, ds, nullptr, b.channels);
         g.taps = 3; g.tmode = TMODE_DOWN2;
         P.gemm(tag + ".downsample", g);
         P.tap(tag + ".ds", ds, B * Ts[l + 1], b.channels);
         cur = ds;
       }
     } else if (b.kind == "mid") {
-      P.resnet(b.res[0], cur, curC, curC, nullptr, 0, 0, Tl, h1, scb, ua);
+      P.resnet(b.res[0], cur, curC, curC, nullptr, 0, 0, Tl, h1, hn, scb, ua, nullptr);
       P.tap("mid.res0", ua, B * Tl, b.channels);
-      P.transformer(b.attn[0], ua, Tl, y, qkv, ao, qb, ffh, ub);
+      P.transformer(b.attn[0], ua, Tl, y, yn, qkv, ao, qb, ffh, ub, nullptr);
       P.tap("mid.attn0", ub, B * Tl, b.channels);
-      P.resnet(b.res[1], ub, b.channels, b.channels, nullptr, 0, 0, Tl, h1, scb, uc);
+      P.resnet(b.res[1], ub, b.channels, b.channels, nullptr, 0, 0, Tl, h1, hn, scb, uc, nullptr);
       P.tap("mid.res1", uc, B * Tl, b.channels);
       cur = uc; curC = b.channels;
     } else {
       for (size_t j = 0; j < b.res.size(); ++j) {
         const Skip sk = skips.back();
         skips.pop_back();
+        const bool last = (j + 1 == b.res.size());
+        const bool has_attn = !b.attn.empty();
         if (sk.l != l) return fail("internal: skip level mismatch at %s", b.res[j].prefix.c_str());
         if (curC + sk.C != b.res[j].cin) return fail("internal: concat width %d+%d != %d at %s", curC, sk.C, b.res[j].cin, b.res[j].prefix.c_str());
         float* rout = (cur == ua) ? ub : ua;
         if (rout == cur) rout = uc;
-        P.resnet(b.res[j], cur, curC, curC, sk.p, sk.C, sk.C, Tl, h1, scb, rout);
+        P.resnet(b.res[j], cur, curC, curC, sk.p, sk.C, sk.C, Tl, h1, hn, scb, rout, (!has_attn && last && b.sampler) ? samp_in : nullptr);
         P.tap(tag + ".res" + std::to_string(j), rout, B * Tl, b.channels);
         cur = rout; curC = b.channels;
-        if (!b.attn.empty()) {
+        if (has_attn) {
           float* aout = (cur == ua) ? ub : ua;
-          P.transformer(b.attn[j], cur, Tl, y, qkv, ao, qb, ffh, aout);
+          P.transformer(b.attn[j], cur, Tl, y, yn, qkv, ao, qb, ffh, aout, (last && b.sampler) ? samp_in : nullptr);
           P.tap(tag + ".attn" + std::to_string(j), aout, B * Tl, b.channels);
           cur = aout;
         }
       }
       if (b.sampler == 2) {
         float* us = (cur == uc) ? ua : uc;
-        GemmArgs g = P.base(cur, curC, curC, Tl, Ts[l - 1], b.samp, us, b.channels);
+        GemmArgs g = P.base(samp_in, curC, curC, Tl, Ts[l - 1], b.samp, us, nullptr, b.channels);
         g.taps = 3; g.tmode = TMODE_UP2;
         P.gemm(tag + ".upsample", g);
         P.tap(tag + ".us", us, B * Ts[l - 1], b.channels);
@@ -789,9 +822,9 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   }
   if (!skips.empty()) return fail("internal: %zu skips left over", skips.size());
   {
-    P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0);
-    GemmArgs g = P.base(cur, curC, curC, T, T, h->conv_out, h->x0, CP);
-    g.taps = 3; g.pscale = P.ps; g.pshift = P.ph; g.silu = 1;
+    P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr);
+    GemmArgs g = P.base(P.xn, curC, curC, T, T, h->conv_out, h->x0, nullptr, CP);
+    g.taps = 3;
     if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
     P.gemm("conv_out", g);
     P.tap("out", h->x0, B * T, CP);
@@ -960,7 +993,7 @@ int ns2vc_unet_set_condition(ns2vc_unet* h, const float* content_bct, const floa
     if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
     if (build_plan(h, false)) return 1;
   }
-  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, h->content_btc, c.content_channels, c.content_channels, s));
+  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, nullptr, h->content_op, h->prec, c.content_channels, c.content_channels, s));
   HIPCHK(hipMemcpyAsync(h->prompt, prompt_blc, (size_t)h->B * h->Lp * c.cross_attention_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (want_mask) {
     HIPCHK(hipMemcpyAsync(h->mask_dev, mask_bl, (size_t)h->B * h->Lp, hipMemcpyDeviceToDevice, s));
@@ -975,7 +1008,7 @@ int ns2vc_unet_forward(ns2vc_unet* h, const float* x_bct, const float* t_b, floa
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
   h->use_step_table = false;
-  HIPCHK(launch_nct_to_btc(x_bct, c.latent_channels, h->T, h->B, h->xe, h->CP, h->CP, s));
+  HIPCHK(launch_nct_to_btc(x_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
   HIPCHK(hipMemcpyAsync(h->t_dev, t_b, (size_t)h->B * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (run_ops(h->fwd_ops, s)) return 1;
   HIPCHK(launch_btc_to_nct(h->x0, h->CP, c.latent_channels, h->T, h->B, out_bct, s));
@@ -996,7 +1029,7 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
 static int run_step(ns2vc_unet* h, hipStream_t s) {
   if (run_ops(h->fwd_ops, s)) return 1;
   const size_t n = (size_t)h->B * h->T * h->CP;
-  HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xbar, h->d1, h->mprev, n, s));
+  HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xe_op, h->prec, h->xbar, h->d1, h->mprev, n, s));
   HIPCHK(launch_step_advance(h->step_dev, s));
   return 0;
 }
@@ -1021,7 +1054,7 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) { h->step_graph = nullptr; return fail("hipGraphInstantiate: %s", hipGetErrorString(e)); }
   }
-  HIPCHK(launch_nct_to_btc(x_inout_bct, c.latent_channels, h->T, h->B, h->xe, h->CP, h->CP, s));
+  HIPCHK(launch_nct_to_btc(x_inout_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
   HIPCHK(hipMemcpyAsync(h->xbar, h->xe, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemsetAsync(h->d1, 0, n * sizeof(float), s));
   HIPCHK(hipMemsetAsync(h->mprev, 0, n * sizeof(float), s));
@@ -1157,13 +1190,46 @@ int ns2vc_k_groupnorm_coef(const float* a0, int lda0, int c0, const float* a1, i
   if (e2 != hipSuccess) return fail("groupnorm sync: %s", hipGetErrorString(e2));
   return 0;
 }
-int ns2vc_k_layernorm_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, void* stream) {
-  hipError_t e = launch_ln_stats(x, ldx, M, C, eps, rstats, (hipStream_t)stream);
-  if (e != hipSuccess) return fail("ln_stats launch: %s", hipGetErrorString(e));
+int ns2vc_k_groupnorm_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, const float* pscale,
+                            const float* pshift, int silu, void* out_op, void* raw_op, int precision, void* stream) {
+  hipError_t e = launch_gn_apply(a0, lda0, c0, a1, lda1, c1, B, T, pscale, pshift, silu, out_op, raw_op, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("gn_apply launch: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream) {
+  hipError_t e = launch_ln_apply_op(x, ldx, M, C, eps, out_op, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("ln_apply launch: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev) {
+  if (!host || !out_dev) return fail("null argument");
+  void* d = nullptr;
+  if (precision == NS2VC_PREC_BF16) {
+    std::vector<uint16_t> q(n);
+    for (size_t i = 0; i < n; ++i) q[i] = f32_to_bf16_bits(host[i]);
+    HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * 2));
+    HIPCHK(hipMemcpy(d, q.data(), n * 2, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * 4));
+    HIPCHK(hipMemcpy(d, host, n * 4, hipMemcpyHostToDevice));
+  }
+  *out_dev = d;
+  return 0;
+}
+int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host) {
+  if (!dev || !host) return fail("null argument");
+  HIPCHK(hipDeviceSynchronize());
+  if (precision == NS2VC_PREC_BF16) {
+    std::vector<uint16_t> q(n);
+    HIPCHK(hipMemcpy(q.data(), dev, n * 2, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) host[i] = bf16_bits_to_f32(q[i]);
+  } else {
+    HIPCHK(hipMemcpy(host, dev, n * 4, hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream) {
-  hipError_t e = launch_nct_to_btc(src, C, T, B, dst, ldd, cpad, (hipStream_t)stream);
+  hipError_t e = launch_nct_to_btc(src, C, T, B, dst, nullptr, PREC_F32, ldd, cpad, (hipStream_t)stream);
   if (e != hipSuccess) return fail("nct_to_btc launch: %s", hipGetErrorString(e));
   return 0;
 }

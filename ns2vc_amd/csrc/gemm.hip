@@ -3,110 +3,82 @@
 //
 // Replaces the reference's F.conv1d / F.linear call sites
 // (unet1d/lora.py:98-104,119-123; unet1d/resnet.py:591-641, 138-173, 214-223;
-//  unet1d/attention.py:206-301; unet1d/attention_processor.py:1013-1045) and
-// fuses what surrounds them:
-//   prologue  GroupNorm-apply(+time scale/shift)(+SiLU)  [PRO_BC, per (batch,channel) affine]
-//             LayerNorm-apply (gamma/beta folded into W)  [PRO_ROW, per-row mean/rstd]
-//             skip-connection concat as a two-pointer K loop (no torch.cat copy)
-//             nearest upsample (src = dst>>1) and stride-2 as row-index math
-//   epilogue  bias, GEGLU (value * gelu_erf(gate)), residual add, fp32/bf16 store
+//  unet1d/attention.py:206-301; unet1d/attention_processor.py:1013-1045).
 //
-// Layout: activations channels-last [B][T][C]; weights packed [N][K] (K contiguous),
-// K index = tap*(c0+c1) + c.  One LDS tile row = 128 B of K (32 f32 / 64 bf16) + 16 B
-// pad (stride 36 dwords = 4*odd -> conflict-free ds_read_b128 for the 32x32 MFMA
-// fragment reads).  256 threads = 4 waves in a 2x2 grid, each wave owns a
-// (BM/2)x(BN/2) output tile built from 32x32 MFMA tiles:
-//   bf16: v_mfma_f32_32x32x16_bf16 (one per 32 B k-slab)
-//   f32 : v_mfma_f32_32x32x2_f32   (four per 32 B k-slab; exact fp32 "parity mode")
-// Global->register prefetch of tile k+1 overlaps the MFMAs of tile k; the prologue
-// transform and the LDS write happen after the MFMAs (one barrier per K tile).
+//   out[m][n] = epi( sum_k A[m,k] * W[n][k] ),  m = b*Tout + t,  k = tap*(c0+c1) + c
+//
+// A is an "operand tensor": channels-last [B][Tin][C] already in the MFMA operand
+// type (bf16, or fp32 in parity mode) and already normalised/activated by the
+// producing kernel, so BOTH operands stream HBM/L2 -> LDS with global_load_lds
+// (16 B per lane, no VGPR round trip, no VALU in the main loop):
+//   * conv taps, stride 2 and nearest-upsample are per-lane SOURCE row indices
+//     (zero padding = a lane pointed at a zero page); the skip-connection concat
+//     is a two-pointer K loop (no torch.cat copy);
+//   * the LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is
+//     applied to the source address: 16-B chunk c of tile row r is stored at chunk
+//     position c ^ ((r>>1)&7) and read back with the same XOR -> conflict-free
+//     ds_read_b128 for the 32x32 MFMA fragment reads;
+//   * STAGES-deep LDS ring, counted s_waitcnt vmcnt(N) (never 0 in steady state),
+//     one raw s_barrier per K tile; the DMA is issued through inline asm so the
+//     compiler does not drain it in front of every ds_read.
+// 256 threads = 2x2 waves, each wave (BM/2)x(BN/2) from 32x32 MFMA tiles:
+//   bf16: v_mfma_f32_32x32x16_bf16 (one per 32-B k-slab)
+//   f32 : v_mfma_f32_32x32x2_f32   (four per 32-B k-slab; exact fp32 parity mode)
+// Epilogue: bias, GEGLU (value * gelu_erf(gate)), fp32 residual add, fp32 store
+// (residual stream) and/or operand-typed store (feeds the next GEMM / attention).
 #include "common.h"
 
 namespace ns2vc {
 
+__device__ uint4 g_zero_page[8];     // 128 B of zeros: source of padded / out-of-range rows
+
 template <typename T> struct MmaT;
 template <> struct MmaT<float> {
   static constexpr int EPC = 4;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
   }
-  __device__ static __forceinline__ uint4 pack(const float* v) {
-    return make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
-  }
 };
 template <> struct MmaT<bf16_t> {
   static constexpr int EPC = 8;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const uint4& a, const uint4& b) {
-    union U { uint4 u; bf16x8_t v; };
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    union U { u32x4_t u; bf16x8_t v; };
     U ua, ub;
     ua.u = a; ub.u = b;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
   }
-  __device__ static __forceinline__ uint4 pack(const float* v) {
-    uint4 r;
-    r.x = (uint32_t)f32_to_bf16_bits(v[0]) | ((uint32_t)f32_to_bf16_bits(v[1]) << 16);
-    r.y = (uint32_t)f32_to_bf16_bits(v[2]) | ((uint32_t)f32_to_bf16_bits(v[3]) << 16);
-    r.z = (uint32_t)f32_to_bf16_bits(v[4]) | ((uint32_t)f32_to_bf16_bits(v[5]) << 16);
-    r.w = (uint32_t)f32_to_bf16_bits(v[6]) | ((uint32_t)f32_to_bf16_bits(v[7]) << 16);
-    return r;
-  }
 };
 
-// raw (un-transformed) register image of one A chunk of EPC elements
-template <typename TA, int EPC> struct RawChunk;
-template <> struct RawChunk<float, 4> {
-  float4 d;
-  __device__ __forceinline__ void load(const float* p) { d = *reinterpret_cast<const float4*>(p); }
-  __device__ __forceinline__ void zero() { d = make_float4(0.f, 0.f, 0.f, 0.f); }
-  __device__ __forceinline__ void get(float* v) const { v[0] = d.x; v[1] = d.y; v[2] = d.z; v[3] = d.w; }
-};
-template <> struct RawChunk<float, 8> {
-  float4 d0, d1;
-  __device__ __forceinline__ void load(const float* p) {
-    d0 = *reinterpret_cast<const float4*>(p);
-    d1 = *reinterpret_cast<const float4*>(p + 4);
-  }
-  __device__ __forceinline__ void zero() { d0 = make_float4(0.f, 0.f, 0.f, 0.f); d1 = d0; }
-  __device__ __forceinline__ void get(float* v) const {
-    v[0] = d0.x; v[1] = d0.y; v[2] = d0.z; v[3] = d0.w; v[4] = d1.x; v[5] = d1.y; v[6] = d1.z; v[7] = d1.w;
-  }
-};
-template <> struct RawChunk<bf16_t, 8> {
-  uint4 d;
-  __device__ __forceinline__ void load(const bf16_t* p) { d = *reinterpret_cast<const uint4*>(p); }
-  __device__ __forceinline__ void zero() { d = make_uint4(0, 0, 0, 0); }
-  __device__ __forceinline__ void get(float* v) const {
-    v[0] = __uint_as_float(d.x << 16); v[1] = __uint_as_float(d.x & 0xffff0000u);
-    v[2] = __uint_as_float(d.y << 16); v[3] = __uint_as_float(d.y & 0xffff0000u);
-    v[4] = __uint_as_float(d.z << 16); v[5] = __uint_as_float(d.z & 0xffff0000u);
-    v[6] = __uint_as_float(d.w << 16); v[7] = __uint_as_float(d.w & 0xffff0000u);
-  }
-};
+// direct HBM/L2 -> LDS DMA of 16 B per lane: LDS address = lds_dst (wave-uniform) + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
 
-template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
-template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
-template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { p->v = f32_to_bf16_bits(v); }
+constexpr int TROW = 128;   // bytes of K per tile row (64 bf16 / 32 f32)
 
-constexpr int ROWB = 144;   // LDS bytes per tile row: 128 B of K + 16 B pad
-
-template <typename TM, typename TA, typename TO, int BM, int BN, int PRO>
-__global__ __launch_bounds__(256) void cgemm_kernel(const GemmArgs g) {
+template <typename TM, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
-  constexpr int AP = BM / 32, BP = BN / 32;
-  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int LA = BM / 32, LB = BN / 32, LPT = LA + LB;     // 16-B DMA pieces per thread per tile
+  constexpr int STAGE = (BM + BN) * TROW;
+  static_assert(LPT * (STAGES - 1) < 60, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lds0 = (unsigned)(size_t)smem;
 
-  // ---- XCD-aware tile mapping: blocks that share an A row-panel (same tm, different tn)
-  // get consecutive logical ids on ONE XCD so the panel is fetched into one L2.
+  // ---- XCD-aware tile mapping (blocks sharing an activation row-panel sit on one XCD's L2)
   const int nb_n = g.N / BN;
   const int nb_m = (g.M + BM - 1) / BM;
   const int nwg = nb_n * nb_m;
@@ -120,96 +92,60 @@ __global__ __launch_bounds__(256) void cgemm_kernel(const GemmArgs g) {
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // ---- per-thread staging coordinates
-  const int srow = tid >> 3;       // 0..31 row inside a pass
-  const int sq = tid & 7;          // 16-B chunk inside the 128-B K row
+  // ---- per-thread DMA coordinates: piece i = tid + 256*j covers tile row i>>3, physical chunk i&7
+  const int prow = tid >> 3;                 // row inside a 32-row pass
+  const int pchunk = tid & 7;
   const int Ctot = g.c0 + g.c1;
-  int ab[AP], at[AP];
-  float rmu[AP], rrs[AP];
+  // Source row index per (piece, tap), or -1 when the tap falls into the zero padding / past M.
+  // Unified index math: u = t*smul + tap - toff; valid iff 0 <= u < ulim; row = min(u >> ushr, Tin-1).
+  const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
+  const int toff = g.taps >> 1;
+  const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
+  const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
+  int rt0[LA], rt1[LA], rt2[LA], acol[LA];
 #pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int m = m0 + p * 32 + srow;
-    if (m < g.M) {
-      const int b = m / g.Tout;
-      ab[p] = b;
-      at[p] = m - b * g.Tout;
-    } else {
-      ab[p] = 0;
-      at[p] = -0x40000000;   // every tap lands out of range -> zero row
-    }
-    if (PRO == PRO_ROW) {
-      if (m < g.M) {
-        const float2 st = *reinterpret_cast<const float2*>(g.rstats + 2 * (size_t)m);
-        rmu[p] = st.x; rrs[p] = st.y;
-      } else { rmu[p] = 0.f; rrs[p] = 0.f; }
-    }
+  for (int j = 0; j < LA; ++j) {
+    const int row = j * 32 + prow;
+    const int m = m0 + row;
+    acol[j] = (pchunk ^ ((row >> 1) & 7)) * EPC;      // logical chunk this lane fetches (source-side swizzle)
+    const bool mok = m < g.M;
+    const int b = mok ? m / g.Tout : 0;
+    const int t = m - b * g.Tout;
+    auto src_row = [&](int tp) __attribute__((always_inline)) {
+      const int u = t * smul + tp - toff;
+      const bool ok = mok && (tp < g.taps) && (u >= 0) && (u < ulim);
+      return ok ? b * g.Tin + min(u >> ushr, g.Tin - 1) : -1;
+    };
+    rt0[j] = src_row(0); rt1[j] = src_row(1); rt2[j] = src_row(2);
   }
+  const TM* wrow[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int row = j * 32 + prow;
+    wrow[j] = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + row) * g.K + (pchunk ^ ((row >> 1) & 7)) * EPC);
+  }
+  const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
 
-  RawChunk<TA, EPC> ra[AP];
-  u32x4_t rb[BP];
-  unsigned okmask = 0;
-  int cur_c = 0;          // concat-space channel of this thread's chunk for the tile held in ra[]
-
-  auto load_tile = [&](int kt) __attribute__((always_inline)) {
+  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
     const int k0 = kt * BKE;
     const int tap = k0 / Ctot;
     const int cc = k0 - tap * Ctot;
-    const TA* src; int ld, csrc;
-    if (cc < g.c0) { src = reinterpret_cast<const TA*>(g.a0); ld = g.lda0; csrc = cc + sq * EPC; }
-    else { src = reinterpret_cast<const TA*>(g.a1); ld = g.lda1; csrc = cc - g.c0 + sq * EPC; }
-    cur_c = cc + sq * EPC;
-    okmask = 0;
+    const bool first = cc < g.c0;
+    const unsigned long long src = reinterpret_cast<unsigned long long>(first ? g.a0 : g.a1);
+    const int ld = first ? g.lda0 : g.lda1;
+    const int csrc = first ? cc : cc - g.c0;
+    const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      int tt; bool ok;
-      if (g.tmode == TMODE_SAME) { tt = at[p] + tap - (g.taps >> 1); ok = (tt >= 0) && (tt < g.Tin); }
-      else if (g.tmode == TMODE_DOWN2) { tt = 2 * at[p] + tap - 1; ok = (tt >= 0) && (tt < g.Tin); }
-      else { const int u = at[p] + tap - 1; ok = (u >= 0) && (u < g.Tout); tt = min(u >> 1, g.Tin - 1); }
-      if (ok) {
-        ra[p].load(src + ((size_t)(ab[p] * g.Tin + tt) * ld + csrc));
-        okmask |= (1u << p);
-      } else {
-        ra[p].zero();
-      }
+    for (int j = 0; j < LA; ++j) {
+      const int r = tap == 0 ? rt0[j] : (tap == 1 ? rt1[j] : rt2[j]);
+      const unsigned eoff = (unsigned)max(r, 0) * (unsigned)ld + (unsigned)(csrc + acol[j]);
+      const unsigned long long pa = src + (unsigned long long)eoff * sizeof(TM);
+      const unsigned long long p = r >= 0 ? pa : zero;
+      glds16(reinterpret_cast<const void*>(p), sbase + j * 4096);
     }
-    const TM* wp = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + srow) * g.K + k0 + sq * EPC);
+    const unsigned bbase = sbase + BM * TROW;
 #pragma unroll
-    for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const u32x4_t*>(wp + (size_t)p * 32 * g.K);
-  };
-
-  auto store_tile = [&](int stage) __attribute__((always_inline)) {
-    char* As = smem + stage * STAGE;
-    char* Bs = As + BM * ROWB;
-#pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      float v[EPC];
-      ra[p].get(v);
-      if (PRO == PRO_BC) {
-        if (okmask & (1u << p)) {
-          const float* ps = g.pscale + (size_t)ab[p] * Ctot + cur_c;
-          const float* ph = g.pshift + (size_t)ab[p] * Ctot + cur_c;
-#pragma unroll
-          for (int e = 0; e < EPC; e += 4) {
-            const float4 s4 = *reinterpret_cast<const float4*>(ps + e);
-            const float4 h4 = *reinterpret_cast<const float4*>(ph + e);
-            v[e + 0] = v[e + 0] * s4.x + h4.x; v[e + 1] = v[e + 1] * s4.y + h4.y;
-            v[e + 2] = v[e + 2] * s4.z + h4.z; v[e + 3] = v[e + 3] * s4.w + h4.w;
-          }
-          if (g.silu) {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) v[e] = silu_f(v[e]);
-          }
-        }
-      } else if (PRO == PRO_ROW) {
-        if (okmask & (1u << p)) {
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) v[e] = (v[e] - rmu[p]) * rrs[p];
-        }
-      }
-      *reinterpret_cast<uint4*>(As + (p * 32 + srow) * ROWB + sq * 16) = MmaT<TM>::pack(v);
-    }
-#pragma unroll
-    for (int p = 0; p < BP; ++p) *reinterpret_cast<u32x4_t*>(Bs + (p * 32 + srow) * ROWB + sq * 16) = rb[p];
+    for (int j = 0; j < LB; ++j) glds16(wrow[j] + k0, bbase + j * 4096);
   };
 
   f32x16_t acc[MT][NT];
@@ -221,38 +157,54 @@ __global__ __launch_bounds__(256) void cgemm_kernel(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / BKE;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue_tile(s, s);
 
   const int l31 = lane & 31, hi = lane >> 5;
+  // fragment reads: row r = w*W? + i*32 + l31, logical chunk 2*ks+hi stored at chunk ^ ((r>>1)&7);
+  // (r>>1)&7 == (l31>>1)&7 because every fragment row block starts at a multiple of 32
+  const int sw = (l31 >> 1) & 7;
+  int stage = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const char* As = smem + (kt & 1) * STAGE;
-    const char* Bs = As + BM * ROWB;
-    const char* ap = As + (wm * WM + l31) * ROWB + hi * 16;
-    const char* bp = Bs + (wn * WN + l31) * ROWB + hi * 16;
+    // tile kt has landed when at most (tiles issued after it) * LPT pieces are still in flight
+    const int after = min(STAGES - 2, nk - 1 - kt);
+    if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
+    else if (after >= 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my ds_reads of the stage about to be refilled are done
+    __builtin_amdgcn_s_barrier();
+    if (kt + STAGES - 1 < nk) {
+      int st2 = stage + STAGES - 1;
+      if (st2 >= STAGES) st2 -= STAGES;
+      issue_tile(kt + STAGES - 1, st2);
+    }
+    const char* As = smem + stage * STAGE;
+    const char* Bs = As + BM * TROW;
+    const char* ap = As + (wm * WM + l31) * TROW;
+    const char* bp = Bs + (wn * WN + l31) * TROW;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      uint4 af[MT], bf[NT];
+      const int coff = ((2 * ks + hi) ^ sw) * 16;
+      u32x4_t af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(ap + i * 32 * ROWB + ks * 32);
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const uint4*>(bp + j * 32 * ROWB + ks * 32);
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
     }
-    if (kt + 1 < nk) store_tile((kt + 1) & 1);
-    __syncthreads();
+    if (++stage == STAGES) stage = 0;
   }
 
   // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  TO* out = reinterpret_cast<TO*>(g.out);
+  float* of = g.out_f32;
+  TM* oo = reinterpret_cast<TM*>(g.out_op);
   if (g.geglu) {
     if constexpr (NT == 2) {
-      const int ncol = n0 + wn * WN + l31;            // packed column of the value half
+      const int ncol = n0 + wn * WN + l31;            // packed column of the value half; gate = +32
       const float bv = g.bias ? g.bias[ncol] : 0.f;
       const float bg = g.bias ? g.bias[ncol + 32] : 0.f;
       const int ocol = ((n0 + wn * WN) >> 1) + l31;
@@ -264,7 +216,8 @@ __global__ __launch_bounds__(256) void cgemm_kernel(const GemmArgs g) {
           if (m < g.M) {
             float v = (acc[i][0][r] + bv) * gelu_erf_f(acc[i][1][r] + bg);
             if (g.res) v += g.res[(size_t)m * g.ldres + ocol];
-            store_out<TO>(out + (size_t)m * g.ldo + ocol, v);
+            if (of) of[(size_t)m * g.ldo_f32 + ocol] = v;
+            if (oo) store_op<TM>(oo + (size_t)m * g.ldo_op + ocol, v);
           }
         }
       }
@@ -282,7 +235,8 @@ __global__ __launch_bounds__(256) void cgemm_kernel(const GemmArgs g) {
           if (m < g.M) {
             float v = acc[i][j][r] + bv;
             if (g.res) v += g.res[(size_t)m * g.ldres + ncol];
-            store_out<TO>(out + (size_t)m * g.ldo + ncol, v);
+            if (of) of[(size_t)m * g.ldo_f32 + ncol] = v;
+            if (oo) store_op<TM>(oo + (size_t)m * g.ldo_op + ncol, v);
           }
         }
       }
@@ -293,77 +247,62 @@ __global__ __launch_bounds__(256) void cgemm_kernel(const GemmArgs g) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <typename TM, typename TA, typename TO, int BM, int BN>
+template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
-  const size_t lds = 2 * (size_t)(BM + BN) * ROWB;
-  const int pro = g.rstats ? PRO_ROW : (g.pscale ? PRO_BC : PRO_NONE);
-  switch (pro) {
-    case PRO_NONE: hipLaunchKernelGGL((cgemm_kernel<TM, TA, TO, BM, BN, PRO_NONE>), dim3(nb), dim3(256), lds, s, g); break;
-    case PRO_BC: hipLaunchKernelGGL((cgemm_kernel<TM, TA, TO, BM, BN, PRO_BC>), dim3(nb), dim3(256), lds, s, g); break;
-    default: hipLaunchKernelGGL((cgemm_kernel<TM, TA, TO, BM, BN, PRO_ROW>), dim3(nb), dim3(256), lds, s, g); break;
-  }
+  const size_t lds = (size_t)STAGES * (BM + BN) * TROW;
+  hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(256), lds, s, g);
   return hipGetLastError();
 }
 
 static int g_force_bm = 0, g_force_bn = 0;
 void set_forced_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
-template <typename TM, typename TA, typename TO>
+template <typename TM>
 static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
-  if (g_force_bm) {   // test / tuning hook (ns2vc_debug_set_gemm_tile)
-    if (g.N % g_force_bn) return hipErrorInvalidValue;
-    if (g.geglu && g_force_bn != 128) return hipErrorInvalidValue;
-    if (g_force_bm == 128 && g_force_bn == 128) return launch_cfg<TM, TA, TO, 128, 128>(g, s);
-    if (g_force_bm == 64 && g_force_bn == 128) return launch_cfg<TM, TA, TO, 64, 128>(g, s);
-    if (g_force_bm == 128 && g_force_bn == 64) return launch_cfg<TM, TA, TO, 128, 64>(g, s);
-    if (g_force_bm == 64 && g_force_bn == 64) return launch_cfg<TM, TA, TO, 64, 64>(g, s);
-    return hipErrorInvalidValue;
-  }
-  // tile choice: the largest tile that still gives the 256 CUs at least ~1.5 waves of blocks
   auto blocks = [&](int bm, int bn) { return (long)(g.N / bn) * ((g.M + bm - 1) / bm); };
+  int bm, bn;
   const bool n128 = (g.N % 128) == 0;
-  if (g.geglu) {
+  if (g_force_bm) {   // test / tuning hook (ns2vc_debug_set_gemm_tile)
+    bm = g_force_bm; bn = g_force_bn;
+    if (g.N % bn || (g.geglu && bn != 128)) return hipErrorInvalidValue;
+  } else if (g.geglu) {
     if (!n128) return hipErrorInvalidValue;
-    if (blocks(128, 128) >= 384) return launch_cfg<TM, TA, TO, 128, 128>(g, s);
-    return launch_cfg<TM, TA, TO, 64, 128>(g, s);
-  }
-  if (n128 && blocks(128, 128) >= 384) return launch_cfg<TM, TA, TO, 128, 128>(g, s);
-  if (n128 && blocks(64, 128) >= 384) return launch_cfg<TM, TA, TO, 64, 128>(g, s);
-  if (blocks(128, 64) >= 384 && g.M >= 4096) return launch_cfg<TM, TA, TO, 128, 64>(g, s);
-  return launch_cfg<TM, TA, TO, 64, 64>(g, s);
+    bn = 128; bm = blocks(128, 128) >= 256 ? 128 : 64;
+  } else if (n128 && blocks(128, 128) >= 256) { bm = 128; bn = 128; }
+  else if (n128 && blocks(64, 128) >= 256) { bm = 64; bn = 128; }
+  else if (blocks(128, 64) >= 256) { bm = 128; bn = 64; }
+  else { bm = 64; bn = 64; }
+  if (bm == 128 && bn == 128) return launch_cfg<TM, 128, 128, 3>(g, s);
+  if (bm == 64 && bn == 128) return launch_cfg<TM, 64, 128, 3>(g, s);
+  if (bm == 128 && bn == 64) return launch_cfg<TM, 128, 64, 3>(g, s);
+  if (bm == 64 && bn == 64) return launch_cfg<TM, 64, 64, 4>(g, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.N % 64 != 0 || g.M <= 0) return hipErrorInvalidValue;
   const int bke = prec == PREC_BF16 ? 64 : 32;
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.K != g.taps * (g.c0 + g.c1)) return hipErrorInvalidValue;
-  if (prec == PREC_BF16) return launch_typed<bf16_t, float, float>(g, s);
-  return launch_typed<float, float, float>(g, s);
+  if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
+  if (!g.out_f32 && !g.out_op) return hipErrorInvalidValue;
+  if (prec == PREC_BF16) return launch_typed<bf16_t>(g, s);
+  return launch_typed<float>(g, s);
 }
 
 template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-#define NS2VC_SET_ALL(TM, TA, TO, BM, BN)                                                                      \
+#define NS2VC_SET(TM, BM, BN, ST)                                                                              \
   do {                                                                                                          \
-    const size_t lds = 2 * (size_t)(BM + BN) * ROWB;                                                            \
-    hipError_t e;                                                                                               \
-    if ((e = set_lds(cgemm_kernel<TM, TA, TO, BM, BN, PRO_NONE>, lds)) != hipSuccess) return e;                 \
-    if ((e = set_lds(cgemm_kernel<TM, TA, TO, BM, BN, PRO_BC>, lds)) != hipSuccess) return e;                   \
-    if ((e = set_lds(cgemm_kernel<TM, TA, TO, BM, BN, PRO_ROW>, lds)) != hipSuccess) return e;                  \
+    hipError_t e = set_lds(gemm2_kernel<TM, BM, BN, ST>, (size_t)ST * (BM + BN) * TROW);                        \
+    if (e != hipSuccess) return e;                                                                              \
   } while (0)
 
 hipError_t init_gemm_attributes() {
-  NS2VC_SET_ALL(float, float, float, 128, 128);
-  NS2VC_SET_ALL(float, float, float, 64, 128);
-  NS2VC_SET_ALL(float, float, float, 128, 64);
-  NS2VC_SET_ALL(float, float, float, 64, 64);
-  NS2VC_SET_ALL(bf16_t, float, float, 128, 128);
-  NS2VC_SET_ALL(bf16_t, float, float, 64, 128);
-  NS2VC_SET_ALL(bf16_t, float, float, 128, 64);
-  NS2VC_SET_ALL(bf16_t, float, float, 64, 64);
+  NS2VC_SET(float, 128, 128, 3); NS2VC_SET(float, 64, 128, 3); NS2VC_SET(float, 128, 64, 3); NS2VC_SET(float, 64, 64, 4);
+  NS2VC_SET(bf16_t, 128, 128, 3); NS2VC_SET(bf16_t, 64, 128, 3); NS2VC_SET(bf16_t, 128, 64, 3); NS2VC_SET(bf16_t, 64, 64, 4);
   return hipSuccess;
 }
 

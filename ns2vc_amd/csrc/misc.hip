@@ -99,34 +99,73 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__
 }
 
 // ---------------------------------------------------------------------------
-// LayerNorm row statistics (mean, rstd), one wave per row (attention.py:83,102,118).
-// gamma/beta are folded into the consumer GEMM's weights at pack time.
+// GroupNorm apply: out = act(x*pscale[b,c] + pshift[b,c]) written as an operand tensor
+// [B*T][c0+c1] (the skip concat is materialised here, in the operand type, as a side effect);
+// optionally also the raw (un-normalised) concat for the resnet's 1x1 shortcut conv.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ x, int ldx, int M, int C, float eps,
-                                                       float* __restrict__ rstats) {
+template <typename TM>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ a0, int lda0, int c0, const float* __restrict__ a1,
+                                                       int lda1, int c1, int T, const float* __restrict__ pscale,
+                                                       const float* __restrict__ pshift, int silu, TM* __restrict__ out,
+                                                       TM* __restrict__ raw, int rows) {
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int C = c0 + c1, nq = C >> 2;
+  const int rl = max(1, 256 / nq);
+  const int quad = tid % nq, rlane = tid / nq;
+  if (rlane >= rl) return;
+  const int c = quad * 4;
+  const float* src; int ld, cs;
+  if (c < c0) { src = a0; ld = lda0; cs = c; } else { src = a1; ld = lda1; cs = c - c0; }
+  const float4 sc = *reinterpret_cast<const float4*>(pscale + (size_t)b * C + c);
+  const float4 sh = *reinterpret_cast<const float4*>(pshift + (size_t)b * C + c);
+  const int r0 = blockIdx.x * rows, r1 = min(T, r0 + rows);
+  for (int r = r0 + rlane; r < r1; r += rl) {
+    const size_t row = (size_t)b * T + r;
+    const float4 v = *reinterpret_cast<const float4*>(src + row * ld + cs);
+    float y0 = v.x * sc.x + sh.x, y1 = v.y * sc.y + sh.y, y2 = v.z * sc.z + sh.z, y3 = v.w * sc.w + sh.w;
+    if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+    store_op4<TM>(out + row * C + c, y0, y1, y2, y3);
+    if (raw) store_op4<TM>(raw + row * C + c, v.x, v.y, v.z, v.w);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm (attention.py:83,102,118) without the affine part (gamma/beta are folded into the
+// consumer GEMM's weights at pack time): one wave per fp32 row -> operand row.  C % 128 == 0.
+// ---------------------------------------------------------------------------
+template <typename TM>
+__global__ __launch_bounds__(256) void ln_apply_op_kernel(const float* __restrict__ x, int ldx, int M, int C, float eps,
+                                                          TM* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* p = x + (size_t)row * ldx;
-  float v[16];
+  float2 v[8];
   float s = 0.f;
-  const int n = C >> 6;                        // elements per lane (C multiple of 64, <= 1024)
+  const int n = C >> 7;                        // float2 pairs per lane (C multiple of 128, <= 1024)
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    v[i] = (i < n) ? p[lane + 64 * i] : 0.f;
-    s += v[i];
+  for (int i = 0; i < 8; ++i) {
+    v[i] = (i < n) ? *reinterpret_cast<const float2*>(p + 2 * (lane + 64 * i)) : make_float2(0.f, 0.f);
+    s += v[i].x + v[i].y;
   }
   const float mean = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float d = (i < n) ? v[i] - mean : 0.f;
-    q += d * d;
+  for (int i = 0; i < 8; ++i) {
+    if (i < n) { const float d0 = v[i].x - mean, d1 = v[i].y - mean; q += d0 * d0 + d1 * d1; }
   }
-  const float var = wave_sum(q) / (float)C;
-  if (lane == 0) {
-    rstats[2 * (size_t)row] = mean;
-    rstats[2 * (size_t)row + 1] = 1.0f / sqrtf(var + eps);
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+  TM* o = out + (size_t)row * C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < n) store_op2<TM>(o + 2 * (lane + 64 * i), (v[i].x - mean) * rstd, (v[i].y - mean) * rstd);
+}
+
+template <typename TM>
+__global__ __launch_bounds__(256) void cast_op_kernel(const float* __restrict__ x, size_t n4, TM* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    store_op4<TM>(out + 4 * i, v.x, v.y, v.z, v.w);
   }
 }
 
@@ -255,11 +294,12 @@ __global__ __launch_bounds__(256) void pool_proj_kernel(const float* __restrict_
 // Reference: embeddings.py:24-64 (flip_sin_to_cos=True, freq_shift=0), :157-201,
 // unet_1d_condition.py:841-848,918.  The timestep is fractional float32.
 // ---------------------------------------------------------------------------
+template <typename TM>
 __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict__ t_ptr, int t_stride, const int* __restrict__ step_ptr,
                                                          int coef_stride, const float* __restrict__ w1t, const float* __restrict__ b1,
                                                          const float* __restrict__ w2t, const float* __restrict__ b2,
                                                          const float* __restrict__ aug, float* __restrict__ emb,
-                                                         float* __restrict__ emb_act, int tdim, int edim) {
+                                                         TM* __restrict__ emb_act, int tdim, int edim) {
   extern __shared__ float s_te[];           // tdim sinusoid + edim hidden
   float* s_sin = s_te;
   float* s_h = s_te + tdim;
@@ -276,16 +316,18 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
   __syncthreads();
   for (int o = tid; o < edim; o += 256) {
     float y = b1[o];
+#pragma unroll 16
     for (int i = 0; i < tdim; ++i) y += w1t[(size_t)i * edim + o] * s_sin[i];
     s_h[o] = y / (1.0f + expf(-y));
   }
   __syncthreads();
   for (int o = tid; o < edim; o += 256) {
     float y = b2[o];
+#pragma unroll 16
     for (int i = 0; i < edim; ++i) y += w2t[(size_t)i * edim + o] * s_h[i];
     if (aug) y += aug[(size_t)b * edim + o];
     emb[(size_t)b * edim + o] = y;
-    emb_act[(size_t)b * edim + o] = y / (1.0f + expf(-y));
+    store_op<TM>(emb_act + (size_t)b * edim + o, y / (1.0f + expf(-y)));
   }
 }
 
@@ -293,8 +335,9 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
 // API-boundary layout changes: reference tensors are NCT (B,C,T); the engine is
 // channels-last (B,T,Cpad).  32x32 LDS tile transpose, both directions coalesced.
 // ---------------------------------------------------------------------------
+template <typename TM>
 __global__ __launch_bounds__(256) void nct_to_btc_kernel(const float* __restrict__ src, int C, int T, float* __restrict__ dst,
-                                                         int ldd, int cpad) {
+                                                         TM* __restrict__ dst_op, int ldd, int cpad) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -305,7 +348,10 @@ __global__ __launch_bounds__(256) void nct_to_btc_kernel(const float* __restrict
   __syncthreads();
   for (int i = ty; i < 32; i += 8) {
     const int t = t0 + i, c = c0 + tx;
-    if (t < T && c < cpad) dst[((size_t)b * T + t) * ldd + c] = tile[tx][i];
+    if (t < T && c < cpad) {
+      if (dst) dst[((size_t)b * T + t) * ldd + c] = tile[tx][i];
+      if (dst_op) store_op<TM>(dst_op + ((size_t)b * T + t) * ldd + c, tile[tx][i]);
+    }
   }
 }
 __global__ __launch_bounds__(256) void btc_to_nct_kernel(const float* __restrict__ src, int lds_, int C, int T, float* __restrict__ dst) {
@@ -335,8 +381,9 @@ __global__ void mask_bias_kernel(const uint8_t* __restrict__ mask, int n, float*
 // the device-resident coefficient table, so the same captured graph serves
 // every step.
 // ---------------------------------------------------------------------------
+template <typename TM>
 __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restrict__ coef, const int* __restrict__ step_ptr, int ncoef,
-                                                            const float* __restrict__ x0, float* __restrict__ xe,
+                                                            const float* __restrict__ x0, float* __restrict__ xe, TM* __restrict__ xe_op,
                                                             float* __restrict__ xbar, float* __restrict__ d1,
                                                             float* __restrict__ mprev, size_t n4) {
   const float* c = coef + (size_t)(*step_ptr) * ncoef;
@@ -360,6 +407,7 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
     NS2VC_UPD(x) NS2VC_UPD(y) NS2VC_UPD(z) NS2VC_UPD(w)
 #undef NS2VC_UPD
     reinterpret_cast<float4*>(xe)[i] = oxe;
+    store_op4<TM>(xe_op + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
     reinterpret_cast<float4*>(xbar)[i] = oxb;
     reinterpret_cast<float4*>(d1)[i] = od1;
     reinterpret_cast<float4*>(mprev)[i] = om;
@@ -385,9 +433,30 @@ hipError_t launch_gn_coef(const double* partial, int nchunk, int B, int T, int C
                      cout, pscale, pshift);
   return hipGetLastError();
 }
-hipError_t launch_ln_stats(const float* x, int ldx, int M, int C, float eps, float* rstats, hipStream_t s) {
-  if (C % 64 || C > 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, C, eps, rstats);
+hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, const float* pscale,
+                           const float* pshift, int silu, void* out_op, void* raw_op, int prec, hipStream_t s) {
+  const int C = c0 + c1;
+  if (C > 1024 || (C & 3) || (c0 & 3)) return hipErrorInvalidValue;
+  const int rows = 32;
+  dim3 grid((T + rows - 1) / rows, B);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, pscale, pshift, silu, (bf16_t*)out_op, (bf16_t*)raw_op, rows);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, pscale, pshift, silu, (float*)out_op, (float*)raw_op, rows);
+  return hipGetLastError();
+}
+hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s) {
+  if (C % 128 || C > 1024) return hipErrorInvalidValue;
+  if (prec == PREC_BF16) hipLaunchKernelGGL(ln_apply_op_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, C, eps, (bf16_t*)out_op);
+  else hipLaunchKernelGGL(ln_apply_op_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, C, eps, (float*)out_op);
+  return hipGetLastError();
+}
+hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s) {
+  if (n & 3) return hipErrorInvalidValue;
+  const size_t n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+  if (prec == PREC_BF16) hipLaunchKernelGGL(cast_op_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, n4, (bf16_t*)out_op);
+  else hipLaunchKernelGGL(cast_op_kernel<float>, dim3(blocks), dim3(256), 0, s, x, n4, (float*)out_op);
   return hipGetLastError();
 }
 hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float* gamma, const float* beta, float* out, int L,
@@ -411,14 +480,19 @@ hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, 
   return hipGetLastError();
 }
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride, const float* w1t,
-                             const float* b1, const float* w2t, const float* b2, const float* aug, float* emb, float* emb_act,
-                             int B, int tdim, int edim, hipStream_t s) {
-  hipLaunchKernelGGL(time_embed_kernel, dim3(B), dim3(256), (size_t)(tdim + edim) * sizeof(float), s, t_ptr, t_stride, step_ptr,
-                     coef_stride, w1t, b1, w2t, b2, aug, emb, emb_act, tdim, edim);
+                             const float* b1, const float* w2t, const float* b2, const float* aug, float* emb, void* emb_act_op,
+                             int prec, int B, int tdim, int edim, hipStream_t s) {
+  const size_t lds = (size_t)(tdim + edim) * sizeof(float);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(time_embed_kernel<bf16_t>, dim3(B), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (bf16_t*)emb_act_op, tdim, edim);
+  else
+    hipLaunchKernelGGL(time_embed_kernel<float>, dim3(B), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (float*)emb_act_op, tdim, edim);
   return hipGetLastError();
 }
-hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, hipStream_t s) {
-  hipLaunchKernelGGL(nct_to_btc_kernel, dim3((T + 31) / 32, (cpad + 31) / 32, B), dim3(256), 0, s, src, C, T, dst, ldd, cpad);
+hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s) {
+  dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
+  if (prec == PREC_BF16) hipLaunchKernelGGL(nct_to_btc_kernel<bf16_t>, grid, dim3(256), 0, s, src, C, T, dst_f32, (bf16_t*)dst_op, ldd, cpad);
+  else hipLaunchKernelGGL(nct_to_btc_kernel<float>, grid, dim3(256), 0, s, src, C, T, dst_f32, (float*)dst_op, ldd, cpad);
   return hipGetLastError();
 }
 hipError_t launch_btc_to_nct(const float* src, int lds_, int C, int T, int B, float* dst, hipStream_t s) {
@@ -429,12 +503,15 @@ hipError_t launch_mask_bias(const uint8_t* mask, int n, float* bias, hipStream_t
   hipLaunchKernelGGL(mask_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, n, bias);
   return hipGetLastError();
 }
-hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0, float* xe, float* xbar,
-                                float* d1, float* mprev, size_t n, hipStream_t s) {
+hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0, float* xe, void* xe_op, int prec,
+                                float* xbar, float* d1, float* mprev, size_t n, hipStream_t s) {
   if (n & 3) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(solver_update_kernel, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, xbar, d1, mprev, n4);
+  if (prec == PREC_BF16)
+    hipLaunchKernelGGL(solver_update_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, (bf16_t*)xe_op, xbar, d1, mprev, n4);
+  else
+    hipLaunchKernelGGL(solver_update_kernel<float>, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, (float*)xe_op, xbar, d1, mprev, n4);
   return hipGetLastError();
 }
 hipError_t launch_step_advance(int* step_ptr, hipStream_t s) {

@@ -20,7 +20,7 @@ from util import bf16_round, gather_rows, gelu_erf, rel_l2, silu
 
 pytestmark = pytest.mark.gpu
 
-TOL = {0: 2e-5, 1: 6e-3}
+TOL = {0: 2e-5, 1: 2e-5}      # operands are pre-rounded to the operand type, accumulation is fp32 in both modes
 
 
 def _lib():
@@ -42,40 +42,51 @@ def _pack(W, prec):
     return p
 
 
-def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, pro, silu_on, bias_on, res_on, geglu, tile=(0, 0)):
+class OpBuf:
+    """device buffer in the engine's operand type (bf16 for prec 1, fp32 for prec 0)"""
+
+    def __init__(self, a, prec):
+        from ns2vc_amd._lib import check
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        self.prec, self.n, self.shape = prec, a.size, a.shape
+        p = C.c_void_p()
+        check(_lib().ns2vc_to_operand(a.ctypes.data, a.size, prec, C.byref(p)), "to_operand")
+        self.ptr = p.value
+        self.esz = 2 if prec == 1 else 4
+
+    def read(self, shape=None):
+        from ns2vc_amd._lib import check
+        out = np.empty(self.n, dtype=np.float32)
+        check(_lib().ns2vc_from_operand(self.ptr, self.n, self.prec, out.ctypes.data), "from_operand")
+        return out.reshape(shape or self.shape)
+
+    def __del__(self):
+        try:
+            _lib().ns2vc_dev_free(self.ptr)
+        except Exception:
+            pass
+
+
+def rnd(a, prec):
+    return bf16_round(np.asarray(a, dtype=np.float32)) if prec == 1 else np.asarray(a, dtype=np.float32)
+
+
+def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, geglu, dual, tile=(0, 0)):
     from ns2vc_amd._lib import GemmArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
     Ct = c0 + c1
     K = taps * Ct
     M = B * Tout
-    a0 = rng.standard_normal((B, Tin, c0)).astype(np.float32)
-    a1 = rng.standard_normal((B, Tin, c1)).astype(np.float32) if c1 else None
-    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    a0 = rnd(rng.standard_normal((B, Tin, c0)), prec)
+    a1 = rnd(rng.standard_normal((B, Tin, c1)), prec) if c1 else None
+    W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
     bias = rng.standard_normal(N).astype(np.float32) if bias_on else None
     Nout = N // 2 if geglu else N
     res = rng.standard_normal((M, Nout)).astype(np.float32) if res_on else None
-    A = a0 if a1 is None else np.concatenate([a0, a1], axis=-1)
-    A = A.astype(np.float64)
-    ps = ph = rs = None
-    if pro == 1:
-        ps = (1.0 + 0.3 * rng.standard_normal((B, Ct))).astype(np.float32)
-        ph = (0.3 * rng.standard_normal((B, Ct))).astype(np.float32)
-        A = A * ps[:, None, :] + ph[:, None, :]
-        if silu_on:
-            A = silu(A)
-    elif pro == 2:
-        assert Tin == Tout and taps == 1
-        mu = A.mean(-1)
-        rstd = 1.0 / np.sqrt(A.var(-1) + 1e-5)
-        rs = np.stack([mu, rstd], axis=-1).reshape(M, 2).astype(np.float32)
-        A = (A - rs[:, 0].reshape(B, Tin, 1).astype(np.float64)) * rs[:, 1].reshape(B, Tin, 1).astype(np.float64)
+    A = (a0 if a1 is None else np.concatenate([a0, a1], axis=-1)).astype(np.float64)
     G = gather_rows(A, B, Tin, Tout, taps, tmode).reshape(M, K)
-    Wd = W.astype(np.float64)
-    if prec == 1:
-        G = bf16_round(G.astype(np.float32)).astype(np.float64)
-        Wd = bf16_round(W).astype(np.float64)
-    ref = G @ Wd.T
+    ref = G @ W.astype(np.float64).T
     if bias is not None:
         ref = ref + bias
     if geglu:
@@ -84,32 +95,28 @@ def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, pro, silu_on, bias
     if res is not None:
         ref = ref + res
 
-    d_a0, d_a1 = _dev(a0), (_dev(a1) if a1 is not None else None)
+    d_a0, d_a1 = OpBuf(a0, prec), (OpBuf(a1, prec) if a1 is not None else None)
     d_w = _pack(W, prec)
     d_bias = _dev(bias) if bias is not None else None
     d_res = _dev(res) if res is not None else None
-    d_ps, d_ph = (_dev(ps), _dev(ph)) if ps is not None else (None, None)
-    d_rs = _dev(rs) if rs is not None else None
     d_out = DevBuf(M * Nout * 4)
     d_out.upload(np.full((M, Nout), np.nan, dtype=np.float32))
+    d_oop = OpBuf(np.full((M, Nout), np.nan, dtype=np.float32), prec) if dual else None
     g = GemmArgs()
     g.a0 = d_a0.ptr; g.lda0 = c0; g.c0 = c0
     if d_a1 is not None:
         g.a1 = d_a1.ptr; g.lda1 = c1; g.c1 = c1
     g.B, g.Tin, g.Tout, g.M = B, Tin, Tout, M
     g.taps, g.tmode = taps, tmode
-    if d_ps is not None:
-        g.pscale, g.pshift = d_ps.ptr, d_ph.ptr
-    if d_rs is not None:
-        g.rstats = d_rs.ptr
-    g.silu = int(silu_on)
     g.w = d_w.value; g.K = K; g.N = N
     if d_bias is not None:
         g.bias = d_bias.ptr
     if d_res is not None:
         g.res = d_res.ptr; g.ldres = Nout
     g.geglu = int(geglu)
-    g.out = d_out.ptr; g.ldo = Nout
+    g.out_f32 = d_out.ptr; g.ldo_f32 = Nout
+    if d_oop is not None:
+        g.out_op = d_oop.ptr; g.ldo_op = Nout
     check(lib.ns2vc_debug_set_gemm_tile(*tile), "set tile")
     try:
         check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
@@ -117,25 +124,27 @@ def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, pro, silu_on, bias
     finally:
         lib.ns2vc_debug_set_gemm_tile(0, 0)
     out = d_out.to_numpy((M, Nout))
+    out_op = d_oop.read() if d_oop is not None else None
     lib.ns2vc_dev_free(d_w)
-    return out, ref
+    return out, ref, out_op
 
 
 GEMM_CASES = [
-    # name, B, Tin, Tout, c0, c1, N, taps, tmode, pro, silu, bias, res, geglu
-    ("linear_plain", 2, 75, 75, 128, 0, 128, 1, 0, 0, 0, 1, 0, 0),
-    ("linear_res_tail", 3, 41, 41, 256, 0, 192, 1, 0, 0, 0, 1, 1, 0),
-    ("conv3_gn_silu", 2, 37, 37, 128, 0, 128, 3, 0, 1, 1, 1, 0, 0),
-    ("conv3_concat_gn_silu_res", 2, 37, 37, 128, 64, 128, 3, 0, 1, 1, 1, 1, 0),
-    ("conv1_concat_shortcut", 2, 37, 37, 192, 128, 256, 1, 0, 0, 0, 1, 0, 0),
-    ("down2_odd", 2, 37, 19, 128, 0, 128, 3, 1, 0, 0, 1, 0, 0),
-    ("down2_even", 2, 38, 19, 128, 0, 128, 3, 1, 0, 0, 1, 0, 0),
-    ("up2_odd", 2, 19, 37, 128, 0, 128, 3, 2, 0, 0, 1, 0, 0),
-    ("up2_even", 2, 19, 38, 128, 0, 128, 3, 2, 0, 0, 1, 0, 0),
-    ("ln_row_qkv", 2, 50, 50, 128, 0, 384, 1, 0, 2, 0, 1, 0, 0),
-    ("ln_row_geglu", 2, 50, 50, 128, 0, 1024, 1, 0, 2, 0, 1, 0, 1),
-    ("gn_noact_proj_in", 2, 33, 33, 256, 0, 256, 1, 0, 1, 0, 1, 0, 0),
-    ("temb_m_small", 3, 1, 1, 512, 0, 640, 1, 0, 0, 0, 1, 0, 0),
+    # name, B, Tin, Tout, c0, c1, N, taps, tmode, bias, res, geglu, dual
+    ("linear_plain", 2, 75, 75, 128, 0, 128, 1, 0, 1, 0, 0, 0),
+    ("linear_res_tail_dual", 3, 41, 41, 256, 0, 192, 1, 0, 1, 1, 0, 1),
+    ("linear_k_long", 2, 33, 33, 1024, 0, 256, 1, 0, 1, 1, 0, 0),
+    ("linear_k_one_tile", 2, 50, 50, 64, 0, 128, 1, 0, 0, 0, 0, 0),
+    ("conv3", 2, 37, 37, 128, 0, 128, 3, 0, 1, 0, 0, 0),
+    ("conv3_concat_res", 2, 37, 37, 128, 64, 128, 3, 0, 1, 1, 0, 1),
+    ("conv1_concat_shortcut", 2, 37, 37, 192, 128, 256, 1, 0, 1, 0, 0, 0),
+    ("down2_odd", 2, 37, 19, 128, 0, 128, 3, 1, 1, 0, 0, 0),
+    ("down2_even", 2, 38, 19, 128, 0, 128, 3, 1, 1, 0, 0, 0),
+    ("up2_odd", 2, 19, 37, 128, 0, 128, 3, 2, 1, 0, 0, 0),
+    ("up2_even", 2, 19, 38, 128, 0, 128, 3, 2, 1, 0, 0, 0),
+    ("qkv_op_only_like", 2, 50, 50, 128, 0, 384, 1, 0, 1, 0, 0, 1),
+    ("geglu", 2, 50, 50, 128, 0, 1024, 1, 0, 1, 0, 1, 1),
+    ("temb_m_small", 3, 1, 1, 512, 0, 640, 1, 0, 1, 0, 0, 0),
 ]
 
 
@@ -144,26 +153,34 @@ GEMM_CASES = [
 def test_gemm_cases(case, prec, diag):
     name, *args = case
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out, ref = run_gemm(rng, prec, *args)
+    out, ref, out_op = run_gemm(rng, prec, *args)
     e = rel_l2(out, ref)
     diag(f"gemm {name} prec={prec} rel_l2={e:.3e} nan={int(np.isnan(out).sum())}")
     if not (e < TOL[prec]):
         bad = np.argwhere(~(np.abs(out - ref) <= 1e-2 + 1e-2 * np.abs(ref)))
         diag(f"  FAIL {name}: {len(bad)} bad of {out.size}; first {bad[:6].tolist()} rows_bad={sorted(set(bad[:, 0].tolist()))[:12]} cols_bad={sorted(set(bad[:, 1].tolist()))[:12]}")
     assert e < TOL[prec], (name, e)
+    if out_op is not None:      # operand-typed copy == the fp32 result rounded to the operand type
+        assert np.array_equal(out_op, rnd(out, prec)), name
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("tile", [(128, 128), (64, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
 def test_gemm_every_tile(tile, prec, diag):
     rng = np.random.default_rng(tile[0] * 1000 + tile[1])
-    # M = 3*167 = 501 rows (tail in every tile size), concat + conv3 + GN/SiLU + bias + residual
-    out, ref = run_gemm(rng, prec, 3, 167, 167, 128, 64, 256, 3, 0, 1, 1, 1, 1, 0, tile=tile)
+    # M = 3*167 = 501 rows (tail in every tile size), concat + conv3 + bias + residual, K = 3*192 (9 / 18 tiles)
+    out, ref, _ = run_gemm(rng, prec, 3, 167, 167, 128, 64, 256, 3, 0, 1, 1, 0, 0, tile=tile)
     e = rel_l2(out, ref)
     diag(f"gemm tile={tile} prec={prec} rel_l2={e:.3e}")
     assert e < TOL[prec]
+    # K of exactly 1, 2 and 3 tiles exercises the pipeline prologue / tail waits
+    for kk in (1, 2, 3):
+        out, ref, _ = run_gemm(rng, prec, 2, 90, 90, (64 if prec else 32) * kk, 0, 128, 1, 0, 1, 0, 0, 0, tile=tile)
+        e = rel_l2(out, ref)
+        diag(f"gemm tile={tile} prec={prec} ktiles={kk} rel_l2={e:.3e}")
+        assert e < TOL[prec]
     if tile[1] == 128:
-        out, ref = run_gemm(rng, prec, 2, 90, 90, 256, 0, 512, 1, 0, 2, 0, 1, 0, 1, tile=tile)
+        out, ref, _ = run_gemm(rng, prec, 2, 90, 90, 256, 0, 512, 1, 0, 1, 0, 1, 0, tile=tile)
         e = rel_l2(out, ref)
         diag(f"gemm geglu tile={tile} prec={prec} rel_l2={e:.3e}")
         assert e < TOL[prec]
@@ -173,7 +190,7 @@ def test_gemm_heuristic_large(diag):
     """A level-0 sized problem (M = 4*938) goes through the tile heuristic."""
     rng = np.random.default_rng(7)
     for prec in (0, 1):
-        out, ref = run_gemm(rng, prec, 4, 938, 938, 128, 0, 128, 3, 0, 1, 1, 1, 1, 0)
+        out, ref, _ = run_gemm(rng, prec, 4, 938, 938, 128, 0, 128, 3, 0, 1, 1, 0, 0)
         e = rel_l2(out, ref)
         diag(f"gemm level0 prec={prec} rel_l2={e:.3e}")
         assert e < TOL[prec]
@@ -234,28 +251,27 @@ def test_attention(case, prec, diag):
     else:
         ref = ref_attention(q, k, v, bias, H, prec)
     a = AttnArgs()
+    esz = 2 if prec == 1 else 4
     if packed:   # q|k|v interleaved per row, as the fused QKV GEMM writes them
-        qkv = np.concatenate([q, k, v], axis=-1)
-        d_qkv = _dev(qkv)
-        a.q, a.k, a.v = d_qkv.ptr, d_qkv.ptr + D * 4, d_qkv.ptr + 2 * D * 4
+        d_qkv = OpBuf(np.concatenate([q, k, v], axis=-1), prec)
+        a.q, a.k, a.v = d_qkv.ptr, d_qkv.ptr + D * esz, d_qkv.ptr + 2 * D * esz
         a.ldq = a.ldk = a.ldv = 3 * D
     else:        # k|v side by side with extra columns around, as the hoisted cross K/V buffer
         pad = 64
         kv = np.concatenate([np.zeros((B, Lk, pad), np.float32), k, v, np.zeros((B, Lk, pad), np.float32)], axis=-1)
-        d_q, d_kv = _dev(q), _dev(kv)
-        a.q, a.k, a.v = d_q.ptr, d_kv.ptr + pad * 4, d_kv.ptr + (pad + D) * 4
+        d_q, d_kv = OpBuf(q, prec), OpBuf(kv, prec)
+        a.q, a.k, a.v = d_q.ptr, d_kv.ptr + pad * esz, d_kv.ptr + (pad + D) * esz
         a.ldq, a.ldk, a.ldv = D, 2 * D + 2 * pad, 2 * D + 2 * pad
     a.B, a.H, a.Lq, a.Lk = B, H, Lq, Lk
     d_bias = _dev(bias) if bias is not None else None
     if d_bias is not None:
         a.bias = d_bias.ptr
     a.scale = 1.0 / np.sqrt(hd)
-    d_out = DevBuf(B * Lq * D * 4)
-    d_out.upload(np.full((B, Lq, D), np.nan, dtype=np.float32))
+    d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
     a.out, a.ldo = d_out.ptr, D
     check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
     sync()
-    out = d_out.to_numpy((B, Lq, D))
+    out = d_out.read((B, Lq, D))
     e = rel_l2(out, ref)
     diag(f"attn {name} prec={prec} rel_l2={e:.3e} nan={int(np.isnan(out).sum())}")
     tol = 2e-5 if prec == 0 else 1.5e-2      # bf16: P is rounded to bf16 before the PV MFMA
@@ -303,21 +319,51 @@ def test_groupnorm_coef(shape, diag):
         assert e1 < 1e-5 and e2 < 1e-5
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [(77, 128), (300, 512), (5, 384), (1000, 256)], ids=str)
-def test_layernorm_stats(shape, diag):
+def test_layernorm_apply(shape, prec, diag):
     from ns2vc_amd._lib import check
-    from ns2vc_amd.engine import DevBuf, sync
+    from ns2vc_amd.engine import sync
     lib = _lib()
     M, C_ = shape
     rng = np.random.default_rng(M)
     x = (rng.standard_normal((M, C_)) * 1.5 + 0.3).astype(np.float32)
-    d_x, d_s = _dev(x), DevBuf(M * 2 * 4)
-    check(lib.ns2vc_k_layernorm_stats(d_x.ptr, C_, M, C_, 1e-5, d_s.ptr, None), "ln_stats")
+    d_x = _dev(x)
+    d_o = OpBuf(np.full((M, C_), np.nan, np.float32), prec)
+    check(lib.ns2vc_k_layernorm_apply(d_x.ptr, C_, M, C_, 1e-5, d_o.ptr, prec, None), "ln_apply")
     sync()
-    st = d_s.to_numpy((M, 2))
-    mu = x.astype(np.float64).mean(-1)
-    rstd = 1 / np.sqrt(x.astype(np.float64).var(-1) + 1e-5)
-    assert rel_l2(st[:, 0], mu) < 1e-5 and rel_l2(st[:, 1], rstd) < 1e-5
+    xd = x.astype(np.float64)
+    ref = (xd - xd.mean(-1, keepdims=True)) / np.sqrt(xd.var(-1, keepdims=True) + 1e-5)
+    e = rel_l2(d_o.read(), ref)
+    diag(f"layernorm_apply {shape} prec={prec} rel_l2={e:.3e}")
+    assert e < (2e-6 if prec == 0 else 4e-3)
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+def test_groupnorm_apply(prec, diag):
+    from ns2vc_amd._lib import check
+    from ns2vc_amd.engine import sync
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    for (B, T, c0, c1, silu_on) in [(2, 37, 128, 0, 1), (2, 90, 512, 384, 1), (3, 70, 256, 0, 0), (1, 5, 128, 128, 1)]:
+        C_ = c0 + c1
+        a0 = rng.standard_normal((B, T, c0)).astype(np.float32)
+        a1 = rng.standard_normal((B, T, c1)).astype(np.float32) if c1 else None
+        ps = (1 + 0.3 * rng.standard_normal((B, C_))).astype(np.float32)
+        ph = (0.3 * rng.standard_normal((B, C_))).astype(np.float32)
+        A = (a0 if a1 is None else np.concatenate([a0, a1], -1)).astype(np.float64)
+        ref = A * ps[:, None, :] + ph[:, None, :]
+        if silu_on:
+            ref = silu(ref)
+        d_a0, d_a1, d_ps, d_ph = _dev(a0), (_dev(a1) if a1 is not None else None), _dev(ps), _dev(ph)
+        d_o = OpBuf(np.full((B, T, C_), np.nan, np.float32), prec)
+        d_r = OpBuf(np.full((B, T, C_), np.nan, np.float32), prec)
+        check(lib.ns2vc_k_groupnorm_apply(d_a0.ptr, c0, c0, d_a1.ptr if d_a1 else None, c1, c1, B, T, d_ps.ptr, d_ph.ptr, silu_on,
+                                          d_o.ptr, d_r.ptr, prec, None), "gn_apply")
+        sync()
+        e1, e2 = rel_l2(d_o.read(), ref), rel_l2(d_r.read(), A)
+        diag(f"groupnorm_apply {(B, T, c0, c1, silu_on)} prec={prec} out {e1:.2e} raw {e2:.2e}")
+        assert e1 < (2e-6 if prec == 0 else 4e-3) and e2 < (1e-7 if prec == 0 else 4e-3)
 
 
 def test_layout_roundtrip(diag):
