@@ -153,13 +153,11 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
 int ns2vc_debug_set_gemm_tile(int bm, int bn); /* force the GEMM tile (128|64 x 128|64); 0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
-/* GroupNorm statistics of a (possibly concatenated) fp32 tensor folded with gamma/beta (+ time scale/shift)
- * into a per-(batch,channel) affine; then ns2vc_k_groupnorm_apply writes act(x*scale+shift) as an operand tensor. */
-int ns2vc_k_groupnorm_coef(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
-                           const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off,
-                           float* pscale, float* pshift, void* stream);
-int ns2vc_k_groupnorm_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T,
-                            const float* pscale, const float* pshift, int silu, void* out_op, void* raw_op, int precision, void* stream);
+/* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,
+ * written as an operand tensor [B*T][c0+c1]; raw_op (optional) receives the un-normalised concat. Synchronous. */
+int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
+                      const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off, int silu,
+                      void* out_op, void* raw_op, int precision, void* stream);
 /* LayerNorm without affine (gamma/beta are folded into the consumer's weights): fp32 rows -> operand rows */
 int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream);
 int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream);

@@ -484,7 +484,6 @@ struct Planner {
   size_t opsz = 2;
   // scratch shared by all layers (stream-ordered)
   double* gn_partial = nullptr;
-  float *ps = nullptr, *ph = nullptr;
   void *xn = nullptr, *xr = nullptr;     // GroupNorm-applied / raw operand copies of a resnet input
   int gn_rows = 64;
 
@@ -539,16 +538,15 @@ struct Planner {
   // (= act(GN(x)) with the concat materialised), optionally also the raw concat `raw` for a 1x1 shortcut.
   void groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
                  const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw) {
+    (void)cout;
     const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N, pr = prec;
-    double* part = gn_partial; float* ps_ = ps; float* ph_ = ph;
+    double* part = gn_partial;
     const double n = (double)Bq * Tl * (c0 + c1);
     add(name + ".gn_stats", [=](hipStream_t s) { return launch_gn_partial(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, part, nchunk, rows, s); },
         3, 3.0 * n, 4.0 * n);
-    add(name + ".gn_coef", [=](hipStream_t s) {
-      return launch_gn_coef(part, nchunk, Bq, Tl, c0 + c1, Gq, eps, gamma, beta, temb, ldt, temb_off, cout, ps_, ph_, s);
-    });
-    add(name + ".gn_apply", [=](hipStream_t s) { return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, ps_, ph_, silu, dst, raw, pr, s); },
-        3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0)));
+    add(name + ".gn_apply", [=](hipStream_t s) {
+      return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, eps, part, nchunk, gamma, beta, temb, ldt, temb_off, silu, dst, raw, pr, s);
+    }, 3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0)));
   }
 
   // ResnetBlock2D (resnet.py:591-641).  out (fp32) [+ out_op operand copy when a conv consumes it next]
@@ -676,9 +674,8 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   h->t_dev = P.alloc<float>((size_t)B);
   h->step_dev = P.alloc<int>(64);
   // ---- shared scratch
-  P.gn_rows = 64;
+  P.gn_rows = 32;
   P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
-  P.ps = P.alloc<float>((size_t)B * 2 * maxC); P.ph = P.alloc<float>((size_t)B * 2 * maxC);
   P.xn = P.alloc_op(maxIn); P.xr = P.alloc_op(maxIn);
   float* h1 = P.alloc<float>(maxMC);
   void* hn = P.alloc_op(maxMC);
@@ -1176,24 +1173,20 @@ int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, voi
   if (e != hipSuccess) return fail("launch_attention: %s", hipGetErrorString(e));
   return 0;
 }
-int ns2vc_k_groupnorm_coef(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
-                           const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off, float* pscale,
-                           float* pshift, void* stream) {
-  const int rows = 64, nchunk = (T + rows - 1) / rows;
+int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
+                      const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op,
+                      void* raw_op, int precision, void* stream) {
+  const int rows = 32, nchunk = (T + rows - 1) / rows;
   double* part = nullptr;
   HIPCHK(hipMalloc((void**)&part, (size_t)B * nchunk * G * 2 * sizeof(double)));
   hipError_t e = launch_gn_partial(a0, lda0, c0, a1, lda1, c1, B, T, G, part, nchunk, rows, (hipStream_t)stream);
-  if (e == hipSuccess) e = launch_gn_coef(part, nchunk, B, T, c0 + c1, G, eps, gamma, beta, temb, ldtemb, temb_off, c0 + c1, pscale, pshift, (hipStream_t)stream);
+  if (e == hipSuccess)
+    e = launch_gn_apply(a0, lda0, c0, a1, lda1, c1, B, T, G, eps, part, nchunk, gamma, beta, temb, ldtemb, temb_off, silu, out_op, raw_op,
+                        precision, (hipStream_t)stream);
   hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(part);
   if (e != hipSuccess) return fail("groupnorm launch: %s", hipGetErrorString(e));
   if (e2 != hipSuccess) return fail("groupnorm sync: %s", hipGetErrorString(e2));
-  return 0;
-}
-int ns2vc_k_groupnorm_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, const float* pscale,
-                            const float* pshift, int silu, void* out_op, void* raw_op, int precision, void* stream) {
-  hipError_t e = launch_gn_apply(a0, lda0, c0, a1, lda1, c1, B, T, pscale, pshift, silu, out_op, raw_op, precision, (hipStream_t)stream);
-  if (e != hipSuccess) return fail("gn_apply launch: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream) {

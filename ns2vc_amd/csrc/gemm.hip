@@ -199,9 +199,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     if (++stage == STAGES) stage = 0;
   }
 
-  // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Residual values are fetched for the whole wave tile BEFORE any store is issued: res may alias
+  // out_f32 element-for-element (in-place y += f(y)), which otherwise serialises load -> store pairs.
   float* of = g.out_f32;
   TM* oo = reinterpret_cast<TM*>(g.out_op);
+  const int mrow0 = m0 + wm * WM + 4 * hi;
   if (g.geglu) {
     if constexpr (NT == 2) {
       const int ncol = n0 + wn * WN + l31;            // packed column of the value half; gate = +32
@@ -210,12 +213,17 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
       const int ocol = ((n0 + wn * WN) >> 1) + l31;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
+        float rv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          rv[r] = (g.res && m < g.M) ? g.res[(size_t)m * g.ldres + ocol] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
           if (m < g.M) {
-            float v = (acc[i][0][r] + bv) * gelu_erf_f(acc[i][1][r] + bg);
-            if (g.res) v += g.res[(size_t)m * g.ldres + ocol];
+            const float v = (acc[i][0][r] + bv) * gelu_erf_f(acc[i][1][r] + bg) + rv[r];
             if (of) of[(size_t)m * g.ldo_f32 + ocol] = v;
             if (oo) store_op<TM>(oo + (size_t)m * g.ldo_op + ocol, v);
           }
@@ -227,14 +235,21 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     for (int j = 0; j < NT; ++j) {
       const int ncol = n0 + wn * WN + j * 32 + l31;
       const float bv = g.bias ? g.bias[ncol] : 0.f;
+      float rv[MT][16];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+          rv[i][r] = (g.res && m < g.M) ? g.res[(size_t)m * g.ldres + ncol] : 0.f;
+        }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
           if (m < g.M) {
-            float v = acc[i][j][r] + bv;
-            if (g.res) v += g.res[(size_t)m * g.ldres + ncol];
+            const float v = acc[i][j][r] + bv + rv[i][r];
             if (of) of[(size_t)m * g.ldo_f32 + ncol] = v;
             if (oo) store_op<TM>(oo + (size_t)m * g.ldo_op + ncol, v);
           }

@@ -18,111 +18,117 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---------------------------------------------------------------------------
-// GroupNorm statistics over a (possibly concatenated) channels-last tensor.
+// GroupNorm over a (possibly concatenated) channels-last fp32 tensor, in two launches.
 // Reference: nn.GroupNorm at resnet.py:536,557 / transformer_1d.py:134 /
 // unet_1d_condition.py:546; concat at unet_1d_blocks.py:2085,2187 (groups may
 // straddle the seam between the two sources).
-// grid (nchunk, B); each block reduces `rows` frames of one batch item for all
-// G groups and writes (sum, sumsq) per group in double.
+//
+// 1) gn_partial: grid (nchunk, B); a half-wave (32 lanes) per group reduces `rows`
+//    frames of one batch item and writes (sum, sumsq) in double.  Deterministic
+//    (fixed shuffle tree), fp32 only inside a lane's <=128-element partial.
+// 2) gn_apply: every block re-derives mean/rstd of its batch item from the
+//    partials (G*nchunk doubles), folds gamma/beta and the resnet's time
+//    scale/shift (resnet.py:625-629) into a per-channel affine and writes
+//    act(x*scale+shift) as an OPERAND tensor [B*T][c0+c1] — the skip concat is
+//    materialised here, in the operand type, as a side effect; optionally also the
+//    raw concat for the resnet's 1x1 shortcut conv.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ a0, int lda0, int c0,
                                                          const float* __restrict__ a1, int lda1, int c1, int T, int G,
                                                          double* __restrict__ partial, int rows) {
-  __shared__ float s_sum[256], s_sq[256];
   const int tid = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
-  const int C = c0 + c1, nq = C >> 2, Cg = C / G;
-  const int rl = max(1, 256 / nq);                 // row lanes
-  const int quad = tid % nq, rlane = tid / nq;
+  const int g = tid >> 5, i = tid & 31;
+  const int C = c0 + c1, Cg = C / G, qpg = Cg >> 2;       // float4 quads per group (<= 32)
+  const int rl = 32 / qpg;                                  // row lanes per half-wave
+  const int quad = i % qpg, rlane = i / qpg;
   float sum = 0.f, sq = 0.f;
   const int r0 = chunk * rows, r1 = min(T, r0 + rows);
-  if (rlane < rl) {                                  // host guarantees C <= 1024, i.e. nq <= 256
-    const int c = quad * 4;
+  if (g < G && rlane < rl) {
+    const int c = g * Cg + quad * 4;
     const float* src; int ld, cs;
     if (c < c0) { src = a0; ld = lda0; cs = c; } else { src = a1; ld = lda1; cs = c - c0; }
-    for (int r = r0 + rlane; r < r1; r += rl) {
-      const float4 v = *reinterpret_cast<const float4*>(src + ((size_t)(b * T + r) * ld + cs));
+    const float* p = src + ((size_t)b * T) * ld + cs;
+    int r = r0 + rlane;
+    for (; r + 3 * rl < r1; r += 4 * rl) {                  // 4 independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(p + (size_t)r * ld);
+      const float4 v1 = *reinterpret_cast<const float4*>(p + (size_t)(r + rl) * ld);
+      const float4 v2 = *reinterpret_cast<const float4*>(p + (size_t)(r + 2 * rl) * ld);
+      const float4 v3 = *reinterpret_cast<const float4*>(p + (size_t)(r + 3 * rl) * ld);
+      sum += ((v0.x + v0.y) + (v0.z + v0.w)) + ((v1.x + v1.y) + (v1.z + v1.w)) + ((v2.x + v2.y) + (v2.z + v2.w)) + ((v3.x + v3.y) + (v3.z + v3.w));
+      sq += ((v0.x * v0.x + v0.y * v0.y) + (v0.z * v0.z + v0.w * v0.w)) + ((v1.x * v1.x + v1.y * v1.y) + (v1.z * v1.z + v1.w * v1.w)) +
+            ((v2.x * v2.x + v2.y * v2.y) + (v2.z * v2.z + v2.w * v2.w)) + ((v3.x * v3.x + v3.y * v3.y) + (v3.z * v3.z + v3.w * v3.w));
+    }
+    for (; r < r1; r += rl) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)r * ld);
       sum += (v.x + v.y) + (v.z + v.w);
       sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
   }
-  s_sum[tid] = sum; s_sq[tid] = sq;
-  __syncthreads();
-  if (tid < G) {
-    double ds = 0.0, dq = 0.0;
-    const int nact = min(256, rl * nq);
-    for (int i = 0; i < nact; ++i) {
-      const int g = ((i % nq) * 4) / Cg;
-      if (g == tid) { ds += (double)s_sum[i]; dq += (double)s_sq[i]; }
-    }
-    double* p = partial + ((size_t)(b * nchunk + chunk) * G + tid) * 2;
+  double ds = (double)sum, dq = (double)sq;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }   // stays inside the half-wave
+  if (i == 0 && g < G) {
+    double* p = partial + ((size_t)(b * nchunk + chunk) * G + g) * 2;
     p[0] = ds; p[1] = dq;
   }
 }
 
-// Finalise GroupNorm statistics and fold everything that is per-(batch,channel)
-// into one affine:  y = x*pscale + pshift  ==  GN(x)*gamma+beta, then optionally
-// *(1+scale)+shift with the resnet's time projection (resnet.py:625-629).
-__global__ __launch_bounds__(256) void gn_coef_kernel(const double* __restrict__ partial, int nchunk, int T, int C, int G,
-                                                      float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ temb, int ldtemb, int temb_off, int cout,
-                                                      float* __restrict__ pscale, float* __restrict__ pshift) {
-  __shared__ float s_mean[64], s_rstd[64];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int Cg = C / G;
-  if (tid < G) {
-    double ds = 0.0, dq = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const double* p = partial + ((size_t)(b * nchunk + k) * G + tid) * 2;
-      ds += p[0]; dq += p[1];
-    }
-    const double n = (double)T * (double)Cg;
-    const double mean = ds / n;
-    double var = dq / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[tid] = (float)mean;
-    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / Cg;
-    float sc = s_rstd[g] * gamma[c];
-    float sh = beta[c] - s_mean[g] * sc;
-    if (temb) {
-      const float s1 = 1.0f + temb[(size_t)b * ldtemb + temb_off + c];
-      const float sf = temb[(size_t)b * ldtemb + temb_off + cout + c];
-      sc *= s1;
-      sh = sh * s1 + sf;
-    }
-    pscale[(size_t)b * C + c] = sc;
-    pshift[(size_t)b * C + c] = sh;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// GroupNorm apply: out = act(x*pscale[b,c] + pshift[b,c]) written as an operand tensor
-// [B*T][c0+c1] (the skip concat is materialised here, in the operand type, as a side effect);
-// optionally also the raw (un-normalised) concat for the resnet's 1x1 shortcut conv.
-// ---------------------------------------------------------------------------
 template <typename TM>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ a0, int lda0, int c0, const float* __restrict__ a1,
-                                                       int lda1, int c1, int T, const float* __restrict__ pscale,
-                                                       const float* __restrict__ pshift, int silu, TM* __restrict__ out,
-                                                       TM* __restrict__ raw, int rows) {
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const int C = c0 + c1, nq = C >> 2;
+                                                       int lda1, int c1, int T, int G, float eps, const double* __restrict__ partial,
+                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ temb, int ldtemb, int temb_off, int silu,
+                                                       TM* __restrict__ out, TM* __restrict__ raw, int rows) {
+  __shared__ float s_mean[8], s_rstd[8];
+  const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
+  const int C = c0 + c1, nq = C >> 2, Cg = C / G;
+  for (int g = wave; g < G; g += 4) {          // finalise the statistics of this batch item (every block, cheap)
+    double ds = 0.0, dq = 0.0;
+    for (int k = lane; k < nchunk; k += 64) {
+      const double* p = partial + ((size_t)(b * nchunk + k) * G + g) * 2;
+      ds += p[0]; dq += p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+    if (lane == 0) {
+      const double n = (double)T * (double)Cg;
+      const double mean = ds / n;
+      double var = dq / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
   const int rl = max(1, 256 / nq);
   const int quad = tid % nq, rlane = tid / nq;
   if (rlane >= rl) return;
   const int c = quad * 4;
   const float* src; int ld, cs;
   if (c < c0) { src = a0; ld = lda0; cs = c; } else { src = a1; ld = lda1; cs = c - c0; }
-  const float4 sc = *reinterpret_cast<const float4*>(pscale + (size_t)b * C + c);
-  const float4 sh = *reinterpret_cast<const float4*>(pshift + (size_t)b * C + c);
+  float sc[4], sh[4];
+  {
+    const int g = c / Cg;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 be = *reinterpret_cast<const float4*>(beta + c);
+    const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sc[e] = s_rstd[g] * gam[e];
+      sh[e] = bet[e] - s_mean[g] * sc[e];
+      if (temb) {
+        const float s1 = 1.0f + temb[(size_t)b * ldtemb + temb_off + c + e];
+        const float sf = temb[(size_t)b * ldtemb + temb_off + C + c + e];
+        sc[e] *= s1;
+        sh[e] = sh[e] * s1 + sf;
+      }
+    }
+  }
   const int r0 = blockIdx.x * rows, r1 = min(T, r0 + rows);
   for (int r = r0 + rlane; r < r1; r += rl) {
     const size_t row = (size_t)b * T + r;
     const float4 v = *reinterpret_cast<const float4*>(src + row * ld + cs);
-    float y0 = v.x * sc.x + sh.x, y1 = v.y * sc.y + sh.y, y2 = v.z * sc.z + sh.z, y3 = v.w * sc.w + sh.w;
+    float y0 = v.x * sc[0] + sh[0], y1 = v.y * sc[1] + sh[1], y2 = v.z * sc[2] + sh[2], y3 = v.w * sc[3] + sh[3];
     if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
     store_op4<TM>(out + row * C + c, y0, y1, y2, y3);
     if (raw) store_op4<TM>(raw + row * C + c, v.x, v.y, v.z, v.w);
@@ -422,27 +428,23 @@ __global__ void fill_i32_kernel(int* p, int v) { if (threadIdx.x == 0 && blockId
 hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G,
                              double* partial, int nchunk, int rows_per_chunk, hipStream_t s) {
   const int C = c0 + c1;
-  if (C > 1024 || (C & 3) || (c0 & 3) || G > 64 || C % G || (C / G) % 4) return hipErrorInvalidValue;
+  if (C > 1024 || (C & 3) || (c0 & 3) || G > 8 || C % G || (C / G) % 4 || (C / G) > 128) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, partial, rows_per_chunk);
   return hipGetLastError();
 }
-hipError_t launch_gn_coef(const double* partial, int nchunk, int B, int T, int C, int G, float eps, const float* gamma,
-                          const float* beta, const float* temb, int ldtemb, int temb_off, int cout, float* pscale,
-                          float* pshift, hipStream_t s) {
-  hipLaunchKernelGGL(gn_coef_kernel, dim3(B), dim3(256), 0, s, partial, nchunk, T, C, G, eps, gamma, beta, temb, ldtemb, temb_off,
-                     cout, pscale, pshift);
-  return hipGetLastError();
-}
-hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, const float* pscale,
-                           const float* pshift, int silu, void* out_op, void* raw_op, int prec, hipStream_t s) {
+hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
+                           const double* partial, int nchunk, const float* gamma, const float* beta, const float* temb, int ldtemb,
+                           int temb_off, int silu, void* out_op, void* raw_op, int prec, hipStream_t s) {
   const int C = c0 + c1;
-  if (C > 1024 || (C & 3) || (c0 & 3)) return hipErrorInvalidValue;
+  if (C > 1024 || (C & 3) || (c0 & 3) || G > 8) return hipErrorInvalidValue;
   const int rows = 32;
   dim3 grid((T + rows - 1) / rows, B);
   if (prec == PREC_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, pscale, pshift, silu, (bf16_t*)out_op, (bf16_t*)raw_op, rows);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, gamma, beta,
+                       temb, ldtemb, temb_off, silu, (bf16_t*)out_op, (bf16_t*)raw_op, rows);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, pscale, pshift, silu, (float*)out_op, (float*)raw_op, rows);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, gamma, beta,
+                       temb, ldtemb, temb_off, silu, (float*)out_op, (float*)raw_op, rows);
   return hipGetLastError();
 }
 hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s) {
