@@ -199,60 +199,75 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     if (++stage == STAGES) stage = 0;
   }
 
-  // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Residual values are fetched for the whole wave tile BEFORE any store is issued: res may alias
-  // out_f32 element-for-element (in-place y += f(y)), which otherwise serialises load -> store pairs.
+  // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), i.e. a lane
+  // owns ONE column: direct stores would be 4-byte (fp32) / 2-byte (bf16) scalars.  Instead every wave transposes
+  // its tile through its own slice of the (now idle) LDS ring and then moves whole rows: 16-B loads of bias /
+  // residual, 16-B fp32 and 8-B bf16 stores, fully coalesced.
+  constexpr int EP = WN + 4;                       // LDS pitch in floats (16-B aligned rows)
+  static_assert(4 * WM * EP * 4 <= STAGES * STAGE, "epilogue staging must fit in the LDS ring");
+  __syncthreads();                                 // every wave is done reading the last K tile
+  float* et = reinterpret_cast<float*>(smem) + wave * (WM * EP);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et[(i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
   float* of = g.out_f32;
   TM* oo = reinterpret_cast<TM*>(g.out_op);
-  const int mrow0 = m0 + wm * WM + 4 * hi;
+  const int mw0 = m0 + wm * WM;
   if (g.geglu) {
     if constexpr (NT == 2) {
-      const int ncol = n0 + wn * WN + l31;            // packed column of the value half; gate = +32
-      const float bv = g.bias ? g.bias[ncol] : 0.f;
-      const float bg = g.bias ? g.bias[ncol + 32] : 0.f;
-      const int ocol = ((n0 + wn * WN) >> 1) + l31;
+      constexpr int LPR = 8, RPI = 8, NIT = WM / RPI;          // 32 output columns per row = 8 lanes x 4
+      const int rsub = lane >> 3, cq = lane & 7;
+      const int pcol = n0 + wn * WN + cq * 4;                  // packed column of the value quad; gate quad = +32
+      const int ocol = ((n0 + wn * WN) >> 1) + cq * 4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+      if (g.bias) { bv = *reinterpret_cast<const float4*>(g.bias + pcol); bg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        float rv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          rv[r] = (g.res && m < g.M) ? g.res[(size_t)m * g.ldres + ocol] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (m < g.M) {
-            const float v = (acc[i][0][r] + bv) * gelu_erf_f(acc[i][1][r] + bg) + rv[r];
-            if (of) of[(size_t)m * g.ldo_f32 + ocol] = v;
-            if (oo) store_op<TM>(oo + (size_t)m * g.ldo_op + ocol, v);
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + rsub, m = mw0 + row;
+        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        const float4 t = *reinterpret_cast<const float4*>(et + row * EP + 32 + cq * 4);
+        if (m < g.M) {
+          float4 v;
+          v.x = (a.x + bv.x) * gelu_erf_f(t.x + bg.x); v.y = (a.y + bv.y) * gelu_erf_f(t.y + bg.y);
+          v.z = (a.z + bv.z) * gelu_erf_f(t.z + bg.z); v.w = (a.w + bv.w) * gelu_erf_f(t.w + bg.w);
+          if (g.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
         }
       }
+      (void)LPR;
     }
   } else {
+    constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;
+    const int rsub = lane / LPR, cq = lane % LPR;
+    const int ncol = n0 + wn * WN + cq * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+    constexpr int RB = NIT < 8 ? NIT : 8;                      // residual rows fetched per batch (before any store:
+#pragma unroll                                                 //  res may alias out_f32 element-for-element)
+    for (int it0 = 0; it0 < NIT; it0 += RB) {
+      float4 rr[RB];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int ncol = n0 + wn * WN + j * 32 + l31;
-      const float bv = g.bias ? g.bias[ncol] : 0.f;
-      float rv[MT][16];
+      for (int k = 0; k < RB; ++k) {
+        const int m = mw0 + (it0 + k) * RPI + rsub;
+        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          rv[i][r] = (g.res && m < g.M) ? g.res[(size_t)m * g.ldres + ncol] : 0.f;
-        }
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-          if (m < g.M) {
-            const float v = acc[i][j][r] + bv + rv[i][r];
-            if (of) of[(size_t)m * g.ldo_f32 + ncol] = v;
-            if (oo) store_op<TM>(oo + (size_t)m * g.ldo_op + ncol, v);
-          }
+      for (int k = 0; k < RB; ++k) {
+        const int row = (it0 + k) * RPI + rsub, m = mw0 + row;
+        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        if (m < g.M) {
+          float4 v;
+          v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
         }
       }
     }
@@ -301,6 +316,7 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.K != g.taps * (g.c0 + g.c1)) return hipErrorInvalidValue;
   if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
   if (!g.out_f32 && !g.out_op) return hipErrorInvalidValue;
+  if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
   if (prec == PREC_BF16) return launch_typed<bf16_t>(g, s);
   return launch_typed<float>(g, s);
 }

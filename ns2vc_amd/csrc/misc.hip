@@ -306,10 +306,13 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
                                                          const float* __restrict__ w2t, const float* __restrict__ b2,
                                                          const float* __restrict__ aug, float* __restrict__ emb,
                                                          TM* __restrict__ emb_act, int tdim, int edim) {
-  extern __shared__ float s_te[];           // tdim sinusoid + edim hidden
+  // grid (B, edim/64): every block recomputes the (cheap) hidden layer and produces 64 outputs of the second
+  // Linear with 4 k-slices per output, so the 1 MB second weight matrix is spread over 8x more CUs.
+  extern __shared__ float s_te[];           // tdim sinusoid + edim hidden + 256 partials
   float* s_sin = s_te;
   float* s_h = s_te + tdim;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  float* s_part = s_h + edim;
+  const int b = blockIdx.x, oc = blockIdx.y, tid = threadIdx.x;
   const float t = step_ptr ? t_ptr[(size_t)(*step_ptr) * coef_stride] : t_ptr[(size_t)b * t_stride];
   const int half = tdim >> 1;
   for (int i = tid; i < half; i += 256) {
@@ -321,16 +324,34 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
   }
   __syncthreads();
   for (int o = tid; o < edim; o += 256) {
-    float y = b1[o];
-#pragma unroll 16
-    for (int i = 0; i < tdim; ++i) y += w1t[(size_t)i * edim + o] * s_sin[i];
+    float y0 = b1[o], y1 = 0.f, y2 = 0.f, y3 = 0.f;
+    for (int i = 0; i < tdim; i += 4) {
+      y0 += w1t[(size_t)i * edim + o] * s_sin[i];
+      y1 += w1t[(size_t)(i + 1) * edim + o] * s_sin[i + 1];
+      y2 += w1t[(size_t)(i + 2) * edim + o] * s_sin[i + 2];
+      y3 += w1t[(size_t)(i + 3) * edim + o] * s_sin[i + 3];
+    }
+    const float y = (y0 + y1) + (y2 + y3);
     s_h[o] = y / (1.0f + expf(-y));
   }
   __syncthreads();
-  for (int o = tid; o < edim; o += 256) {
-    float y = b2[o];
-#pragma unroll 16
-    for (int i = 0; i < edim; ++i) y += w2t[(size_t)i * edim + o] * s_h[i];
+  {
+    const int o = oc * 64 + (tid & 63), ks = tid >> 6, kn = edim >> 2;     // k-slice [ks*kn, (ks+1)*kn)
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+    const float* wp = w2t + (size_t)(ks * kn) * edim + o;
+    const float* hp = s_h + ks * kn;
+    for (int i = 0; i < kn; i += 4) {
+      y0 += wp[(size_t)i * edim] * hp[i];
+      y1 += wp[(size_t)(i + 1) * edim] * hp[i + 1];
+      y2 += wp[(size_t)(i + 2) * edim] * hp[i + 2];
+      y3 += wp[(size_t)(i + 3) * edim] * hp[i + 3];
+    }
+    s_part[tid] = (y0 + y1) + (y2 + y3);
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int o = oc * 64 + tid;
+    float y = b2[o] + ((s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]));
     if (aug) y += aug[(size_t)b * edim + o];
     emb[(size_t)b * edim + o] = y;
     store_op<TM>(emb_act + (size_t)b * edim + o, y / (1.0f + expf(-y)));
@@ -484,11 +505,12 @@ hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, 
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride, const float* w1t,
                              const float* b1, const float* w2t, const float* b2, const float* aug, float* emb, void* emb_act_op,
                              int prec, int B, int tdim, int edim, hipStream_t s) {
-  const size_t lds = (size_t)(tdim + edim) * sizeof(float);
+  const size_t lds = (size_t)(tdim + edim + 256) * sizeof(float);
+  if ((edim & 63) || (tdim & 3) || (edim & 15)) return hipErrorInvalidValue;
   if (prec == PREC_BF16)
-    hipLaunchKernelGGL(time_embed_kernel<bf16_t>, dim3(B), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (bf16_t*)emb_act_op, tdim, edim);
+    hipLaunchKernelGGL(time_embed_kernel<bf16_t>, dim3(B, edim / 64), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (bf16_t*)emb_act_op, tdim, edim);
   else
-    hipLaunchKernelGGL(time_embed_kernel<float>, dim3(B), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (float*)emb_act_op, tdim, edim);
+    hipLaunchKernelGGL(time_embed_kernel<float>, dim3(B, edim / 64), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (float*)emb_act_op, tdim, edim);
   return hipGetLastError();
 }
 hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s) {
