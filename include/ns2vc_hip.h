@@ -151,7 +151,7 @@ int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev)
 int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);
 int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
-int ns2vc_debug_set_gemm_tile(int bm, int bn); /* force the GEMM tile (128|64 x 128|64); 0,0 = heuristic */
+int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile (128|64 x 128|64) and LDS ring depth (2..4); 0,0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
 /* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,
  * written as an operand tensor [B*T][c0+c1]; raw_op (optional) receives the un-normalised concat. Synchronous. */

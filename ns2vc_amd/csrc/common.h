@@ -93,7 +93,7 @@ enum Precision { PREC_F32 = 0, PREC_BF16 = 1 };
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
-void set_forced_gemm_tile(int bm, int bn);
+void set_forced_gemm_tile(int bm, int bn, int stages);
 hipError_t init_attn_attributes();
 
 // misc kernels (misc.hip).  "op" buffers are operand-typed (bf16 when prec == PREC_BF16, else fp32)

@@ -1160,7 +1160,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
   *out_dev = d;
   return 0;
 }
-int ns2vc_debug_set_gemm_tile(int bm, int bn) { set_forced_gemm_tile(bm, bn); return 0; }
+int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages) { set_forced_gemm_tile(bm, bn, stages); return 0; }
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_gemm(*a, precision, (hipStream_t)stream);

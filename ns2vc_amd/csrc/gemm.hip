@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   // its tile through its own slice of the (now idle) LDS ring and then moves whole rows: 16-B loads of bias /
   // residual, 16-B fp32 and 8-B bf16 stores, fully coalesced.
   constexpr int EP = WN + 4;                       // LDS pitch in floats (16-B aligned rows)
-  static_assert(4 * WM * EP * 4 <= STAGES * STAGE, "epilogue staging must fit in the LDS ring");
   __syncthreads();                                 // every wave is done reading the last K tile
   float* et = reinterpret_cast<float*>(smem) + wave * (WM * EP);
 #pragma unroll
@@ -277,36 +276,54 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+// LDS = max(STAGES-deep operand ring, the epilogue's per-wave transpose tiles)
+static constexpr size_t gemm_lds_bytes(int bm, int bn, int stages) {
+  const size_t ring = (size_t)stages * (bm + bn) * TROW;
+  const size_t epi = (size_t)4 * (bm / 2) * (bn / 2 + 4) * 4;
+  return ring > epi ? ring : epi;
+}
+
 template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
-  const size_t lds = (size_t)STAGES * (BM + BN) * TROW;
+  const size_t lds = gemm_lds_bytes(BM, BN, STAGES);
   hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(256), lds, s, g);
   return hipGetLastError();
 }
 
-static int g_force_bm = 0, g_force_bn = 0;
-void set_forced_gemm_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
+static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
+void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages; }
 
 template <typename TM>
 static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
   auto blocks = [&](int bm, int bn) { return (long)(g.N / bn) * ((g.M + bm - 1) / bm); };
-  int bm, bn;
+  const int bke = 128 / (int)sizeof(TM);
+  const int nk = g.K / bke;
+  int bm, bn, st;
   const bool n128 = (g.N % 128) == 0;
   if (g_force_bm) {   // test / tuning hook (ns2vc_debug_set_gemm_tile)
-    bm = g_force_bm; bn = g_force_bn;
+    bm = g_force_bm; bn = g_force_bn; st = g_force_st ? g_force_st : 3;
     if (g.N % bn || (g.geglu && bn != 128)) return hipErrorInvalidValue;
-  } else if (g.geglu) {
-    if (!n128) return hipErrorInvalidValue;
-    bn = 128; bm = blocks(128, 128) >= 256 ? 128 : 64;
-  } else if (n128 && blocks(128, 128) >= 256) { bm = 128; bn = 128; }
-  else if (n128 && blocks(64, 128) >= 256) { bm = 64; bn = 128; }
-  else if (blocks(128, 64) >= 256) { bm = 128; bn = 64; }
-  else { bm = 64; bn = 64; }
-  if (bm == 128 && bn == 128) return launch_cfg<TM, 128, 128, 3>(g, s);
-  if (bm == 64 && bn == 128) return launch_cfg<TM, 64, 128, 3>(g, s);
-  if (bm == 128 && bn == 64) return launch_cfg<TM, 128, 64, 3>(g, s);
-  if (bm == 64 && bn == 64) return launch_cfg<TM, 64, 64, 4>(g, s);
+  } else {
+    // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01.txt):
+    // these GEMMs are short (7-35 us) and latency/occupancy-bound, so the small-LDS configurations that keep
+    // 3-5 workgroups resident per CU win; deeper rings only pay for long K at small M.
+    (void)blocks;
+    if (g.geglu) {
+      if (!n128) return hipErrorInvalidValue;
+      bm = 64; bn = 128; st = 2;
+    } else if (n128 && (g.M >= 12000 || g.N >= 1024)) {
+      bm = 64; bn = 128; st = nk >= 24 ? 3 : 2;
+    } else {
+      bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
+    }
+  }
+#define NS2VC_CASE(BM_, BN_, ST_) if (bm == BM_ && bn == BN_ && st == ST_) return launch_cfg<TM, BM_, BN_, ST_>(g, s)
+  NS2VC_CASE(128, 128, 2); NS2VC_CASE(128, 128, 3);
+  NS2VC_CASE(64, 128, 2); NS2VC_CASE(64, 128, 3); NS2VC_CASE(64, 128, 4);
+  NS2VC_CASE(128, 64, 2); NS2VC_CASE(128, 64, 3); NS2VC_CASE(128, 64, 4);
+  NS2VC_CASE(64, 64, 2); NS2VC_CASE(64, 64, 3); NS2VC_CASE(64, 64, 4);
+#undef NS2VC_CASE
   return hipErrorInvalidValue;
 }
 
@@ -327,13 +344,16 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
 
 #define NS2VC_SET(TM, BM, BN, ST)                                                                              \
   do {                                                                                                          \
-    hipError_t e = set_lds(gemm2_kernel<TM, BM, BN, ST>, (size_t)ST * (BM + BN) * TROW);                        \
+    hipError_t e = set_lds(gemm2_kernel<TM, BM, BN, ST>, gemm_lds_bytes(BM, BN, ST));                           \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 
+#define NS2VC_SET_BOTH(BM, BN, ST) NS2VC_SET(float, BM, BN, ST); NS2VC_SET(bf16_t, BM, BN, ST)
 hipError_t init_gemm_attributes() {
-  NS2VC_SET(float, 128, 128, 3); NS2VC_SET(float, 64, 128, 3); NS2VC_SET(float, 128, 64, 3); NS2VC_SET(float, 64, 64, 4);
-  NS2VC_SET(bf16_t, 128, 128, 3); NS2VC_SET(bf16_t, 64, 128, 3); NS2VC_SET(bf16_t, 128, 64, 3); NS2VC_SET(bf16_t, 64, 64, 4);
+  NS2VC_SET_BOTH(128, 128, 2); NS2VC_SET_BOTH(128, 128, 3);
+  NS2VC_SET_BOTH(64, 128, 2); NS2VC_SET_BOTH(64, 128, 3); NS2VC_SET_BOTH(64, 128, 4);
+  NS2VC_SET_BOTH(128, 64, 2); NS2VC_SET_BOTH(128, 64, 3); NS2VC_SET_BOTH(128, 64, 4);
+  NS2VC_SET_BOTH(64, 64, 2); NS2VC_SET_BOTH(64, 64, 3); NS2VC_SET_BOTH(64, 64, 4);
   return hipSuccess;
 }
 

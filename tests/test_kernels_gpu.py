@@ -71,7 +71,7 @@ def rnd(a, prec):
     return bf16_round(np.asarray(a, dtype=np.float32)) if prec == 1 else np.asarray(a, dtype=np.float32)
 
 
-def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, geglu, dual, tile=(0, 0)):
+def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, geglu, dual, tile=(0, 0, 0)):
     from ns2vc_amd._lib import GemmArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
@@ -122,7 +122,7 @@ def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, g
         check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
         sync()
     finally:
-        lib.ns2vc_debug_set_gemm_tile(0, 0)
+        lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
     out = d_out.to_numpy((M, Nout))
     out_op = d_oop.read() if d_oop is not None else None
     lib.ns2vc_dev_free(d_w)
@@ -165,7 +165,8 @@ def test_gemm_cases(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
-@pytest.mark.parametrize("tile", [(128, 128), (64, 128), (128, 64), (64, 64)], ids=lambda t: f"{t[0]}x{t[1]}")
+@pytest.mark.parametrize("tile", [(128, 128, 2), (128, 128, 3), (64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 64, 2), (128, 64, 3),
+                                  (128, 64, 4), (64, 64, 2), (64, 64, 3), (64, 64, 4)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_every_tile(tile, prec, diag):
     rng = np.random.default_rng(tile[0] * 1000 + tile[1])
     # M = 3*167 = 501 rows (tail in every tile size), concat + conv3 + bias + residual, K = 3*192 (9 / 18 tiles)

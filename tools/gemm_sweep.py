@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Time the model's GEMM shapes under every tile / ring-depth configuration (GPU box only).
+
+    python tools/gemm_sweep.py [--prec bf16] [--reps 30] > gpurun_out/gemm_sweep.txt
+
+Drives ns2vc_k_gemm through the C ABI with HIP events; used to derive the tile heuristic
+in csrc/gemm.hip.  Shapes: the distinct (M, N, K, taps, geglu, res, out) of the 10 s x batch-32 plan.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ns2vc_amd import _lib                     # noqa: E402
+from ns2vc_amd._lib import GemmArgs, check     # noqa: E402
+from ns2vc_amd.engine import DevBuf, Event, Stream  # noqa: E402
+
+CONFIGS = [(128, 128, 2), (128, 128, 3), (64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 64, 2), (128, 64, 3), (128, 64, 4),
+           (64, 64, 2), (64, 64, 3), (64, 64, 4)]
+
+
+def shapes(B=32, T=938):
+    Ts = [T, (T + 1) // 2, ((T + 1) // 2 + 1) // 2, (((T + 1) // 2 + 1) // 2 + 1) // 2]
+    Cs = [128, 256, 384, 512]
+    out = []
+    for l, (Tl, c) in enumerate(zip(Ts, Cs)):
+        M = B * Tl
+        out += [(f"L{l}.conv3 {c}->{c}", M, c, 3 * c, 3, 0, 1, "f32"),
+                (f"L{l}.lin {c}->{c} +res", M, c, c, 1, 0, 1, "f32"),
+                (f"L{l}.lin {c}->{c} op", M, c, c, 1, 0, 0, "op"),
+                (f"L{l}.qkv", M, 3 * c, c, 1, 0, 0, "op"),
+                (f"L{l}.geglu", M, 8 * c, c, 1, 1, 0, "op"),
+                (f"L{l}.ff_out", M, c, 4 * c, 1, 0, 1, "op")]
+    out += [("L3.conv3 1024->512", B * Ts[3], 512, 3 * 1024, 3, 0, 0, "f32"), ("L2.conv3 896->384", B * Ts[2], 384, 3 * 896, 3, 0, 0, "f32"),
+            ("L1.conv3 640->256", B * Ts[1], 256, 3 * 640, 3, 0, 0, "f32"), ("L0.conv3 384->128", B * Ts[0], 128, 3 * 384, 3, 0, 0, "f32"),
+            ("L3.sc 1024->512", B * Ts[3], 512, 1024, 1, 0, 0, "f32"), ("temb", B, 14848, 512, 1, 0, 0, "f32")]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prec", default="bf16")
+    ap.add_argument("--reps", type=int, default=30)
+    a = ap.parse_args()
+    prec = 1 if a.prec == "bf16" else 0
+    esz = 2 if prec else 4
+    lib = _lib.load()
+    st = Stream()
+    rng = np.random.default_rng(0)
+    print(f"# prec={a.prec}; time in us (best config marked *)")
+    for name, M, N, K, taps, geglu, res, outk in shapes():
+        Cin = K // taps
+        Tt = M // 32 if M >= 32 * 8 else 1
+        Bb = M // Tt
+        M = Bb * Tt
+        A = DevBuf(M * Cin * esz + 4096)
+        W = DevBuf(N * K * esz)
+        bias = DevBuf.from_numpy(rng.standard_normal(N).astype(np.float32))
+        Nout = N // 2 if geglu else N
+        R = DevBuf(M * Nout * 4) if res else None
+        O32 = DevBuf(M * Nout * 4)
+        Oop = DevBuf(M * Nout * esz)
+        g = GemmArgs()
+        g.a0 = A.ptr; g.lda0 = Cin; g.c0 = Cin
+        g.B, g.Tin, g.Tout, g.M = Bb, Tt, Tt, M
+        g.taps, g.tmode = taps, 0
+        g.w = W.ptr; g.K = K; g.N = N; g.bias = bias.ptr
+        if R is not None:
+            g.res = R.ptr; g.ldres = Nout
+        g.geglu = geglu
+        if outk == "f32":
+            g.out_f32 = O32.ptr; g.ldo_f32 = Nout
+        else:
+            g.out_op = Oop.ptr; g.ldo_op = Nout
+        flops = 2.0 * M * N * K
+        row = []
+        for cfg in CONFIGS:
+            if N % cfg[1] or (geglu and cfg[1] != 128):
+                row.append(None)
+                continue
+            check(lib.ns2vc_debug_set_gemm_tile(*cfg), "tile")
+            for _ in range(3):
+                check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
+            e0, e1 = Event(), Event()
+            e0.record(st)
+            for _ in range(a.reps):
+                check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
+            e1.record(st)
+            st.sync()
+            row.append(e0.elapsed_ms(e1) * 1e3 / a.reps)
+        lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+        for _ in range(3):
+            check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
+        e0, e1 = Event(), Event()
+        e0.record(st)
+        for _ in range(a.reps):
+            check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
+        e1.record(st)
+        st.sync()
+        heur = e0.elapsed_ms(e1) * 1e3 / a.reps
+        best = min(v for v in row if v is not None)
+        cells = " ".join(("   -- " if v is None else f"{v:6.1f}" + ("*" if v == best else " ")) for v in row)
+        print(f"{name:22s} M={M:6d} N={N:5d} K={K:5d} | {cells} | heur {heur:6.1f} best {flops/best/1e6:6.0f} TF/s")
+    print("# configs:", " ".join(f"{c[0]}x{c[1]}s{c[2]}" for c in CONFIGS))
+
+
+if __name__ == "__main__":
+    main()
