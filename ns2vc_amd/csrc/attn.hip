@@ -227,11 +227,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         }
     }
     l_run = l_run * alpha + psum;
+    if (__any(m_new > m_run)) {                      // wave-uniform: once the running max has settled alpha == 1 exactly
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
     m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
 
     // ---- O^T[d][q] += sum_key V^T[d][key] * P^T[key][q]
 #pragma unroll
