@@ -88,7 +88,7 @@ def cpu_baseline(T: int, Lp: int, budget_s: float = 20.0):
     th, dt2 = best
     torch.set_num_threads(th)
     B = 8
-    iters = int(max(1, min(5, (budget_s * 0.6) / max(dt2 * B / 2, 1e-3))))
+    iters = int(max(2, min(60, (budget_s * 0.7) / max(dt2 * B / 2, 1e-3))))
     dt = run(B, iters)
     sample_steps = B * iters / dt
     return {"value": sample_steps / 32.0, "unit": "denoiser-steps/s (batch 32)", "cores": th, "host_cores": cores, "kind": "port",
@@ -178,8 +178,8 @@ def main():
     fam = {}
     if rank == 0:
         ops = eng.op_info(0)
-        ms = eng.profile_forward(stream=stream)          # warm: second call is the one we keep
-        ms = eng.profile_forward(stream=stream)
+        eng.profile_forward(reps=2, stream=stream)        # warm-up pass
+        ms = eng.profile_forward(reps=8, stream=stream)   # 8 back-to-back launches per event pair
         names = {0: "other", 1: "implicit_gemm", 2: "attention", 3: "norm_stats", 4: "copy"}
         if a.ops:
             with open(a.ops, "w") as f:

@@ -104,8 +104,9 @@ int ns2vc_unet_num_launches(ns2vc_unet* h, int* per_forward, int* per_condition)
 /* which: 0 = per-step forward plan, 1 = condition plan.  kind: 0 other, 1 implicit GEMM, 2 attention,
  * 3 norm statistics, 4 copy.  flops / bytes: algorithmic work of that launch. */
 int ns2vc_unet_op_info(ns2vc_unet* h, int which, int idx, char* name, int buflen, int* kind, double* flops, double* bytes);
-/* Eager run of the per-step plan with a hipEvent pair around every launch; ms[n_ms >= launches]. Synchronous. */
-int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, void* stream);
+/* Per-launch timing of the per-step plan: each launch repeated `reps` times between one hipEvent pair on
+ * `stream`; ms[i] = average milliseconds of launch i (n_ms >= launches). Leaves garbage in the workspace. Synchronous. */
+int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, int reps, void* stream);
 
 /* ---- raw device helpers so tests/bench can drive the ABI without torch ------------------ */
 int ns2vc_dev_malloc(void** out, size_t bytes);

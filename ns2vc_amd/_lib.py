@@ -80,7 +80,7 @@ PROTOTYPES = {
     "ns2vc_unet_tap_read": (_I, [_P, _I, _P]),
     "ns2vc_unet_num_launches": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "ns2vc_unet_op_info": (_I, [_P, _I, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "ns2vc_unet_profile_forward": (_I, [_P, C.POINTER(C.c_float), _I, _P]),
+    "ns2vc_unet_profile_forward": (_I, [_P, C.POINTER(C.c_float), _I, _I, _P]),
     "ns2vc_dev_malloc": (_I, [_PP, C.c_size_t]),
     "ns2vc_dev_free": (_I, [_P]),
     "ns2vc_memcpy_h2d": (_I, [_P, _P, C.c_size_t]),

@@ -1094,27 +1094,33 @@ int ns2vc_unet_op_info(ns2vc_unet* h, int which, int idx, char* name, int buflen
   return 0;
 }
 
-// Runs the per-step forward plan EAGERLY with a hipEvent pair around every launch on `stream`
-// and returns the elapsed milliseconds per op (ms[num_launches]).  The model input is whatever
-// the last forward / sampler call left in the engine's x buffer.  Synchronous.
-int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, void* stream) {
+// Times every launch of the per-step forward plan on `stream`: each op is launched `reps` times back to back
+// between one hipEvent pair (so the event/launch overhead is amortised and the figure approaches the kernel's
+// own duration, comparable with rocprofv3's kernel trace).  ms[i] = average milliseconds of launch i.
+// The tensors hold garbage afterwards (in-place ops were repeated).  Synchronous.
+int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, int reps, void* stream) {
   if (check_ready(h, true)) return 1;
   const size_t n = h->fwd_ops.size();
   if ((size_t)n_ms < n) return fail("ms buffer too small: need %zu", n);
+  if (reps < 1) reps = 1;
   hipStream_t s = (hipStream_t)stream;
   h->use_step_table = false;      // time with the (B,) timestep buffer of the plain forward
-  std::vector<hipEvent_t> ev(n + 1);
+  std::vector<hipEvent_t> ev(2 * n);
   for (auto& e : ev) HIPCHK(hipEventCreate(&e));
   int rc = 0;
-  HIPCHK(hipEventRecord(ev[0], s));
   for (size_t i = 0; i < n && !rc; ++i) {
-    hipError_t e = h->fwd_ops[i].fn(s);
-    if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", h->fwd_ops[i].name.c_str(), hipGetErrorString(e));
-    if (!rc && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = fail("hipEventRecord failed");
+    if (hipEventRecord(ev[2 * i], s) != hipSuccess) rc = fail("hipEventRecord failed");
+    for (int r = 0; r < reps && !rc; ++r) {
+      hipError_t e = h->fwd_ops[i].fn(s);
+      if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", h->fwd_ops[i].name.c_str(), hipGetErrorString(e));
+    }
+    if (!rc && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) rc = fail("hipEventRecord failed");
   }
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
-  for (size_t i = 0; i < n && !rc; ++i)
-    if (hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
+  for (size_t i = 0; i < n && !rc; ++i) {
+    if (hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
+    ms[i] /= (float)reps;
+  }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }

@@ -262,11 +262,11 @@ class Engine:
             out.append((name.value.decode(), int(kind.value), float(fl.value), float(by.value)))
         return out
 
-    def profile_forward(self, stream=None) -> np.ndarray:
-        """Eager per-launch HIP-event timing of one per-step forward (ms per launch)."""
+    def profile_forward(self, reps: int = 5, stream=None) -> np.ndarray:
+        """Per-launch HIP-event timing of the per-step plan (average ms per launch over `reps` back-to-back launches)."""
         nf, _ = self.launches()
         ms = (C.c_float * nf)()
-        check(self.lib.ns2vc_unet_profile_forward(self.h, ms, nf, _stream_ptr(stream)), "profile_forward")
+        check(self.lib.ns2vc_unet_profile_forward(self.h, ms, nf, int(reps), _stream_ptr(stream)), "profile_forward")
         return np.array(list(ms), dtype=np.float64)
 
     # -- debug taps -----------------------------------------------------------------
