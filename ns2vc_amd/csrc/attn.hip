@@ -65,6 +65,17 @@ template <> __device__ __forceinline__ void vt_scatter<bf16_t>(char* vp, int row
   *reinterpret_cast<uint16_t*>(vp + 7 * rowb) = (uint16_t)(v.w >> 16);
 }
 
+// combine a value with its partner lane (lane ^ 32) without an LDS round trip: v_permlane32_swap puts the lower
+// half's values in one result and the upper half's in the other, for every lane
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <typename TM, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int SZ = AMma<TM>::SZ;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
     if (!need_bias) mx *= sc2;                       // sc2 > 0: max commutes with the scaling
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_max(mx);
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   }
 
   // ---- normalise and store O[q][h*HD + d]; lane holds d = dt*32 + 8*g + 4*hi + i
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = half_sum(l_run);
   const float inv = 1.0f / l_tot;
   if (q < a.Lq) {
     TM* op = reinterpret_cast<TM*>(a.out) + ((size_t)(b * a.Lq + q) * a.ldo + h * HD);

@@ -125,13 +125,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
   }
   const int r0 = blockIdx.x * rows, r1 = min(T, r0 + rows);
-  for (int r = r0 + rlane; r < r1; r += rl) {
-    const size_t row = (size_t)b * T + r;
-    const float4 v = *reinterpret_cast<const float4*>(src + row * ld + cs);
-    float y0 = v.x * sc[0] + sh[0], y1 = v.y * sc[1] + sh[1], y2 = v.z * sc[2] + sh[2], y3 = v.w * sc[3] + sh[3];
-    if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-    store_op4<TM>(out + row * C + c, y0, y1, y2, y3);
-    if (raw) store_op4<TM>(raw + row * C + c, v.x, v.y, v.z, v.w);
+  for (int rb = r0 + rlane; rb < r1; rb += 4 * rl) {     // 4 independent 16-B loads in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rb + k * rl;
+      v[k] = (r < r1) ? *reinterpret_cast<const float4*>(src + ((size_t)b * T + r) * ld + cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rb + k * rl;
+      if (r < r1) {
+        const size_t row = (size_t)b * T + r;
+        float y0 = v[k].x * sc[0] + sh[0], y1 = v[k].y * sc[1] + sh[1], y2 = v[k].z * sc[2] + sh[2], y3 = v[k].w * sc[3] + sh[3];
+        if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+        store_op4<TM>(out + row * C + c, y0, y1, y2, y3);
+        if (raw) store_op4<TM>(raw + row * C + c, v[k].x, v[k].y, v[k].z, v[k].w);
+      }
+    }
   }
 }
 
@@ -139,32 +150,51 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // LayerNorm (attention.py:83,102,118) without the affine part (gamma/beta are folded into the
 // consumer GEMM's weights at pack time): one wave per fp32 row -> operand row.  C % 128 == 0.
 // ---------------------------------------------------------------------------
-template <typename TM>
+template <typename TM, int NP>      // NP = float2 pairs per lane = C / 128
 __global__ __launch_bounds__(256) void ln_apply_op_kernel(const float* __restrict__ x, int ldx, int M, int C, float eps,
                                                           TM* __restrict__ out) {
+  constexpr int R = 4;                          // rows per wave: 4 independent load streams / reduction chains
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  const float* p = x + (size_t)row * ldx;
-  float2 v[8];
-  float s = 0.f;
-  const int n = C >> 7;                        // float2 pairs per lane (C multiple of 128, <= 1024)
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
+  float2 v[R][NP];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    v[i] = (i < n) ? *reinterpret_cast<const float2*>(p + 2 * (lane + 64 * i)) : make_float2(0.f, 0.f);
-    s += v[i].x + v[i].y;
+  for (int r = 0; r < R; ++r) {
+    const float* p = x + (size_t)min(row0 + r, M - 1) * ldx;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) v[r][i] = *reinterpret_cast<const float2*>(p + 2 * (lane + 64 * i));
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  float s[R], q[R];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    if (i < n) { const float d0 = v[i].x - mean, d1 = v[i].y - mean; q += d0 * d0 + d1 * d1; }
+  for (int r = 0; r < R; ++r) {
+    s[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s[r] += v[r][i].x + v[r][i].y;
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-  TM* o = out + (size_t)row * C;
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (i < n) store_op2<TM>(o + 2 * (lane + 64 * i), (v[i].x - mean) * rstd, (v[i].y - mean) * rstd);
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    s[r] /= (float)C;                           // mean
+    q[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { const float d0 = v[r][i].x - s[r], d1 = v[r][i].y - s[r]; q[r] += d0 * d0 + d1 * d1; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (row0 + r < M) {
+      const float rstd = 1.0f / sqrtf(q[r] / (float)C + eps);
+      TM* o = out + (size_t)(row0 + r) * C;
+#pragma unroll
+      for (int i = 0; i < NP; ++i) store_op2<TM>(o + 2 * (lane + 64 * i), (v[r][i].x - s[r]) * rstd, (v[r][i].y - s[r]) * rstd);
+    }
+  }
 }
 
 template <typename TM>
@@ -468,11 +498,20 @@ hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, i
                        temb, ldtemb, temb_off, silu, (float*)out_op, (float*)raw_op, rows);
   return hipGetLastError();
 }
-hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s) {
-  if (C % 128 || C > 1024) return hipErrorInvalidValue;
-  if (prec == PREC_BF16) hipLaunchKernelGGL(ln_apply_op_kernel<bf16_t>, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, C, eps, (bf16_t*)out_op);
-  else hipLaunchKernelGGL(ln_apply_op_kernel<float>, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, M, C, eps, (float*)out_op);
+template <typename TM> static hipError_t launch_ln_t(const float* x, int ldx, int M, int C, float eps, TM* out, hipStream_t s) {
+  dim3 grid((M + 15) / 16);
+  switch (C / 128) {
+    case 1: hipLaunchKernelGGL((ln_apply_op_kernel<TM, 1>), grid, dim3(256), 0, s, x, ldx, M, C, eps, out); break;
+    case 2: hipLaunchKernelGGL((ln_apply_op_kernel<TM, 2>), grid, dim3(256), 0, s, x, ldx, M, C, eps, out); break;
+    case 3: hipLaunchKernelGGL((ln_apply_op_kernel<TM, 3>), grid, dim3(256), 0, s, x, ldx, M, C, eps, out); break;
+    case 4: hipLaunchKernelGGL((ln_apply_op_kernel<TM, 4>), grid, dim3(256), 0, s, x, ldx, M, C, eps, out); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
+}
+hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s) {
+  if (C % 128 || C > 512) return hipErrorInvalidValue;
+  return prec == PREC_BF16 ? launch_ln_t<bf16_t>(x, ldx, M, C, eps, (bf16_t*)out_op, s) : launch_ln_t<float>(x, ldx, M, C, eps, (float*)out_op, s);
 }
 hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s) {
   if (n & 3) return hipErrorInvalidValue;
