@@ -136,6 +136,10 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   int32_t geglu;
   float* out_f32; int32_t ldo_f32;/* fp32 result (residual stream), or NULL */
   void* out_op; int32_t ldo_op;   /* operand-typed copy of the result (feeds the next GEMM / attention), or NULL */
+  /* optional GroupNorm statistics of the result, accumulated by the epilogue: int64 fixed point
+   * [B][N/16][2] = (sum * 2^28, sum of squares * 2^16) per batch item and 16-channel block; must be zeroed
+   * by the caller; needs Tout >= 32, geglu == 0 */
+  long long* stats;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

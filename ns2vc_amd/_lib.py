@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldres", C.c_int32), ("geglu", C.c_int32),
         ("out_f32", C.c_void_p), ("ldo_f32", C.c_int32),
         ("out_op", C.c_void_p), ("ldo_op", C.c_int32),
+        ("stats", C.c_void_p),
     ]
 
 

@@ -88,6 +88,9 @@ typedef ::ns2vc_gemm_args GemmArgs;   // public POD, include/ns2vc_hip.h
 typedef ::ns2vc_attn_args AttnArgs;
 
 enum Precision { PREC_F32 = 0, PREC_BF16 = 1 };
+// fixed-point scales of the epilogue GroupNorm statistics (order-independent int64 atomics => deterministic)
+constexpr double GN_SUM_SCALE = 268435456.0;   // 2^28
+constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
@@ -100,8 +103,9 @@ hipError_t init_attn_attributes();
 hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1,
                              int B, int T, int G, double* partial, int nchunk, int rows_per_chunk, hipStream_t s);
 hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
-                           const double* partial, int nchunk, const float* gamma, const float* beta, const float* temb, int ldtemb,
-                           int temb_off, int silu, void* out_op, void* raw_op, int prec, hipStream_t s);
+                           const double* partial, int nchunk, const long long* st0, const long long* st1, const float* gamma,
+                           const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, void* raw_op,
+                           int prec, hipStream_t s);
 hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s);
 hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s);
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride,

@@ -124,6 +124,7 @@ struct ns2vc_unet {
   float *t_dev = nullptr;
   uint8_t* mask_dev = nullptr;
   int* step_dev = nullptr;
+  size_t stats_bytes = 8;
   float* coef_dev = nullptr;
   int steps = 0;
   bool use_step_table = false;
@@ -486,6 +487,24 @@ struct Planner {
   double* gn_partial = nullptr;
   void *xn = nullptr, *xr = nullptr;     // GroupNorm-applied / raw operand copies of a resnet input
   int gn_rows = 64;
+  // GroupNorm statistics accumulated by the producing GEMM's epilogue (int64 fixed point, [B][C/16][2]);
+  // one zeroed slab per produced tensor, all carved from stats_pool (cleared by one memset per forward)
+  long long* stats_pool = nullptr;
+  size_t stats_cap = 0, stats_used = 0;
+  std::map<const void*, long long*> stats_of;
+  long long* new_stats(const float* tensor, int Tl, int C) {
+    if (Tl < 64 || (C & 15)) { stats_of.erase(tensor); return nullptr; }
+    const size_t n = (size_t)B * (C / 16) * 2;
+    if (stats_used + n > stats_cap) { stats_of.erase(tensor); return nullptr; }
+    long long* p = stats_pool ? stats_pool + stats_used : reinterpret_cast<long long*>(sizeof(long long) * (stats_used + 1));  // sizing pass: non-null token
+    stats_used += n;
+    stats_of[tensor] = p;
+    return p;
+  }
+  long long* find_stats(const float* tensor) const {
+    auto it = stats_of.find(tensor);
+    return it == stats_of.end() ? nullptr : it->second;
+  }
 
   char* alloc_bytes(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -542,10 +561,17 @@ struct Planner {
     const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N, pr = prec;
     double* part = gn_partial;
     const double n = (double)Bq * Tl * (c0 + c1);
-    add(name + ".gn_stats", [=](hipStream_t s) { return launch_gn_partial(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, part, nchunk, rows, s); },
-        3, 3.0 * n, 4.0 * n);
+    const long long* st0 = find_stats(a0);
+    const long long* st1 = a1 ? find_stats(a1) : nullptr;
+    const bool epi = st0 && (!a1 || st1) && (((c0 + c1) / Gq) % 16 == 0) && (c0 % 16 == 0);
+    if (!epi) {
+      st0 = st1 = nullptr;
+      add(name + ".gn_stats", [=](hipStream_t s) { return launch_gn_partial(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, part, nchunk, rows, s); },
+          3, 3.0 * n, 4.0 * n);
+    }
     add(name + ".gn_apply", [=](hipStream_t s) {
-      return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, eps, part, nchunk, gamma, beta, temb, ldt, temb_off, silu, dst, raw, pr, s);
+      return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, eps, part, nchunk, st0, st1, gamma, beta, temb, ldt, temb_off, silu, dst,
+                             raw, pr, s);
     }, 3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0)));
   }
 
@@ -556,6 +582,7 @@ struct Planner {
     groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
+    g.stats = new_stats(h1, Tl, r.cout);
     gemm(r.prefix + ".conv1", g);
     groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
     const float* res; int ldres;
@@ -568,6 +595,7 @@ struct Planner {
     }
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3; g2.res = res; g2.ldres = ldres;
+    g2.stats = new_stats(out, Tl, r.cout);
     gemm(r.prefix + ".conv2", g2);
   }
 
@@ -623,6 +651,7 @@ struct Planner {
     gemm(t + ".ff.out", g);
     g = base(yn, d, d, Tl, Tl, a.proj_out, out, out_op, d);
     g.res = x; g.ldres = d;
+    g.stats = new_stats(out, Tl, d);
     gemm(a.prefix + ".proj_out", g);
   }
 };
@@ -725,6 +754,14 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   // ================= per-step forward plan =================
   P.ops = &h->fwd_ops;
   {
+    const size_t cap = (size_t)1 << 20;                 // 8 MB of int64 statistics slots
+    P.stats_pool = P.alloc<long long>(cap);
+    P.stats_cap = cap; P.stats_used = 0;
+    long long* pool = P.stats_pool;
+    ns2vc_unet* hq = h;
+    P.add("gn_stats.clear", [=](hipStream_t s) { return hipMemsetAsync(pool, 0, hq->stats_bytes, s); }, 4);
+  }
+  {
     ns2vc_unet* hh = h;
     const float *w1t = h->t_w1t, *b1 = h->t_b1, *w2t = h->t_w2t, *b2 = h->t_b2, *aug = h->aug;
     float *emb = h->emb, *tdev = h->t_dev;
@@ -747,6 +784,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     float* s0 = new_skip(0);
     GemmArgs g = P.base(h->xe_op, CP, CP, T, T, h->conv_in_x, s0, nullptr, c0);
     g.taps = 3; g.res = h->content_conv; g.ldres = c0;
+    g.stats = P.new_stats(s0, T, c0);
     P.gemm("conv_in", g);
     P.tap("conv_in", s0, B * T, c0);
   }
@@ -775,6 +813,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
         skips.back().C = b.channels;     // this block's channels at the next level's length
         GemmArgs g = P.base(samp_in, curC, curC, Tl, Ts[l + 1], b.samp, ds, nullptr, b.channels);
         g.taps = 3; g.tmode = TMODE_DOWN2;
+        g.stats = P.new_stats(ds, Ts[l + 1], b.channels);
         P.gemm(tag + ".downsample", g);
         P.tap(tag + ".ds", ds, B * Ts[l + 1], b.channels);
         cur = ds;
@@ -811,6 +850,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
         float* us = (cur == uc) ? ua : uc;
         GemmArgs g = P.base(samp_in, curC, curC, Tl, Ts[l - 1], b.samp, us, nullptr, b.channels);
         g.taps = 3; g.tmode = TMODE_UP2;
+        g.stats = P.new_stats(us, Ts[l - 1], b.channels);
         P.gemm(tag + ".upsample", g);
         P.tap(tag + ".us", us, B * Ts[l - 1], b.channels);
         cur = us;
@@ -828,6 +868,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   }
   if (sizing) h->arena_bytes = P.off;
   h->arena_used = P.off;
+  h->stats_bytes = std::max<size_t>(P.stats_used, 1) * sizeof(long long);
   return 0;
 }
 
@@ -1187,8 +1228,8 @@ int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int ld
   HIPCHK(hipMalloc((void**)&part, (size_t)B * nchunk * G * 2 * sizeof(double)));
   hipError_t e = launch_gn_partial(a0, lda0, c0, a1, lda1, c1, B, T, G, part, nchunk, rows, (hipStream_t)stream);
   if (e == hipSuccess)
-    e = launch_gn_apply(a0, lda0, c0, a1, lda1, c1, B, T, G, eps, part, nchunk, gamma, beta, temb, ldtemb, temb_off, silu, out_op, raw_op,
-                        precision, (hipStream_t)stream);
+    e = launch_gn_apply(a0, lda0, c0, a1, lda1, c1, B, T, G, eps, part, nchunk, nullptr, nullptr, gamma, beta, temb, ldtemb, temb_off, silu,
+                        out_op, raw_op, precision, (hipStream_t)stream);
   hipError_t e2 = hipStreamSynchronize((hipStream_t)stream);
   (void)hipFree(part);
   if (e != hipSuccess) return fail("groupnorm launch: %s", hipGetErrorString(e));

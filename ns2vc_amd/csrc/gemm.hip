@@ -249,6 +249,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     const int ncol = n0 + wn * WN + cq * 4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+    // optional GroupNorm statistics of the result: this wave's rows belong to batch b0 or b0+1 (Tout >= WM)
+    const int b0 = min(mw0, g.M - 1) / g.Tout;
+    const int mB = (b0 + 1) * g.Tout;                          // first row of the next batch item
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     constexpr int RB = NIT < 8 ? NIT : 8;                      // residual rows fetched per batch (before any store:
 #pragma unroll                                                 //  res may alias out_f32 element-for-element)
     for (int it0 = 0; it0 < NIT; it0 += RB) {
@@ -267,6 +271,31 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
           v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
           if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
           if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
+          const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
+        }
+      }
+    }
+    if (g.stats) {
+      // fixed shuffle tree over the lanes that share a 16-channel block (4 column quads x all row lanes),
+      // then ONE int64 fixed-point atomic per (batch item, block, moment): order-independent => deterministic
+      double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {                       // the 4 column quads of a 16-channel block
+        d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {                     // the row lanes
+        d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+      }
+      if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
+        const int blk = ncol >> 4, nblk = g.N >> 4;
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
+        atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
+        atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
+        if (mB < g.M && mB < mw0 + WM) {
+          atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
+          atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
         }
       }
     }
@@ -333,6 +362,7 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.K != g.taps * (g.c0 + g.c1)) return hipErrorInvalidValue;
   if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
   if (!g.out_f32 && !g.out_op) return hipErrorInvalidValue;
+  if (g.stats && (g.geglu || g.Tout < 64 || (g.N & 15))) return hipErrorInvalidValue;
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
   if (prec == PREC_BF16) return launch_typed<bf16_t>(g, s);
   return launch_typed<float>(g, s);

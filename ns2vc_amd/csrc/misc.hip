@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 template <typename TM>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ a0, int lda0, int c0, const float* __restrict__ a1,
                                                        int lda1, int c1, int T, int G, float eps, const double* __restrict__ partial,
-                                                       int nchunk, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       int nchunk, const long long* __restrict__ st0, const long long* __restrict__ st1,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ temb, int ldtemb, int temb_off, int silu,
                                                        TM* __restrict__ out, TM* __restrict__ raw, int rows) {
   __shared__ float s_mean[8], s_rstd[8];
@@ -84,9 +85,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   const int C = c0 + c1, nq = C >> 2, Cg = C / G;
   for (int g = wave; g < G; g += 4) {          // finalise the statistics of this batch item (every block, cheap)
     double ds = 0.0, dq = 0.0;
-    for (int k = lane; k < nchunk; k += 64) {
-      const double* p = partial + ((size_t)(b * nchunk + k) * G + g) * 2;
-      ds += p[0]; dq += p[1];
+    if (st0) {                                 // fixed-point statistics left by the producing GEMMs' epilogues
+      const int nb = Cg >> 4, nblk0 = c0 >> 4, nblk1 = c1 >> 4;
+      if (lane < nb) {
+        const int blk = g * nb + lane;         // 16-channel block of the (concatenated) input
+        const long long* p = blk < nblk0 ? st0 + ((size_t)b * nblk0 + blk) * 2 : st1 + ((size_t)b * nblk1 + (blk - nblk0)) * 2;
+        ds = (double)p[0] * (1.0 / GN_SUM_SCALE);
+        dq = (double)p[1] * (1.0 / GN_SQ_SCALE);
+      }
+    } else {
+      for (int k = lane; k < nchunk; k += 64) {
+        const double* p = partial + ((size_t)(b * nchunk + k) * G + g) * 2;
+        ds += p[0]; dq += p[1];
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
@@ -484,18 +495,20 @@ hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1,
   return hipGetLastError();
 }
 hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
-                           const double* partial, int nchunk, const float* gamma, const float* beta, const float* temb, int ldtemb,
-                           int temb_off, int silu, void* out_op, void* raw_op, int prec, hipStream_t s) {
+                           const double* partial, int nchunk, const long long* st0, const long long* st1, const float* gamma,
+                           const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, void* raw_op,
+                           int prec, hipStream_t s) {
   const int C = c0 + c1;
   if (C > 1024 || (C & 3) || (c0 & 3) || G > 8) return hipErrorInvalidValue;
+  if (st0 && (((C / G) & 15) || (c0 & 15) || (c1 && !st1))) return hipErrorInvalidValue;
   const int rows = 32;
   dim3 grid((T + rows - 1) / rows, B);
   if (prec == PREC_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, gamma, beta,
-                       temb, ldtemb, temb_off, silu, (bf16_t*)out_op, (bf16_t*)raw_op, rows);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, st0, st1,
+                       gamma, beta, temb, ldtemb, temb_off, silu, (bf16_t*)out_op, (bf16_t*)raw_op, rows);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, gamma, beta,
-                       temb, ldtemb, temb_off, silu, (float*)out_op, (float*)raw_op, rows);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, st0, st1,
+                       gamma, beta, temb, ldtemb, temb_off, silu, (float*)out_op, (float*)raw_op, rows);
   return hipGetLastError();
 }
 template <typename TM> static hipError_t launch_ln_t(const float* x, int ldx, int M, int C, float eps, TM* out, hipStream_t s) {

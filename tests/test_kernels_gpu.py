@@ -187,6 +187,48 @@ def test_gemm_every_tile(tile, prec, diag):
         assert e < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+def test_gemm_epilogue_groupnorm_stats(prec, diag):
+    """The epilogue's int64 fixed-point (sum, sumsq) per (batch item, 16-channel block) == numpy on the stored result,
+    for every tile shape, with row tiles that straddle batch boundaries (T = 167 is not a multiple of 32)."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(5)
+    B, T, c0, N = 3, 167, 128, 256
+    for tile in [(0, 0, 0), (128, 128, 2), (64, 128, 2), (128, 64, 2), (64, 64, 2)]:
+        a0 = rnd(rng.standard_normal((B, T, c0)), prec)
+        W = rnd(rng.standard_normal((N, 3 * c0)) / np.sqrt(3 * c0), prec)
+        bias = rng.standard_normal(N).astype(np.float32)
+        res = rng.standard_normal((B * T, N)).astype(np.float32)
+        d_a, d_w, d_b, d_r = OpBuf(a0, prec), _pack(W, prec), _dev(bias), _dev(res)
+        d_o = DevBuf(B * T * N * 4)
+        d_s = DevBuf.from_numpy(np.zeros((B, N // 16, 2), dtype=np.int64))
+        g = GemmArgs()
+        g.a0 = d_a.ptr; g.lda0 = c0; g.c0 = c0
+        g.B, g.Tin, g.Tout, g.M = B, T, T, B * T
+        g.taps, g.tmode = 3, 0
+        g.w = d_w.value; g.K = 3 * c0; g.N = N
+        g.bias = d_b.ptr; g.res = d_r.ptr; g.ldres = N
+        g.out_f32 = d_o.ptr; g.ldo_f32 = N
+        g.stats = d_s.ptr
+        check(lib.ns2vc_debug_set_gemm_tile(*tile), "tile")
+        try:
+            check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+            sync()
+        finally:
+            lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+        out = d_o.to_numpy((B, T, N)).astype(np.float64)
+        st = d_s.to_numpy((B, N // 16, 2), dtype=np.int64).astype(np.float64)
+        blk = out.reshape(B, T, N // 16, 16)
+        ref_s, ref_q = blk.sum(axis=(1, 3)), (blk ** 2).sum(axis=(1, 3))
+        e_s = np.abs(st[..., 0] / 2 ** 28 - ref_s).max() / np.abs(ref_s).max()
+        e_q = np.abs(st[..., 1] / 2 ** 16 - ref_q).max() / np.abs(ref_q).max()
+        diag(f"gemm epilogue stats tile={tile} prec={prec}: sum {e_s:.2e} sumsq {e_q:.2e}")
+        assert e_s < 1e-5 and e_q < 1e-5
+        lib.ns2vc_dev_free(d_w)
+
+
 def test_gemm_heuristic_large(diag):
     """A level-0 sized problem (M = 4*938) goes through the tile heuristic."""
     rng = np.random.default_rng(7)
