@@ -140,6 +140,9 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * [B][N/16][2] = (sum * 2^28, sum of squares * 2^16) per batch item and 16-channel block; must be zeroed
    * by the caller; needs Tout >= 32, geglu == 0 */
   long long* stats;
+  /* optional second K segment (a fused 1x1 conv on another operand tensor, e.g. the resnet shortcut):
+   * K = taps*(c0+c1) + c2, out += A2[m, :] * W[:, taps*(c0+c1):]; same row mapping, centre tap */
+  const void* a2; int32_t lda2, c2;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("out_f32", C.c_void_p), ("ldo_f32", C.c_int32),
         ("out_op", C.c_void_p), ("ldo_op", C.c_int32),
         ("stats", C.c_void_p),
+        ("a2", C.c_void_p), ("lda2", C.c_int32), ("c2", C.c_int32),
     ]
 
 

@@ -393,8 +393,24 @@ int pack_all(ns2vc_unet* h) {
       r.n1g = P.vec(r.prefix + ".norm1.weight"); r.n1b = P.vec(r.prefix + ".norm1.bias");
       r.n2g = P.vec(r.prefix + ".norm2.weight"); r.n2b = P.vec(r.prefix + ".norm2.bias");
       r.conv1 = P.conv(r.prefix + ".conv1");
-      r.conv2 = P.conv(r.prefix + ".conv2");
-      if (r.shortcut) r.sc = P.conv(r.prefix + ".conv_shortcut");
+      if (r.shortcut) {   // conv2 and the 1x1 shortcut share one GEMM: K = 3*cout + cin, biases summed
+        const HostTensor& w2 = P.T(r.prefix + ".conv2.weight");
+        const HostTensor& ws = P.T(r.prefix + ".conv_shortcut.weight");
+        const HostTensor& b2 = P.T(r.prefix + ".conv2.bias");
+        const HostTensor& bs = P.T(r.prefix + ".conv_shortcut.bias");
+        if (P.err) return 1;
+        const std::vector<float> r2 = P.conv_rows(w2, 0, r.cout, r.cout);
+        const int K1 = 3 * r.cout, K2 = r.cin;
+        std::vector<float> rows((size_t)r.cout * (K1 + K2)), bias(r.cout);
+        for (int n = 0; n < r.cout; ++n) {
+          memcpy(&rows[(size_t)n * (K1 + K2)], &r2[(size_t)n * K1], K1 * sizeof(float));
+          memcpy(&rows[(size_t)n * (K1 + K2) + K1], &ws.data[(size_t)n * K2], K2 * sizeof(float));
+          bias[n] = b2.data[n] + bs.data[n];
+        }
+        r.conv2 = P.pack(rows, r.cout, K1 + K2, bias);
+      } else {
+        r.conv2 = P.conv(r.prefix + ".conv2");
+      }
       const HostTensor& tw = P.T(r.prefix + ".time_emb_proj.weight");
       const HostTensor& tb = P.T(r.prefix + ".time_emb_proj.bias");
       if (P.err) return 1;
@@ -537,7 +553,7 @@ struct Planner {
     const double nout = g.geglu ? g.N / 2 : g.N;
     const double flops = 2.0 * g.M * (double)g.N * g.K;
     const double in_rows = (double)g.B * g.Tin;
-    const double bytes = in_rows * (g.c0 + g.c1) * osz + (double)g.N * g.K * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
+    const double bytes = in_rows * (g.c0 + g.c1 + g.c2) * osz + (double)g.N * g.K * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
                          (g.out_op ? g.M * nout * osz : 0.0) + (g.res ? g.M * nout * 4.0 : 0.0);
     add(name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes);
   }
@@ -585,16 +601,13 @@ struct Planner {
     g.stats = new_stats(h1, Tl, r.cout);
     gemm(r.prefix + ".conv1", g);
     groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
-    const float* res; int ldres;
-    if (r.shortcut) {
-      GemmArgs s = base(xr, cin, cin, Tl, Tl, r.sc, sc, nullptr, r.cout);
-      gemm(r.prefix + ".conv_shortcut", s);
-      res = sc; ldres = r.cout;
-    } else {
-      res = a0; ldres = lda0;
-    }
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
-    g2.taps = 3; g2.res = res; g2.ldres = ldres;
+    g2.taps = 3;
+    if (r.shortcut) {      // out = conv2(hn) + conv_shortcut(x): the 1x1 conv rides along as a second K segment
+      g2.a2 = xr; g2.lda2 = cin; g2.c2 = cin;
+    } else {
+      g2.res = a0; g2.ldres = lda0;
+    }
     g2.stats = new_stats(out, Tl, r.cout);
     gemm(r.prefix + ".conv2", g2);
   }

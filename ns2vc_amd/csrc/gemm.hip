@@ -126,14 +126,18 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   }
   const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
 
+  const int K1 = g.taps * Ctot;                      // K of the main (conv / linear) segment; the rest is the fused 1x1 segment
   auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
     const int k0 = kt * BKE;
-    const int tap = k0 / Ctot;
-    const int cc = k0 - tap * Ctot;
+    const bool seg2 = k0 >= K1;                      // block-uniform
+    const int k1 = seg2 ? 0 : k0;
+    const int tapq = k1 / Ctot;
+    const int tap = seg2 ? toff : tapq;              // the fused 1x1 segment reads the centre tap's rows
+    const int cc = k1 - tapq * Ctot;
     const bool first = cc < g.c0;
-    const unsigned long long src = reinterpret_cast<unsigned long long>(first ? g.a0 : g.a1);
-    const int ld = first ? g.lda0 : g.lda1;
-    const int csrc = first ? cc : cc - g.c0;
+    const unsigned long long src = reinterpret_cast<unsigned long long>(seg2 ? g.a2 : (first ? g.a0 : g.a1));
+    const int ld = seg2 ? g.lda2 : (first ? g.lda0 : g.lda1);
+    const int csrc = seg2 ? k0 - K1 : (first ? cc : cc - g.c0);
     const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int j = 0; j < LA; ++j) {
@@ -359,7 +363,8 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.N % 64 != 0 || g.M <= 0) return hipErrorInvalidValue;
   const int bke = prec == PREC_BF16 ? 64 : 32;
-  if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.K != g.taps * (g.c0 + g.c1)) return hipErrorInvalidValue;
+  if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return hipErrorInvalidValue;
+  if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return hipErrorInvalidValue;
   if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
   if (!g.out_f32 && !g.out_op) return hipErrorInvalidValue;
   if (g.stats && (g.geglu || g.Tout < 64 || (g.N & 15))) return hipErrorInvalidValue;

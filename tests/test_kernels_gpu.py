@@ -229,6 +229,38 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
         lib.ns2vc_dev_free(d_w)
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+def test_gemm_fused_shortcut_segment(prec, diag):
+    """conv3(hn) + conv1x1(x) in one launch: K = 3*c0 + c2 with the second segment on another operand tensor."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(9)
+    for (B, T, c0, c2, N) in [(2, 37, 128, 192, 128), (3, 70, 256, 640, 256)]:
+        M = B * T
+        hn = rnd(rng.standard_normal((B, T, c0)), prec)
+        x = rnd(rng.standard_normal((B, T, c2)), prec)
+        W = rnd(rng.standard_normal((N, 3 * c0 + c2)) / np.sqrt(3 * c0 + c2), prec)
+        bias = rng.standard_normal(N).astype(np.float32)
+        G = gather_rows(hn.astype(np.float64), B, T, T, 3, 0).reshape(M, 3 * c0)
+        ref = G @ W[:, :3 * c0].astype(np.float64).T + x.reshape(M, c2).astype(np.float64) @ W[:, 3 * c0:].astype(np.float64).T + bias
+        d_h, d_x, d_w, d_b = OpBuf(hn, prec), OpBuf(x, prec), _pack(W, prec), _dev(bias)
+        d_o = DevBuf(M * N * 4)
+        g = GemmArgs()
+        g.a0 = d_h.ptr; g.lda0 = c0; g.c0 = c0
+        g.a2 = d_x.ptr; g.lda2 = c2; g.c2 = c2
+        g.B, g.Tin, g.Tout, g.M = B, T, T, M
+        g.taps, g.tmode = 3, 0
+        g.w = d_w.value; g.K = 3 * c0 + c2; g.N = N; g.bias = d_b.ptr
+        g.out_f32 = d_o.ptr; g.ldo_f32 = N
+        check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+        sync()
+        e = rel_l2(d_o.to_numpy((M, N)), ref)
+        diag(f"gemm fused shortcut {(B, T, c0, c2, N)} prec={prec}: {e:.3e}")
+        assert e < TOL[prec]
+        lib.ns2vc_dev_free(d_w)
+
+
 def test_gemm_heuristic_large(diag):
     """A level-0 sized problem (M = 4*938) goes through the tile heuristic."""
     rng = np.random.default_rng(7)
