@@ -159,8 +159,17 @@ int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev)
 int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);
 int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
+int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile (128|64 x 128|64) and LDS ring depth (2..4); 0,0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
+/* Fused transformer row chains (bf16 operand type only).  A chain's weights are ONE device buffer of 16 KB tiles
+ * ([128 rows][64 k] bf16 in the kernel's swizzled LDS image, in consumption order) built by ns2vc_pack_chain_stream
+ * from `count` row-major fp32 matrices [Ns[i]][Ks[i]] (Ns multiple of 128, Ks multiple of 64).
+ * ns2vc_k_chain_ab:  y = A*W1^T + bias1 (+res) [fp32, M x D]; out2 = LayerNorm(y)*W2^T + bias2 [bf16, M x N2]
+ * (LayerNorm without affine: gamma/beta are folded into W2/bias2 by the caller). */
+int ns2vc_pack_chain_stream(const float* const* mats_host, const int* Ns, const int* Ks, int count, void** out_dev);
+int ns2vc_k_chain_ab(const void* a_op, int M, int D, const void* wstream, const float* bias1, const float* res, float* y, float eps,
+                     const float* bias2, void* out2_op, int N2, void* stream);
 /* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,
  * written as an operand tensor [B*T][c0+c1]; raw_op (optional) receives the un-normalised concat. Synchronous. */
 int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,

@@ -97,8 +97,11 @@ PROTOTYPES = {
     "ns2vc_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
     "ns2vc_pack_weight": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_k_gemm": (_I, [C.POINTER(GemmArgs), _I, _P]),
+    "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
+    "ns2vc_pack_chain_stream": (_I, [C.POINTER(C.c_void_p), C.POINTER(_I), C.POINTER(_I), _I, _PP]),
+    "ns2vc_k_chain_ab": (_I, [_P, _I, _I, _P, _P, _P, _P, C.c_float, _P, _P, _I, _P]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),

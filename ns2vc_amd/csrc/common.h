@@ -96,7 +96,11 @@ constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
+// fused row-panel chains (chain.hip), bf16 operand type only
+hipError_t launch_chain_ab(const void* a, int M, int D, const void* wstream, const float* bias1, const float* res, float* y, float eps,
+                           const float* bias2, void* out2, int N2, hipStream_t s);
 void set_forced_gemm_tile(int bm, int bn, int stages);
+void set_gemm_trace(unsigned long long* p);
 hipError_t init_attn_attributes();
 
 // misc kernels (misc.hip).  "op" buffers are operand-typed (bf16 when prec == PREC_BF16, else fp32)

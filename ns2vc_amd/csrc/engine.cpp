@@ -64,6 +64,9 @@ struct AttnW {
   int dim = 0, kv_off = 0;
   float *ng = nullptr, *nb = nullptr;
   PackedW proj_in, qkv, o1, q2, o2, ff1, ff2, proj_out;
+  // fused row chains (bf16): A = proj_in -> LN1 -> q|k|v ; B = attn1.to_out(+y) -> LN2 -> attn2.to_q
+  void *chain_a = nullptr, *chain_b = nullptr;
+  float *ca_b1 = nullptr, *ca_b2 = nullptr, *cb_b1 = nullptr, *cb_b2 = nullptr;
 };
 struct BlockW {
   std::string kind;   // down | mid | up
@@ -112,6 +115,7 @@ struct ns2vc_unet {
   size_t arena_bytes = 0, arena_used = 0;
   std::vector<Op> cond_ops, fwd_ops;
   bool debug = false;
+  bool use_chains = true;     // bf16: fused row-chain kernels for the transformer linears
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -267,6 +271,20 @@ void build_expected(ns2vc_unet* h) {
 // ------------------------------------------------------------------------------------
 // weight packing (host, fp32/double) -> device
 // ------------------------------------------------------------------------------------
+// Append the 16 KB weight tiles of a row-major [N][K] matrix (N % 128 == 0, K % 64 == 0) to a chain stream, in the
+// order the chain kernels consume them (128-row chunk major, 64-wide k-tile minor), each tile already in the
+// XOR-swizzled LDS image: byte r*128 + p*16 holds logical 16-B chunk p ^ ((r>>1)&7) of row r.
+static void append_chain_tiles(std::vector<uint16_t>& stream, const float* rows, int N, int K) {
+  for (int nc = 0; nc < N / 128; ++nc)
+    for (int kt = 0; kt < K / 64; ++kt)
+      for (int r = 0; r < 128; ++r)
+        for (int p = 0; p < 8; ++p) {
+          const int lc = p ^ ((r >> 1) & 7);
+          const float* src = rows + (size_t)(nc * 128 + r) * K + kt * 64 + lc * 8;
+          for (int e = 0; e < 8; ++e) stream.push_back(f32_to_bf16_bits(src[e]));
+        }
+}
+
 struct Packer {
   ns2vc_unet* h;
   int err = 0;
@@ -284,6 +302,13 @@ struct Packer {
     return (float*)d;
   }
   float* vec(const std::string& k) { return upload_f32(T(k).data); }
+  void* upload_stream(const std::vector<uint16_t>& v) {
+    void* d = nullptr;
+    if (hipMalloc(&d, std::max<size_t>(v.size(), 1) * 2) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return nullptr; }
+    h->weight_allocs.push_back(d);
+    if (hipMemcpy(d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed (weights)");
+    return d;
+  }
 
   // rows: [N][K] fp32, bias: [N] or empty.  Pads N to a multiple of 128 with zero rows.
   PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias) {
@@ -439,6 +464,22 @@ int pack_all(ns2vc_unet* h) {
         a.q2 = P.pack(rows, d, d, bias);
       }
       a.o2 = P.pack(P.T(t + ".attn2.to_out.0.weight").data, d, d, P.T(t + ".attn2.to_out.0.bias").data);
+      if (h->prec == PREC_BF16) {   // weight streams of the fused row chains
+        std::vector<float> qkv_rows, qkv_bias, q2_rows, q2_bias;
+        for (const char* nm : {"to_q", "to_k", "to_v"}) P.ln_fold(P.T(t + ".attn1." + nm + ".weight"), nullptr, P.T(t + ".norm1.weight"), P.T(t + ".norm1.bias"), qkv_rows, qkv_bias);
+        P.ln_fold(P.T(t + ".attn2.to_q.weight"), nullptr, P.T(t + ".norm2.weight"), P.T(t + ".norm2.bias"), q2_rows, q2_bias);
+        const HostTensor& pin = P.T(a.prefix + ".proj_in.weight");
+        const HostTensor& o1w = P.T(t + ".attn1.to_out.0.weight");
+        if (P.err) return 1;
+        std::vector<uint16_t> sa, sb;
+        append_chain_tiles(sa, pin.data.data(), d, d);            // (D, D, 1) conv == [D][D] rows
+        append_chain_tiles(sa, qkv_rows.data(), 3 * d, d);
+        append_chain_tiles(sb, o1w.data.data(), d, d);
+        append_chain_tiles(sb, q2_rows.data(), d, d);
+        a.chain_a = P.upload_stream(sa); a.chain_b = P.upload_stream(sb);
+        a.ca_b1 = P.vec(a.prefix + ".proj_in.bias"); a.ca_b2 = P.upload_f32(qkv_bias);
+        a.cb_b1 = P.vec(t + ".attn1.to_out.0.bias"); a.cb_b2 = P.upload_f32(q2_bias);
+      }
       {  // GEGLU projection: LayerNorm(norm3) folded, rows interleaved in (32 value | 32 gate) groups
         std::vector<float> rows, bias;
         P.ln_fold(P.T(t + ".ff.net.0.proj.weight"), &P.T(t + ".ff.net.0.proj.bias"), P.T(t + ".norm3.weight"), P.T(t + ".norm3.bias"), rows, bias);
@@ -631,23 +672,40 @@ struct Planner {
     const int d = a.dim, M = B * Tl, hd = d / h->cfg.heads, pr = prec;
     const std::string t = a.prefix + ".transformer_blocks.0";
     groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
-    GemmArgs g = base(xn, d, d, Tl, Tl, a.proj_in, y, nullptr, d);
-    gemm(a.prefix + ".proj_in", g);
+    GemmArgs g;
     auto layernorm = [&](const std::string& nm) {
       add(nm, [=](hipStream_t s) { return launch_ln_apply_op(y, d, M, d, 1e-5f, yn, pr, s); }, 3, 8.0 * M * d, (4.0 + opsz) * M * d);
     };
-    // self attention
-    layernorm(t + ".norm1");
-    g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
-    gemm(t + ".attn1.qkv", g);
+    const bool fused = (pr == PREC_BF16) && a.chain_a && h->use_chains;
+    const double wsz = (double)opsz;
+    if (fused) {
+      // proj_in -> LayerNorm(norm1) -> q|k|v in one launch: y (fp32) and qkv (operand) leave the chip, nothing else
+      const void* wsa = a.chain_a; const float *b1 = a.ca_b1, *b2 = a.ca_b2; void* xn_ = xn;
+      add(a.prefix + ".chainA[proj_in+norm1+qkv]", [=](hipStream_t s) { return launch_chain_ab(xn_, M, d, wsa, b1, nullptr, y, 1e-5f, b2, qkv, 3 * d, s); },
+          1, 2.0 * M * d * (4.0 * d), M * d * wsz + 4.0 * d * d * wsz + 4.0 * M * d + 3.0 * M * d * wsz);
+    } else {
+      g = base(xn, d, d, Tl, Tl, a.proj_in, y, nullptr, d);
+      gemm(a.prefix + ".proj_in", g);
+      // self attention
+      layernorm(t + ".norm1");
+      g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
+      gemm(t + ".attn1.qkv", g);
+    }
     attention(t + ".attn1.sdpa", qkv, 3 * d, op_off(qkv, d), 3 * d, op_off(qkv, 2 * d), 3 * d, Tl, Tl, nullptr, hd, ao, d);
-    g = base(ao, d, d, Tl, Tl, a.o1, y, nullptr, d);
-    g.res = y; g.ldres = d;
-    gemm(t + ".attn1.to_out", g);
+    if (fused) {
+      // attn1.to_out + residual -> LayerNorm(norm2) -> attn2.to_q
+      const void* wsb = a.chain_b; const float *b1 = a.cb_b1, *b2 = a.cb_b2;
+      add(t + ".chainB[attn1.to_out+norm2+to_q]", [=](hipStream_t s) { return launch_chain_ab(ao, M, d, wsb, b1, y, y, 1e-5f, b2, qb, d, s); },
+          1, 2.0 * M * d * (2.0 * d), M * d * wsz + 2.0 * d * d * wsz + 8.0 * M * d + M * d * wsz);
+    } else {
+      g = base(ao, d, d, Tl, Tl, a.o1, y, nullptr, d);
+      g.res = y; g.ldres = d;
+      gemm(t + ".attn1.to_out", g);
+      layernorm(t + ".norm2");
+      g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
+      gemm(t + ".attn2.to_q", g);
+    }
     // cross attention (k|v hoisted into h->kv by set_condition)
-    layernorm(t + ".norm2");
-    g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
-    gemm(t + ".attn2.to_q", g);
     const int nkv = h->kv_all.N;
     attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
               h->has_mask ? h->maskbias : nullptr, hd, ao, d);
@@ -1220,6 +1278,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
   *out_dev = d;
   return 0;
 }
+int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) { set_gemm_trace((unsigned long long*)dev_u64_blocks_x8); return 0; }
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages) { set_forced_gemm_tile(bm, bn, stages); return 0; }
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
@@ -1231,6 +1290,25 @@ int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, voi
   if (!a) return fail("null args");
   hipError_t e = launch_attention(*a, head_dim, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("launch_attention: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_pack_chain_stream(const float* const* mats_host, const int* Ns, const int* Ks, int count, void** out_dev) {
+  if (!mats_host || !Ns || !Ks || !out_dev || count <= 0) return fail("bad argument");
+  std::vector<uint16_t> st;
+  for (int i = 0; i < count; ++i) {
+    if (Ns[i] % 128 || Ks[i] % 64) return fail("chain matrix %d: N %% 128 and K %% 64 must be 0", i);
+    append_chain_tiles(st, mats_host[i], Ns[i], Ks[i]);
+  }
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, st.size() * 2));
+  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  *out_dev = d;
+  return 0;
+}
+int ns2vc_k_chain_ab(const void* a_op, int M, int D, const void* wstream, const float* bias1, const float* res, float* y, float eps,
+                     const float* bias2, void* out2_op, int N2, void* stream) {
+  hipError_t e = launch_chain_ab(a_op, M, D, wstream, bias1, res, y, eps, bias2, out2_op, N2, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("chain_ab launch: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,

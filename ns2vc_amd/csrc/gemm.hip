@@ -27,38 +27,13 @@
 // Epilogue: bias, GEGLU (value * gelu_erf(gate)), fp32 residual add, fp32 store
 // (residual stream) and/or operand-typed store (feeds the next GEMM / attention).
 #include "common.h"
+#include "mma.h"
 
 namespace ns2vc {
 
-__device__ uint4 g_zero_page[8];     // 128 B of zeros: source of padded / out-of-range rows
-
-template <typename T> struct MmaT;
-template <> struct MmaT<float> {
-  static constexpr int EPC = 4;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
-  }
-};
-template <> struct MmaT<bf16_t> {
-  static constexpr int EPC = 8;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
-    union U { u32x4_t u; bf16x8_t v; };
-    U ua, ub;
-    ua.u = a; ub.u = b;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
-  }
-};
-
-// direct HBM/L2 -> LDS DMA of 16 B per lane: LDS address = lds_dst (wave-uniform) + lane*16
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+// optional per-workgroup phase timestamps (s_memtime) for tuning: [block][8] uint64, set by ns2vc_debug_set_gemm_trace
+__device__ unsigned long long* g_gemm_trace = nullptr;
+#define NS2VC_STAMP(i) do { if (tr && tid == 0) tr[i] = __builtin_readcyclecounter(); } while (0)
 
 constexpr int TROW = 128;   // bytes of K per tile row (64 bf16 / 32 f32)
 
@@ -77,6 +52,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned long long* tr = g_gemm_trace ? g_gemm_trace + (size_t)blockIdx.x * 8 : nullptr;
+  NS2VC_STAMP(0);
 
   // ---- XCD-aware tile mapping (blocks sharing an activation row-panel sit on one XCD's L2)
   const int nb_n = g.N / BN;
@@ -161,9 +138,11 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / BKE;
+  NS2VC_STAMP(1);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue_tile(s, s);
+  NS2VC_STAMP(2);
 
   const int l31 = lane & 31, hi = lane >> 5;
   // fragment reads: row r = w*W? + i*32 + l31, logical chunk 2*ks+hi stored at chunk ^ ((r>>1)&7);
@@ -178,6 +157,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my ds_reads of the stage about to be refilled are done
     __builtin_amdgcn_s_barrier();
+    if (kt == 0) NS2VC_STAMP(3);
     if (kt + STAGES - 1 < nk) {
       int st2 = stage + STAGES - 1;
       if (st2 >= STAGES) st2 -= STAGES;
@@ -208,6 +188,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   // its tile through its own slice of the (now idle) LDS ring and then moves whole rows: 16-B loads of bias /
   // residual, 16-B fp32 and 8-B bf16 stores, fully coalesced.
   constexpr int EP = WN + 4;                       // LDS pitch in floats (16-B aligned rows)
+  NS2VC_STAMP(4);
   __syncthreads();                                 // every wave is done reading the last K tile
   float* et = reinterpret_cast<float*>(smem) + wave * (WM * EP);
 #pragma unroll
@@ -217,6 +198,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) et[(i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[i][j][r];
   __syncthreads();
+  NS2VC_STAMP(5);
   float* of = g.out_f32;
   TM* oo = reinterpret_cast<TM*>(g.out_op);
   const int mw0 = m0 + wm * WM;
@@ -304,6 +286,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NS2VC_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -324,6 +308,7 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
+void set_gemm_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &p, sizeof(p)); }
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
 void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages; }
 

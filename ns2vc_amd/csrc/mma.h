@@ -1,0 +1,38 @@
+// MFMA / LDS-DMA helpers shared by the GEMM and the fused row-chain kernels (gfx950).
+#pragma once
+#include "common.h"
+
+namespace ns2vc {
+
+static __device__ uint4 g_zero_page[8];     // 128 B of zeros: source of padded / out-of-range rows (one copy per TU)
+
+template <typename T> struct MmaT;
+template <> struct MmaT<float> {
+  static constexpr int EPC = 4;
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct MmaT<bf16_t> {
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    union U { u32x4_t u; bf16x8_t v; };
+    U ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+  }
+};
+
+// direct HBM/L2 -> LDS DMA of 16 B per lane: LDS address = lds_dst (wave-uniform) + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+
+}  // namespace ns2vc

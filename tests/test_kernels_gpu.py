@@ -271,6 +271,49 @@ def test_gemm_heuristic_large(diag):
         assert e < TOL[prec]
 
 
+def _chain_stream(mats):
+    from ns2vc_amd._lib import check
+    arrs = [np.ascontiguousarray(m, dtype=np.float32) for m in mats]
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    Ns = (C.c_int * len(arrs))(*[a.shape[0] for a in arrs])
+    Ks = (C.c_int * len(arrs))(*[a.shape[1] for a in arrs])
+    out = C.c_void_p()
+    check(_lib().ns2vc_pack_chain_stream(ptrs, Ns, Ks, len(arrs), C.byref(out)), "pack_chain_stream")
+    return out
+
+
+@pytest.mark.parametrize("shape", [(130, 128, 384, True), (333, 256, 256, True), (100, 384, 1152, False), (77, 512, 512, True),
+                                   (30016 // 8, 128, 384, False)], ids=str)
+def test_chain_linear_layernorm_linear(shape, diag):
+    """Fused row chain (bf16): y = A W1^T + b1 (+res); out2 = LayerNorm(y) W2^T + b2 — vs float64 numpy on the same
+    bf16-rounded operands.  y is fp32; out2 differs from the reference only by the bf16 rounding of LN(y) and of itself."""
+    from ns2vc_amd._lib import check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    M, D, N2, with_res = shape
+    rng = np.random.default_rng(M + D)
+    a = bf16_round(rng.standard_normal((M, D)).astype(np.float32))
+    W1 = bf16_round((rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32))
+    W2 = bf16_round((rng.standard_normal((N2, D)) / np.sqrt(D)).astype(np.float32))
+    b1, b2 = rng.standard_normal(D).astype(np.float32), rng.standard_normal(N2).astype(np.float32)
+    res = (rng.standard_normal((M, D)) * 1.5 + 0.5).astype(np.float32) if with_res else None
+    y_ref = a.astype(np.float64) @ W1.astype(np.float64).T + b1 + (res if res is not None else 0.0)
+    n = (y_ref - y_ref.mean(-1, keepdims=True)) / np.sqrt(y_ref.var(-1, keepdims=True) + 1e-5)
+    o_ref = bf16_round(n.astype(np.float32)).astype(np.float64) @ W2.astype(np.float64).T + b2
+    ws = _chain_stream([W1, W2])
+    d_a, d_b1, d_b2 = OpBuf(a, 1), _dev(b1), _dev(b2)
+    d_y = DevBuf.from_numpy(res.copy()) if with_res else DevBuf(M * D * 4)      # in place: res aliases y like the engine does
+    d_o = OpBuf(np.full((M, N2), np.nan, np.float32), 1)
+    check(lib.ns2vc_k_chain_ab(d_a.ptr, M, D, ws, d_b1.ptr, d_y.ptr if with_res else None, d_y.ptr, 1e-5, d_b2.ptr, d_o.ptr, N2, None), "chain_ab")
+    sync()
+    y = d_y.to_numpy((M, D))
+    o = d_o.read()
+    e_y, e_o = rel_l2(y, y_ref), rel_l2(o, o_ref)
+    diag(f"chain_ab {shape}: y {e_y:.3e} out2 {e_o:.3e}")
+    assert e_y < 2e-6 and e_o < 6e-3
+    lib.ns2vc_dev_free(ws)
+
+
 # ---------------------------------------------------------------------------------------
 def ref_attention(q, k, v, bias, H, prec):
     B, Lq, D = q.shape
