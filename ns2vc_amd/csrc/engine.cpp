@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <memory>
@@ -115,7 +116,10 @@ struct ns2vc_unet {
   size_t arena_bytes = 0, arena_used = 0;
   std::vector<Op> cond_ops, fwd_ops;
   bool debug = false;
-  bool use_chains = true;     // bf16: fused row-chain kernels for the transformer linears
+  // bf16: fused row-chain kernels for the transformer linears (csrc/chain.hip).  Correct, but measured SLOWER than
+  // the separate launches on MI355X (5.74-6.09 vs 5.61 ms/step, profiles/chain_ab_r01.txt): one workgroup per CU
+  // serialises 4-5 dependent global round trips.  Off unless NS2VC_USE_CHAINS=1.
+  bool use_chains = false;
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -1007,6 +1011,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (e != hipSuccess) return fail("kernel attribute setup failed: %s (is a gfx950 GPU visible?)", hipGetErrorString(e));
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
+  if (const char* e = getenv("NS2VC_USE_CHAINS")) h->use_chains = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;

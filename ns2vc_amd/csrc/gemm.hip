@@ -37,6 +37,124 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 
 constexpr int TROW = 128;   // bytes of K per tile row (64 bf16 / 32 f32)
 
+// ---------------------------------------------------------------------------
+// shared epilogue (bias, GEGLU, residual, fp32 / operand stores, GroupNorm statistics)
+// ---------------------------------------------------------------------------
+template <typename TM, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)[BM / 64][BN / 64], char* smem, int m0, int n0, int tid,
+                                              unsigned long long* tr) {
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), i.e. a lane
+  // owns ONE column: direct stores would be 4-byte (fp32) / 2-byte (bf16) scalars.  Instead every wave transposes
+  // its tile through its own slice of the (now idle) LDS ring and then moves whole rows: 16-B loads of bias /
+  // residual, 16-B fp32 and 8-B bf16 stores, fully coalesced.
+  constexpr int EP = WN + 4;                       // LDS pitch in floats (16-B aligned rows)
+  NS2VC_STAMP(4);
+  __syncthreads();                                 // every wave is done reading the last K tile
+  float* et = reinterpret_cast<float*>(smem) + wave * (WM * EP);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et[(i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  NS2VC_STAMP(5);
+  float* of = g.out_f32;
+  TM* oo = reinterpret_cast<TM*>(g.out_op);
+  const int mw0 = m0 + wm * WM;
+  if (g.geglu) {
+    if constexpr (NT == 2) {
+      constexpr int LPR = 8, RPI = 8, NIT = WM / RPI;          // 32 output columns per row = 8 lanes x 4
+      const int rsub = lane >> 3, cq = lane & 7;
+      const int pcol = n0 + wn * WN + cq * 4;                  // packed column of the value quad; gate quad = +32
+      const int ocol = ((n0 + wn * WN) >> 1) + cq * 4;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+      if (g.bias) { bv = *reinterpret_cast<const float4*>(g.bias + pcol); bg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = it * RPI + rsub, m = mw0 + row;
+        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        const float4 t = *reinterpret_cast<const float4*>(et + row * EP + 32 + cq * 4);
+        if (m < g.M) {
+          float4 v;
+          v.x = (a.x + bv.x) * gelu_erf_f(t.x + bg.x); v.y = (a.y + bv.y) * gelu_erf_f(t.y + bg.y);
+          v.z = (a.z + bv.z) * gelu_erf_f(t.z + bg.z); v.w = (a.w + bv.w) * gelu_erf_f(t.w + bg.w);
+          if (g.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
+        }
+      }
+      (void)LPR;
+    }
+  } else {
+    constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;
+    const int rsub = lane / LPR, cq = lane % LPR;
+    const int ncol = n0 + wn * WN + cq * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+    // optional GroupNorm statistics of the result: this wave's rows belong to batch b0 or b0+1 (Tout >= WM)
+    const int b0 = min(mw0, g.M - 1) / g.Tout;
+    const int mB = (b0 + 1) * g.Tout;                          // first row of the next batch item
+    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+    constexpr int RB = NIT < 8 ? NIT : 8;                      // residual rows fetched per batch (before any store:
+#pragma unroll                                                 //  res may alias out_f32 element-for-element)
+    for (int it0 = 0; it0 < NIT; it0 += RB) {
+      float4 rr[RB];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int m = mw0 + (it0 + k) * RPI + rsub;
+        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < RB; ++k) {
+        const int row = (it0 + k) * RPI + rsub, m = mw0 + row;
+        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        if (m < g.M) {
+          float4 v;
+          v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
+          const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
+        }
+      }
+    }
+    if (g.stats) {
+      // fixed shuffle tree over the lanes that share a 16-channel block (4 column quads x all row lanes),
+      // then ONE int64 fixed-point atomic per (batch item, block, moment): order-independent => deterministic
+      double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {                       // the 4 column quads of a 16-channel block
+        d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {                     // the row lanes
+        d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+      }
+      if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
+        const int blk = ncol >> 4, nblk = g.N >> 4;
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
+        atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
+        atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
+        if (mB < g.M && mB < mw0 + WM) {
+          atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
+          atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NS2VC_STAMP(6);
+}
+
 template <typename TM, int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   constexpr int EPC = MmaT<TM>::EPC;
@@ -182,112 +300,164 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     }
     if (++stage == STAGES) stage = 0;
   }
+  gemm_epilogue<TM, BM, BN>(g, acc, smem, m0, n0, tid, tr);
+}
 
-  // ---- epilogue.  C layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5), i.e. a lane
-  // owns ONE column: direct stores would be 4-byte (fp32) / 2-byte (bf16) scalars.  Instead every wave transposes
-  // its tile through its own slice of the (now idle) LDS ring and then moves whole rows: 16-B loads of bias /
-  // residual, 16-B fp32 and 8-B bf16 stores, fully coalesced.
-  constexpr int EP = WN + 4;                       // LDS pitch in floats (16-B aligned rows)
-  NS2VC_STAMP(4);
-  __syncthreads();                                 // every wave is done reading the last K tile
-  float* et = reinterpret_cast<float*>(smem) + wave * (WM * EP);
+// ---------------------------------------------------------------------------
+// Register-staged variant.  Measured on MI355X (tools/gemm_trace.py): one global_load_lds costs a wave ~100-170
+// issue cycles per KB, and with the small tiles this workload allows (64x128: 6 DMA pieces per 8 MFMAs) the
+// K loop of gemm2_kernel is DMA-ISSUE-bound (~1600 cycles per K tile for 256 cycles of MFMA).  A plain
+// global_load_dwordx4 + ds_write_b128 moves the same KB for ~20 issue cycles, so here the operands go
+// HBM/L2 -> VGPR -> LDS: two LDS stages, two register sets (tiles kt+1 and kt+2 in flight while tile kt is
+// multiplied), swizzle applied on the LDS write address (global reads stay perfectly coalesced: 8 lanes = one
+// 128-B row), one __syncthreads per K tile.  hipcc counts vmcnt for ordinary loads itself.
+// ---------------------------------------------------------------------------
+template <typename TM, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
+  constexpr int EPC = MmaT<TM>::EPC;
+  constexpr int BKE = 8 * EPC;
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  constexpr int LA = BM / 32, LB = BN / 32;
+  constexpr int STAGE = (BM + BN) * TROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  unsigned long long* tr = g_gemm_trace ? g_gemm_trace + (size_t)blockIdx.x * 8 : nullptr;
+  NS2VC_STAMP(0);
+
+  const int nb_n = g.N / BN;
+  const int nb_m = (g.M + BM - 1) / BM;
+  const int nwg = nb_n * nb_m;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tm = swz / nb_n;
+    tn = swz - tm * nb_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int prow = tid >> 3, pchunk = tid & 7;
+  const int Ctot = g.c0 + g.c1;
+  const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
+  const int toff = g.taps >> 1;
+  const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
+  const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
+  int rt0[LA], rt1[LA], rt2[LA];
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int m = m0 + j * 32 + prow;
+    const bool mok = m < g.M;
+    const int b = mok ? m / g.Tout : 0;
+    const int t = m - b * g.Tout;
+    auto src_row = [&](int tp) __attribute__((always_inline)) {
+      const int u = t * smul + tp - toff;
+      const bool ok = mok && (tp < g.taps) && (u >= 0) && (u < ulim);
+      return ok ? b * g.Tin + min(u >> ushr, g.Tin - 1) : -1;
+    };
+    rt0[j] = src_row(0); rt1[j] = src_row(1); rt2[j] = src_row(2);
+  }
+  const TM* wrow[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) wrow[j] = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + j * 32 + prow) * g.K + pchunk * EPC);
+  const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
+  // LDS byte offset of this thread's piece inside a tile pass (row prow of the pass, swizzled chunk position)
+  int woff[LA > LB ? LA : LB];
+#pragma unroll
+  for (int j = 0; j < (LA > LB ? LA : LB); ++j) {
+    const int row = j * 32 + prow;
+    woff[j] = row * TROW + ((pchunk ^ ((row >> 1) & 7)) << 4);
+  }
+  const int K1 = g.taps * Ctot;
+
+  auto load_tile = [&](int kt, u32x4_t (&ra)[LA], u32x4_t (&rb)[LB]) __attribute__((always_inline)) {
+    const int k0 = kt * BKE;
+    const bool seg2 = k0 >= K1;
+    const int k1 = seg2 ? 0 : k0;
+    const int tapq = k1 / Ctot;
+    const int tap = seg2 ? toff : tapq;
+    const int cc = k1 - tapq * Ctot;
+    const bool first = cc < g.c0;
+    const unsigned long long src = reinterpret_cast<unsigned long long>(seg2 ? g.a2 : (first ? g.a0 : g.a1));
+    const int ld = seg2 ? g.lda2 : (first ? g.lda0 : g.lda1);
+    const int csrc = (seg2 ? k0 - K1 : (first ? cc : cc - g.c0)) + pchunk * EPC;
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const int r = tap == 0 ? rt0[j] : (tap == 1 ? rt1[j] : rt2[j]);
+      const unsigned eoff = (unsigned)max(r, 0) * (unsigned)ld + (unsigned)csrc;
+      const unsigned long long pa = src + (unsigned long long)eoff * sizeof(TM);
+      ra[j] = *reinterpret_cast<const u32x4_t*>(r >= 0 ? pa : zero);
+    }
+#pragma unroll
+    for (int j = 0; j < LB; ++j) rb[j] = *reinterpret_cast<const u32x4_t*>(wrow[j] + k0);
+  };
+  auto store_tile = [&](int stage, const u32x4_t (&ra)[LA], const u32x4_t (&rb)[LB]) __attribute__((always_inline)) {
+    char* As = smem + stage * STAGE;
+    char* Bs = As + BM * TROW;
+#pragma unroll
+    for (int j = 0; j < LA; ++j) *reinterpret_cast<u32x4_t*>(As + woff[j]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < LB; ++j) *reinterpret_cast<u32x4_t*>(Bs + woff[j]) = rb[j];
+  };
+
+  f32x16_t acc[MT][NT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) et[(i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int sw = (l31 >> 1) & 7;
+  auto compute = [&](int stage) __attribute__((always_inline)) {
+    const char* As = smem + stage * STAGE;
+    const char* Bs = As + BM * TROW;
+    const char* ap = As + (wm * WM + l31) * TROW;
+    const char* bp = Bs + (wn * WN + l31) * TROW;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((2 * ks + hi) ^ sw) * 16;
+      u32x4_t af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
+    }
+  };
+
+  const int nk = g.K / BKE;
+  u32x4_t a0[LA], b0[LB], a1[LA], b1[LB];      // two register sets: tiles kt+1 and kt+2 in flight
+  NS2VC_STAMP(1);
+  load_tile(0, a0, b0);
+  if (nk > 1) load_tile(1, a1, b1);
+  NS2VC_STAMP(2);
+  store_tile(0, a0, b0);
   __syncthreads();
-  NS2VC_STAMP(5);
-  float* of = g.out_f32;
-  TM* oo = reinterpret_cast<TM*>(g.out_op);
-  const int mw0 = m0 + wm * WM;
-  if (g.geglu) {
-    if constexpr (NT == 2) {
-      constexpr int LPR = 8, RPI = 8, NIT = WM / RPI;          // 32 output columns per row = 8 lanes x 4
-      const int rsub = lane >> 3, cq = lane & 7;
-      const int pcol = n0 + wn * WN + cq * 4;                  // packed column of the value quad; gate quad = +32
-      const int ocol = ((n0 + wn * WN) >> 1) + cq * 4;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
-      if (g.bias) { bv = *reinterpret_cast<const float4*>(g.bias + pcol); bg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int row = it * RPI + rsub, m = mw0 + row;
-        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
-        const float4 t = *reinterpret_cast<const float4*>(et + row * EP + 32 + cq * 4);
-        if (m < g.M) {
-          float4 v;
-          v.x = (a.x + bv.x) * gelu_erf_f(t.x + bg.x); v.y = (a.y + bv.y) * gelu_erf_f(t.y + bg.y);
-          v.z = (a.z + bv.z) * gelu_erf_f(t.z + bg.z); v.w = (a.w + bv.w) * gelu_erf_f(t.w + bg.w);
-          if (g.res) {
-            const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          }
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
-        }
-      }
-      (void)LPR;
-    }
-  } else {
-    constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;
-    const int rsub = lane / LPR, cq = lane % LPR;
-    const int ncol = n0 + wn * WN + cq * 4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
-    // optional GroupNorm statistics of the result: this wave's rows belong to batch b0 or b0+1 (Tout >= WM)
-    const int b0 = min(mw0, g.M - 1) / g.Tout;
-    const int mB = (b0 + 1) * g.Tout;                          // first row of the next batch item
-    float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
-    constexpr int RB = NIT < 8 ? NIT : 8;                      // residual rows fetched per batch (before any store:
-#pragma unroll                                                 //  res may alias out_f32 element-for-element)
-    for (int it0 = 0; it0 < NIT; it0 += RB) {
-      float4 rr[RB];
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int m = mw0 + (it0 + k) * RPI + rsub;
-        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int k = 0; k < RB; ++k) {
-        const int row = (it0 + k) * RPI + rsub, m = mw0 + row;
-        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
-        if (m < g.M) {
-          float4 v;
-          v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
-          const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-          if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
-        }
-      }
-    }
-    if (g.stats) {
-      // fixed shuffle tree over the lanes that share a 16-channel block (4 column quads x all row lanes),
-      // then ONE int64 fixed-point atomic per (batch item, block, moment): order-independent => deterministic
-      double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
-#pragma unroll
-      for (int o = 1; o <= 2; o <<= 1) {                       // the 4 column quads of a 16-channel block
-        d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
-      }
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {                     // the row lanes
-        d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
-      }
-      if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
-        const int blk = ncol >> 4, nblk = g.N >> 4;
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
-        atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
-        atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
-        if (mB < g.M && mB < mw0 + WM) {
-          atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
-          atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
-        }
-      }
-    }
+  NS2VC_STAMP(3);
+  // steady state, unrolled by two so the register sets are named statically
+  int kt = 0;
+  for (; kt + 2 <= nk; kt += 2) {
+    if (kt + 2 < nk) load_tile(kt + 2, a0, b0);
+    compute(0);
+    if (kt + 1 < nk) store_tile(1, a1, b1);
+    __syncthreads();
+    if (kt + 3 < nk) load_tile(kt + 3, a1, b1);
+    compute(1);
+    if (kt + 2 < nk) store_tile(0, a0, b0);
+    __syncthreads();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  NS2VC_STAMP(6);
+  if (kt < nk) compute(0);                     // odd tail: tile nk-1 sits in stage 0
+  NS2VC_STAMP(4);
+  gemm_epilogue<TM, BM, BN>(g, acc, smem, m0, n0, tid, tr);
 }
 
 // ---------------------------------------------------------------------------
@@ -309,6 +479,14 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
 }
 
 void set_gemm_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &p, sizeof(p)); }
+template <typename TM, int BM, int BN>
+static hipError_t launch_cfg3(const GemmArgs& g, hipStream_t s) {
+  const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
+  const size_t lds = gemm_lds_bytes(BM, BN, 2);
+  hipLaunchKernelGGL((gemm3_kernel<TM, BM, BN>), dim3(nb), dim3(256), lds, s, g);
+  return hipGetLastError();
+}
+
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
 void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages; }
 
@@ -335,6 +513,13 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
     } else {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
+  }
+  if (st == 1) {     // register-staged kernel (ring depth is fixed: 2 LDS stages + 2 register sets)
+    if (bm == 128 && bn == 128) return launch_cfg3<TM, 128, 128>(g, s);
+    if (bm == 64 && bn == 128) return launch_cfg3<TM, 64, 128>(g, s);
+    if (bm == 128 && bn == 64) return launch_cfg3<TM, 128, 64>(g, s);
+    if (bm == 64 && bn == 64) return launch_cfg3<TM, 64, 64>(g, s);
+    return hipErrorInvalidValue;
   }
 #define NS2VC_CASE(BM_, BN_, ST_) if (bm == BM_ && bn == BN_ && st == ST_) return launch_cfg<TM, BM_, BN_, ST_>(g, s)
   NS2VC_CASE(128, 128, 2); NS2VC_CASE(128, 128, 3);
@@ -369,7 +554,14 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
   } while (0)
 
 #define NS2VC_SET_BOTH(BM, BN, ST) NS2VC_SET(float, BM, BN, ST); NS2VC_SET(bf16_t, BM, BN, ST)
+#define NS2VC_SET3(TM, BM, BN)                                                                                  \
+  do {                                                                                                          \
+    hipError_t e = set_lds(gemm3_kernel<TM, BM, BN>, gemm_lds_bytes(BM, BN, 2));                                \
+    if (e != hipSuccess) return e;                                                                              \
+  } while (0)
 hipError_t init_gemm_attributes() {
+  NS2VC_SET3(float, 128, 128); NS2VC_SET3(float, 64, 128); NS2VC_SET3(float, 128, 64); NS2VC_SET3(float, 64, 64);
+  NS2VC_SET3(bf16_t, 128, 128); NS2VC_SET3(bf16_t, 64, 128); NS2VC_SET3(bf16_t, 128, 64); NS2VC_SET3(bf16_t, 64, 64);
   NS2VC_SET_BOTH(128, 128, 2); NS2VC_SET_BOTH(128, 128, 3);
   NS2VC_SET_BOTH(64, 128, 2); NS2VC_SET_BOTH(64, 128, 3); NS2VC_SET_BOTH(64, 128, 4);
   NS2VC_SET_BOTH(128, 64, 2); NS2VC_SET_BOTH(128, 64, 3); NS2VC_SET_BOTH(128, 64, 4);

@@ -20,7 +20,8 @@ from ns2vc_amd import _lib                     # noqa: E402
 from ns2vc_amd._lib import GemmArgs, check     # noqa: E402
 from ns2vc_amd.engine import DevBuf, Event, Stream  # noqa: E402
 
-CONFIGS = [(128, 128, 2), (128, 128, 3), (64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 64, 2), (128, 64, 3), (128, 64, 4),
+# stages == 1 selects the register-staged kernel (gemm3_kernel); 2..4 = global_load_lds ring depth (gemm2_kernel)
+CONFIGS = [(128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 2), (64, 128, 2), (64, 128, 3), (128, 64, 2),
            (64, 64, 2), (64, 64, 3), (64, 64, 4)]
 
 
