@@ -32,8 +32,18 @@
 namespace ns2vc {
 
 // optional per-workgroup phase timestamps (s_memtime) for tuning: [block][8] uint64, set by ns2vc_debug_set_gemm_trace
+// (compiled in only with -DNS2VC_GEMM_TRACE=1: `make TRACE=1`; the stamps cost a few % otherwise)
 __device__ unsigned long long* g_gemm_trace = nullptr;
+#ifndef NS2VC_GEMM_TRACE
+#define NS2VC_GEMM_TRACE 0
+#endif
+#if NS2VC_GEMM_TRACE
 #define NS2VC_STAMP(i) do { if (tr && tid == 0) tr[i] = __builtin_readcyclecounter(); } while (0)
+#define NS2VC_TRACE_PTR() (g_gemm_trace ? g_gemm_trace + (size_t)blockIdx.x * 8 : nullptr)
+#else
+#define NS2VC_STAMP(i) do { (void)tr; } while (0)
+#define NS2VC_TRACE_PTR() nullptr
+#endif
 
 constexpr int TROW = 128;   // bytes of K per tile row (64 bf16 / 32 f32)
 
@@ -156,7 +166,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
 }
 
 template <typename TM, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int flags) {
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const unsigned lds0 = (unsigned)(size_t)smem;
-  unsigned long long* tr = g_gemm_trace ? g_gemm_trace + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* tr = NS2VC_TRACE_PTR();
   NS2VC_STAMP(0);
 
   // ---- XCD-aware tile mapping (blocks sharing an activation row-panel sit on one XCD's L2)
@@ -256,10 +266,14 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = g.K / BKE;
+  // experiment (flags bit 0): every row-panel starts its K loop at a different tile, so the workgroups of one
+  // column do not all pull the same weight lines from L2 at the same moment
+  const int rot = (flags & 1) ? tm % nk : 0;
+  auto ktile = [&](int kt) __attribute__((always_inline)) { const int kk = kt + rot; return kk >= nk ? kk - nk : kk; };
   NS2VC_STAMP(1);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_tile(s, s);
+    if (s < nk) issue_tile(ktile(s), s);
   NS2VC_STAMP(2);
 
   const int l31 = lane & 31, hi = lane >> 5;
@@ -276,11 +290,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my ds_reads of the stage about to be refilled are done
     __builtin_amdgcn_s_barrier();
     if (kt == 0) NS2VC_STAMP(3);
-    if (kt + STAGES - 1 < nk) {
+    if (kt + STAGES - 1 < nk && !(flags & 4)) {      // (flags bit 2: ablation, no steady-state loads)
       int st2 = stage + STAGES - 1;
       if (st2 >= STAGES) st2 -= STAGES;
-      issue_tile(kt + STAGES - 1, st2);
+      issue_tile(ktile(kt + STAGES - 1), st2);
     }
+    if (flags & 2) { if (++stage == STAGES) stage = 0; continue; }   // (flags bit 1: ablation, loads only)
     const char* As = smem + stage * STAGE;
     const char* Bs = As + BM * TROW;
     const char* ap = As + (wm * WM + l31) * TROW;
@@ -325,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  unsigned long long* tr = g_gemm_trace ? g_gemm_trace + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* tr = NS2VC_TRACE_PTR();
   NS2VC_STAMP(0);
 
   const int nb_n = g.N / BN;
@@ -461,6 +476,271 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
+// 8-wave variant with an intra-workgroup K split.
+//
+// tools/dma_probe.hip (profiles/dma_probe_r01_*.txt) measured what feeds a CU on MI355X: one wave lands one 1-KB
+// LDS-DMA piece per ~117 cycles however many it has in flight (4 waves: 35 B/clk/CU, 8 waves: 55-63 B/clk/CU = the L2
+// peak), a 2-deep ring stalls for a full L2 round trip per K tile (3-deep streams continuously), and anything that
+// misses the XCD's L2 arrives at <= 15 B/clk/CU.  The ablation runs of gemm2_kernel (tools/gemm_sweep.py --ablate) showed
+// its K loop to be load-stream-bound at 17-23 B/clk/CU with the LDS fragment reads (1.5 KB per MFMA for a 32x64 wave
+// tile) as the second limit.  This kernel is shaped by those numbers:
+//   * 512 threads: waves 0-3 and 4-7 own the SAME 2x2 grid of 64x64 (or 32x64) wave tiles but opposite halves of every
+//     64-wide K tile (ks 0,1 / ks 2,3), so a wave issues half the DMA pieces (3-4 per tile instead of 6-8), eight
+//     waves keep the CU's load path full, and fragment reads drop to 0.5-0.75 KB per MFMA;
+//   * BM x 128 tiles with BM = 128 where the grid still covers the chip (one workgroup per CU) and 64 otherwise;
+//   * 3-deep ring by default: the DMA queue never drains between K tiles;
+//   * the two K halves meet in the epilogue: both stage their accumulators in LDS (32-row slabs, re-using the ring),
+//     then all eight waves add the pair while they transpose rows out -- every wave stores, nothing idles.
+// ---------------------------------------------------------------------------
+template <typename TM, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
+  constexpr int EPC = MmaT<TM>::EPC;
+  constexpr int BKE = 8 * EPC;
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
+  constexpr int LA = BM / 64, LB = BN / 64, LPT = LA + LB;     // 16-B DMA pieces per thread per tile (64 rows per pass)
+  constexpr int STAGE = (BM + BN) * TROW;
+  static_assert(BN == 128 && NT == 2, "wave tile is (BM/2) x 64");
+  static_assert(LPT * (STAGES - 1) < 60, "vmcnt range");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, wq = wave & 3;         // K half, wave tile
+  const int wm = wq >> 1, wn = wq & 1;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned long long* tr = NS2VC_TRACE_PTR();
+  NS2VC_STAMP(0);
+
+  const int nb_n = g.N / BN;
+  const int nb_m = (g.M + BM - 1) / BM;
+  const int nwg = nb_n * nb_m;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tm = swz / nb_n;
+    tn = swz - tm * nb_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA coordinates: piece j of this thread = tile row j*64 + tid/8, physical 16-B chunk tid%8
+  const int prow = tid >> 3, pchunk = tid & 7;
+  const int Ctot = g.c0 + g.c1;
+  const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
+  const int toff = g.taps >> 1;
+  const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
+  const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
+  int rt0[LA], rt1[LA], rt2[LA];
+  const int acol = (pchunk ^ ((prow >> 1) & 7)) * EPC;          // source-side swizzle (row j*64+prow: same (row>>1)&7)
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int m = m0 + j * 64 + prow;
+    const bool mok = m < g.M;
+    const int b = mok ? m / g.Tout : 0;
+    const int t = m - b * g.Tout;
+    auto src_row = [&](int tp) __attribute__((always_inline)) {
+      const int u = t * smul + tp - toff;
+      const bool ok = mok && (tp < g.taps) && (u >= 0) && (u < ulim);
+      return ok ? b * g.Tin + min(u >> ushr, g.Tin - 1) : -1;
+    };
+    rt0[j] = src_row(0); rt1[j] = src_row(1); rt2[j] = src_row(2);
+  }
+  const TM* wrow[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) wrow[j] = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + j * 64 + prow) * g.K + acol);
+  const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
+
+  const int K1 = g.taps * Ctot;
+  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
+    const int k0 = kt * BKE;
+    const bool seg2 = k0 >= K1;
+    const int k1 = seg2 ? 0 : k0;
+    const int tapq = k1 / Ctot;
+    const int tap = seg2 ? toff : tapq;
+    const int cc = k1 - tapq * Ctot;
+    const bool first = cc < g.c0;
+    const unsigned long long src = reinterpret_cast<unsigned long long>(seg2 ? g.a2 : (first ? g.a0 : g.a1));
+    const int ld = seg2 ? g.lda2 : (first ? g.lda0 : g.lda1);
+    const int csrc = (seg2 ? k0 - K1 : (first ? cc : cc - g.c0)) + acol;
+    const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+      const int r = tap == 0 ? rt0[j] : (tap == 1 ? rt1[j] : rt2[j]);
+      const unsigned eoff = (unsigned)max(r, 0) * (unsigned)ld + (unsigned)csrc;
+      const unsigned long long pa = src + (unsigned long long)eoff * sizeof(TM);
+      glds16(reinterpret_cast<const void*>(r >= 0 ? pa : zero), sbase + j * 8192);
+    }
+    const unsigned bbase = sbase + BM * TROW;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) glds16(wrow[j] + k0, bbase + j * 8192);
+  };
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / BKE;
+  NS2VC_STAMP(1);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue_tile(s, s);
+  NS2VC_STAMP(2);
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int sw = (l31 >> 1) & 7;
+  int stage = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int after = min(STAGES - 2, nk - 1 - kt);
+    if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
+    else if (STAGES >= 3 && after >= 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt == 0) NS2VC_STAMP(3);
+    auto refill = [&]() __attribute__((always_inline)) {
+      if (kt + STAGES - 1 < nk) {
+        int st2 = stage + STAGES - 1;
+        if (st2 >= STAGES) st2 -= STAGES;
+        issue_tile(kt + STAGES - 1, st2);
+      }
+    };
+    auto multiply = [&]() __attribute__((always_inline)) {
+      const char* As = smem + stage * STAGE;
+      const char* Bs = As + BM * TROW;
+      const char* ap = As + (wm * WM + l31) * TROW;
+      const char* bp = Bs + (wn * WN + l31) * TROW;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((2 * (2 * kg + kk) + hi) ^ sw) * 16;       // this K half's two 32-B k-slabs
+        u32x4_t af[MT], bf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
+      }
+    };
+    // The two K halves run the step in opposite order, so the CU's load path and its MFMA pipes are both busy all
+    // the time instead of alternating (the refill target, the stage of tile kt-1, is free for everyone after the barrier).
+    if (kg == 0) { refill(); multiply(); } else { multiply(); refill(); }
+    if (++stage == STAGES) stage = 0;
+  }
+
+  NS2VC_STAMP(4);
+  // ---- epilogue: per 32-row slab, both K halves stage their partial tile, then each of the eight waves adds the
+  // pair for 16 rows and moves whole rows out (16-B fp32 / 8-B bf16 stores, coalesced)
+  constexpr int EP = WN + 4;                        // staging pitch in floats
+  constexpr int SLAB = 32 * EP;                     // floats per staged 32 x 64 slab
+  float* const et_mine = reinterpret_cast<float*>(smem) + wave * SLAB;
+  const float* const et_a = reinterpret_cast<const float*>(smem) + wq * SLAB + kg * 16 * EP;        // K half 0, my 16 rows
+  const float* const et_b = et_a + 4 * SLAB;                                                          // K half 1
+  float* of = g.out_f32;
+  TM* oo = reinterpret_cast<TM*>(g.out_op);
+  const int mw0 = m0 + wm * WM;                     // first row of the wave tile (both K halves)
+  const int b0 = min(mw0, g.M - 1) / g.Tout;
+  const int mB = (b0 + 1) * g.Tout;
+  float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+  constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = 16 / RPI;    // 16 lanes per row, 4 rows per pass, 4 passes
+  const int rsub = lane / LPR, cq = lane % LPR;
+  const int ncol = n0 + wn * WN + cq * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && !g.geglu) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+  // GEGLU: 32 output columns per row = 8 lanes x 4, 8 rows per pass
+  const int grsub = lane >> 3, gcq = lane & 7;
+  const int pcol = n0 + wn * WN + gcq * 4;          // packed column of the value quad; gate quad = +32
+  const int ocol = ((n0 + wn * WN) >> 1) + gcq * 4;
+  float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f), gbg = gbv;
+  if (g.bias && g.geglu) { gbv = *reinterpret_cast<const float4*>(g.bias + pcol); gbg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    __syncthreads();                                // ring (or the previous slab) is free
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et_mine[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
+    __syncthreads();
+    if (mt == 0) NS2VC_STAMP(5);
+    const int mrow0 = mw0 + mt * 32 + kg * 16;      // first of my 16 rows
+    if (g.geglu) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + grsub, m = mrow0 + row;
+        const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + gcq * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + gcq * 4);
+        const float4 t0 = *reinterpret_cast<const float4*>(et_a + row * EP + 32 + gcq * 4);
+        const float4 t1 = *reinterpret_cast<const float4*>(et_b + row * EP + 32 + gcq * 4);
+        if (m < g.M) {
+          float4 v;
+          v.x = (a0.x + a1.x + gbv.x) * gelu_erf_f(t0.x + t1.x + gbg.x); v.y = (a0.y + a1.y + gbv.y) * gelu_erf_f(t0.y + t1.y + gbg.y);
+          v.z = (a0.z + a1.z + gbv.z) * gelu_erf_f(t0.z + t1.z + gbg.z); v.w = (a0.w + a1.w + gbv.w) * gelu_erf_f(t0.w + t1.w + gbg.w);
+          if (g.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
+        }
+      }
+    } else {
+      float4 rr[NIT];                               // residual rows first (res may alias out_f32 element-for-element)
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int m = mrow0 + k * RPI + rsub;
+        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int row = k * RPI + rsub, m = mrow0 + row;
+        const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + cq * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + cq * 4);
+        if (m < g.M) {
+          float4 v;
+          v.x = (a0.x + a1.x) + bv.x + rr[k].x; v.y = (a0.y + a1.y) + bv.y + rr[k].y;
+          v.z = (a0.z + a1.z) + bv.z + rr[k].z; v.w = (a0.w + a1.w) + bv.w + rr[k].w;
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
+          const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
+        }
+      }
+    }
+  }
+  if (g.stats) {
+    double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+    }
+    if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
+      const int blk = ncol >> 4, nblk = g.N >> 4;
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
+      atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
+      atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
+      if (mB < g.M && mB < mw0 + WM) {
+        atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
+        atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NS2VC_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 // LDS = max(STAGES-deep operand ring, the epilogue's per-wave transpose tiles)
@@ -470,11 +750,12 @@ static constexpr size_t gemm_lds_bytes(int bm, int bn, int stages) {
   return ring > epi ? ring : epi;
 }
 
+static int g_gemm_flags = 0;
 template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
   const size_t lds = gemm_lds_bytes(BM, BN, STAGES);
-  hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(256), lds, s, g);
+  hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(256), lds, s, g, g_gemm_flags);
   return hipGetLastError();
 }
 
@@ -487,8 +768,20 @@ static hipError_t launch_cfg3(const GemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
+static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
+  const size_t ring = (size_t)stages * (bm + bn) * TROW;
+  const size_t epi = (size_t)8 * 32 * (bn / 2 + 4) * 4;
+  return ring > epi ? ring : epi;
+}
+template <typename TM, int BM, int BN, int STAGES>
+static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
+  const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
+  hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  return hipGetLastError();
+}
+
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
-void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages; }
+void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
 template <typename TM>
 static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
@@ -508,11 +801,23 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
     if (g.geglu) {
       if (!n128) return hipErrorInvalidValue;
       bm = 64; bn = 128; st = 2;
+    } else if (n128 && g.N <= 512 && !(g.N == 384 && nk <= 6)) {
+      // narrow outputs (every conv and the to_out / proj / ff-out linears): the 8-wave K-split kernel, 3-deep ring.
+      // Equal or a few % ahead at levels 0-2 and 20-25 % ahead at level 3 (profiles/gemm_sweep_r01c_ksplit.txt)
+      bm = 64; bn = 128; st = 13;
     } else if (n128 && (g.M >= 12000 || g.N >= 1024)) {
       bm = 64; bn = 128; st = nk >= 24 ? 3 : 2;
     } else {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
+  }
+  if (st >= 12 && st <= 14) {   // 8-wave K-split kernel, ring depth st - 10
+    if (bn != 128) return hipErrorInvalidValue;
+#define NS2VC_CASE4(BM_, ST_) if (bm == BM_ && st == 10 + ST_) return launch_cfg4<TM, BM_, 128, ST_>(g, s)
+    NS2VC_CASE4(128, 2); NS2VC_CASE4(128, 3); NS2VC_CASE4(128, 4);
+    NS2VC_CASE4(64, 2); NS2VC_CASE4(64, 3); NS2VC_CASE4(64, 4);
+#undef NS2VC_CASE4
+    return hipErrorInvalidValue;
   }
   if (st == 1) {     // register-staged kernel (ring depth is fixed: 2 LDS stages + 2 register sets)
     if (bm == 128 && bn == 128) return launch_cfg3<TM, 128, 128>(g, s);
@@ -559,7 +864,16 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
     hipError_t e = set_lds(gemm3_kernel<TM, BM, BN>, gemm_lds_bytes(BM, BN, 2));                                \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
+#define NS2VC_SET4(TM, BM, ST)                                                                                  \
+  do {                                                                                                          \
+    hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST>, gemm4_lds_bytes(BM, 128, ST));                        \
+    if (e != hipSuccess) return e;                                                                              \
+  } while (0)
 hipError_t init_gemm_attributes() {
+  NS2VC_SET4(float, 128, 2); NS2VC_SET4(float, 128, 3); NS2VC_SET4(float, 128, 4);
+  NS2VC_SET4(float, 64, 2); NS2VC_SET4(float, 64, 3); NS2VC_SET4(float, 64, 4);
+  NS2VC_SET4(bf16_t, 128, 2); NS2VC_SET4(bf16_t, 128, 3); NS2VC_SET4(bf16_t, 128, 4);
+  NS2VC_SET4(bf16_t, 64, 2); NS2VC_SET4(bf16_t, 64, 3); NS2VC_SET4(bf16_t, 64, 4);
   NS2VC_SET3(float, 128, 128); NS2VC_SET3(float, 64, 128); NS2VC_SET3(float, 128, 64); NS2VC_SET3(float, 64, 64);
   NS2VC_SET3(bf16_t, 128, 128); NS2VC_SET3(bf16_t, 64, 128); NS2VC_SET3(bf16_t, 128, 64); NS2VC_SET3(bf16_t, 64, 64);
   NS2VC_SET_BOTH(128, 128, 2); NS2VC_SET_BOTH(128, 128, 3);

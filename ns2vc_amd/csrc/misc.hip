@@ -83,6 +83,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   __shared__ float s_mean[8], s_rstd[8];
   const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
   const int C = c0 + c1, nq = C >> 2, Cg = C / G;
+  // streaming coordinates first: the activation loads do not depend on the statistics, so the first batch is in
+  // flight while the block finalises mean / rstd (a chain of dependent global loads, shuffles and a double sqrt)
+  const int rl = max(1, 256 / nq);
+  const int quad = tid % nq, rlane = tid / nq;
+  const bool active = rlane < rl;
+  const int c = quad * 4;
+  const float* src; int ld, cs;
+  if (c < c0) { src = a0; ld = lda0; cs = c; } else { src = a1; ld = lda1; cs = c - c0; }
+  const int r0 = blockIdx.x * rows, r1 = min(T, r0 + rows);
+  float4 v[4];
+  auto fetch = [&](int rb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = rb + k * rl;
+      v[k] = (active && r < r1) ? *reinterpret_cast<const float4*>(src + ((size_t)b * T + r) * ld + cs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(r0 + rlane);
+
   for (int g = wave; g < G; g += 4) {          // finalise the statistics of this batch item (every block, cheap)
     double ds = 0.0, dq = 0.0;
     if (st0) {                                 // fixed-point statistics left by the producing GEMMs' epilogues
@@ -111,12 +130,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
   }
   __syncthreads();
-  const int rl = max(1, 256 / nq);
-  const int quad = tid % nq, rlane = tid / nq;
-  if (rlane >= rl) return;
-  const int c = quad * 4;
-  const float* src; int ld, cs;
-  if (c < c0) { src = a0; ld = lda0; cs = c; } else { src = a1; ld = lda1; cs = c - c0; }
+  if (!active) return;
   float sc[4], sh[4];
   {
     const int g = c / Cg;
@@ -135,23 +149,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
       }
     }
   }
-  const int r0 = blockIdx.x * rows, r1 = min(T, r0 + rows);
   for (int rb = r0 + rlane; rb < r1; rb += 4 * rl) {     // 4 independent 16-B loads in flight per thread
-    float4 v[4];
+    float4 w[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int r = rb + k * rl;
-      v[k] = (r < r1) ? *reinterpret_cast<const float4*>(src + ((size_t)b * T + r) * ld + cs) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int k = 0; k < 4; ++k) w[k] = v[k];
+    if (rb + 4 * rl < r1) fetch(rb + 4 * rl);            // next batch before this one is stored
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = rb + k * rl;
       if (r < r1) {
         const size_t row = (size_t)b * T + r;
-        float y0 = v[k].x * sc[0] + sh[0], y1 = v[k].y * sc[1] + sh[1], y2 = v[k].z * sc[2] + sh[2], y3 = v[k].w * sc[3] + sh[3];
+        float y0 = w[k].x * sc[0] + sh[0], y1 = w[k].y * sc[1] + sh[1], y2 = w[k].z * sc[2] + sh[2], y3 = w[k].w * sc[3] + sh[3];
         if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
         store_op4<TM>(out + row * C + c, y0, y1, y2, y3);
-        if (raw) store_op4<TM>(raw + row * C + c, v[k].x, v[k].y, v[k].z, v[k].w);
+        if (raw) store_op4<TM>(raw + row * C + c, w[k].x, w[k].y, w[k].z, w[k].w);
       }
     }
   }
@@ -501,7 +512,12 @@ hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, i
   const int C = c0 + c1;
   if (C > 1024 || (C & 3) || (c0 & 3) || G > 8) return hipErrorInvalidValue;
   if (st0 && (((C / G) & 15) || (c0 & 15) || (c1 && !st1))) return hipErrorInvalidValue;
-  const int rows = 32;
+  // rows per block: at least one full batch of loads per thread (4 * rl), at most 32, sized so that the grid has >= ~1500
+  // blocks -- at the coarse levels (T = 118 / 235) 32-row blocks left most of the chip without a wave to hide latency
+  const int rl = 256 / (C >> 2) > 0 ? 256 / (C >> 2) : 1;
+  int rows = 32;
+  while (rows > 4 * rl && (long)((T + rows - 1) / rows) * B < 1500) rows >>= 1;
+  if (rows < 4 * rl) rows = 4 * rl;
   dim3 grid((T + rows - 1) / rows, B);
   if (prec == PREC_BF16)
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, st0, st1,

@@ -165,9 +165,28 @@ def test_gemm_cases(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("tile", [(128, 128, 13), (64, 128, 13)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+def test_gemm_cases_ksplit_kernel(tile, prec, diag):
+    """Every feature case (taps, stride 2, upsample, concat, residual, GEGLU, dual outputs) through the 8-wave K-split kernel."""
+    for name, *args in GEMM_CASES:
+        if args[5] % 128:
+            continue
+        rng = np.random.default_rng(zlib.crc32(name.encode()))
+        out, ref, out_op = run_gemm(rng, prec, *args, tile=tile)
+        e = rel_l2(out, ref)
+        diag(f"gemm4 {name} tile={tile} prec={prec} rel_l2={e:.3e}")
+        assert e < TOL[prec], (name, e)
+        if out_op is not None:
+            assert np.array_equal(out_op, rnd(out, prec)), name
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("tile", [(128, 128, 2), (128, 128, 3), (64, 128, 2), (64, 128, 3), (64, 128, 4), (128, 64, 2), (128, 64, 3),
                                   (128, 64, 4), (64, 64, 2), (64, 64, 3), (64, 64, 4),
-                                  (128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+                                  (128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1),
+                                  # stages 12..14 = the 8-wave K-split kernel (gemm4_kernel) with ring depth 2..4
+                                  (128, 128, 12), (128, 128, 13), (128, 128, 14), (64, 128, 12), (64, 128, 13), (64, 128, 14)],
+                         ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_every_tile(tile, prec, diag):
     rng = np.random.default_rng(tile[0] * 1000 + tile[1])
     # M = 3*167 = 501 rows (tail in every tile size), concat + conv3 + bias + residual, K = 3*192 (9 / 18 tiles)
@@ -197,7 +216,7 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
     lib = _lib()
     rng = np.random.default_rng(5)
     B, T, c0, N = 3, 167, 128, 256
-    for tile in [(0, 0, 0), (128, 128, 2), (64, 128, 2), (128, 64, 2), (64, 64, 2), (64, 128, 1), (64, 64, 1)]:
+    for tile in [(0, 0, 0), (128, 128, 2), (64, 128, 2), (128, 64, 2), (64, 64, 2), (64, 128, 1), (64, 64, 1), (128, 128, 13), (64, 128, 13)]:
         a0 = rnd(rng.standard_normal((B, T, c0)), prec)
         W = rnd(rng.standard_normal((N, 3 * c0)) / np.sqrt(3 * c0), prec)
         bias = rng.standard_normal(N).astype(np.float32)

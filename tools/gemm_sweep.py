@@ -21,8 +21,10 @@ from ns2vc_amd._lib import GemmArgs, check     # noqa: E402
 from ns2vc_amd.engine import DevBuf, Event, Stream  # noqa: E402
 
 # stages == 1 selects the register-staged kernel (gemm3_kernel); 2..4 = global_load_lds ring depth (gemm2_kernel)
-CONFIGS = [(128, 128, 1), (64, 128, 1), (128, 64, 1), (64, 64, 1), (128, 128, 2), (64, 128, 2), (64, 128, 3), (128, 64, 2),
-           (64, 64, 2), (64, 64, 3), (64, 64, 4)]
+# (BM, BN, stages | flags << 8); stages 1 = register-staged kernel; flags: 1 = K rotation, 2 = loads only, 4 = no steady-state loads
+CONFIGS = [(128, 128, 12), (128, 128, 13), (128, 128, 14), (64, 128, 12), (64, 128, 13), (64, 128, 14), (128, 128, 2), (64, 128, 2), (64, 128, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
+ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 1024), (64, 128, 3 | 512), (64, 64, 2 | 256), (64, 64, 2 | 512), (64, 64, 2 | 1024),
+          (128, 128, 2 | 256), (128, 128, 2 | 512), (128, 128, 2 | 1024), (128, 128, 3 | 512)]
 
 
 def shapes(B=32, T=938):
@@ -47,7 +49,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--prec", default="bf16")
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--ablate", action="store_true", help="time the ABLATE list (K rotation / loads-only / compute-only variants)")
     a = ap.parse_args()
+    global CONFIGS
+    if a.ablate:
+        CONFIGS = ABLATE
     prec = 1 if a.prec == "bf16" else 0
     esz = 2 if prec else 4
     lib = _lib.load()
@@ -107,7 +113,7 @@ def main():
         best = min(v for v in row if v is not None)
         cells = " ".join(("   -- " if v is None else f"{v:6.1f}" + ("*" if v == best else " ")) for v in row)
         print(f"{name:22s} M={M:6d} N={N:5d} K={K:5d} | {cells} | heur {heur:6.1f} best {flops/best/1e6:6.0f} TF/s")
-    print("# configs:", " ".join(f"{c[0]}x{c[1]}s{c[2]}" for c in CONFIGS))
+    print("# configs:", " ".join(f"{c[0]}x{c[1]}s{c[2] & 255}" + (f"f{c[2] >> 8}" if c[2] >> 8 else "") for c in CONFIGS))
 
 
 if __name__ == "__main__":
