@@ -95,8 +95,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 128 + wave * 32 + l31;
+  // XCD-aware mapping: consecutive workgroup ids round-robin over the 8 XCDs (each with a private L2), so the ids are
+  // remapped to give every XCD a contiguous run of (batch item, head, query block): all heads and query blocks of one
+  // batch item share K/V rows (a head is a 32..128-B column slice of them) and now hit the same L2.  Measured before
+  // the remap (rocprofv3 FETCH_SIZE): 77-132 MB fetched per launch for ~28 MB of Q/K/V, L2 hit rate 24-29 %.
+  const int nqb = (a.Lq + 127) >> 7;
+  int b, h, qb;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qn = nwg >> 3, rn = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int swz = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    b = swz / (a.H * nqb);
+    const int rem = swz - b * (a.H * nqb);
+    h = rem / nqb;
+    qb = rem - h * nqb;
+  }
+  const int q = qb * 128 + wave * 32 + l31;
   const float LOG2E = 1.4426950408889634f;
   const float sc2 = a.scale * LOG2E;      // scores are kept in log2 units: t = s*sc2 (+ bias*log2e)
 
@@ -292,7 +306,7 @@ template <typename TM, int HD> static constexpr size_t attn_lds() {
 }
 
 template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
-  dim3 grid((a.Lq + 127) / 128, a.H, a.B);
+  dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);
   const size_t lds = attn_lds<TM, HD>();
   hipLaunchKernelGGL((attn_kernel<TM, HD>), grid, dim3(256), lds, s, a);
   return hipGetLastError();

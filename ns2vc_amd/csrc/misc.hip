@@ -101,6 +101,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
   };
   fetch(r0 + rlane);
+  // ... and so are the affine / time-conditioning vectors
+  float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), be = ga, t1 = ga, t2 = ga;
+  if (active) {
+    ga = *reinterpret_cast<const float4*>(gamma + c);
+    be = *reinterpret_cast<const float4*>(beta + c);
+    if (temb) {
+      const float* tp = temb + (size_t)b * ldtemb + temb_off + c;
+      if ((((size_t)b * ldtemb + temb_off) & 3) == 0) {
+        t1 = *reinterpret_cast<const float4*>(tp);
+        t2 = *reinterpret_cast<const float4*>(tp + C);
+      } else {
+        t1 = make_float4(tp[0], tp[1], tp[2], tp[3]);
+        t2 = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
+      }
+    }
+  }
 
   for (int g = wave; g < G; g += 4) {          // finalise the statistics of this batch item (every block, cheap)
     double ds = 0.0, dq = 0.0;
@@ -134,18 +150,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   float sc[4], sh[4];
   {
     const int g = c / Cg;
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-    const float4 be = *reinterpret_cast<const float4*>(beta + c);
     const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+    const float ts[4] = {t1.x, t1.y, t1.z, t1.w}, tf[4] = {t2.x, t2.y, t2.z, t2.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       sc[e] = s_rstd[g] * gam[e];
       sh[e] = bet[e] - s_mean[g] * sc[e];
       if (temb) {
-        const float s1 = 1.0f + temb[(size_t)b * ldtemb + temb_off + c + e];
-        const float sf = temb[(size_t)b * ldtemb + temb_off + C + c + e];
+        const float s1 = 1.0f + ts[e];
         sc[e] *= s1;
-        sh[e] = sh[e] * s1 + sf;
+        sh[e] = sh[e] * s1 + tf[e];
       }
     }
   }
