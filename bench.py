@@ -194,9 +194,20 @@ def main():
         peak = MFMA_PEAK_TFLOPS[a.precision]
         g = fam.get("implicit_gemm", {"launches": 1, "ms": 1.0, "flops": 0.0, "bytes": 0.0})
         gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+        # HBM bytes per launch of the same family from the PMC passes of this very command (rocprofv3 cannot run inside
+        # bench.py): profiles/r01_pmc_hbm_traffic.json, FETCH_SIZE x2-corrected + WRITE_SIZE, valid for the default workload
+        traffic, traffic_src = None, None
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")
+        if os.path.exists(tj) and a.precision == "bf16" and (B, T, Lp) == (32, 938, 469):
+            with open(tj) as fh:
+                tf = json.load(fh)["families"].get("implicit_gemm")
+            if tf:
+                traffic, traffic_src = tf["hbm_mb_per_launch"] * 1e6, "profiles/r01_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
         roof = {
-            "bound": "mfma", "kernel": "cgemm_kernel (implicit GEMM: conv1d k3/k1 + linear)",
-            "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": None,
+            "bound": "mfma", "kernel": "gemm4_kernel / gemm2_kernel (implicit GEMM: conv1d k3/k1 + linear)",
+            "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
             "launches_per_step": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1),
             "algorithmic_gflop_per_launch": g["flops"] / 1e9 / max(g["launches"], 1),
             "algorithmic_hbm_gbs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
