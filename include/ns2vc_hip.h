@@ -143,6 +143,15 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   /* optional second K segment (a fused 1x1 conv on another operand tensor, e.g. the resnet shortcut):
    * K = taps*(c0+c1) + c2, out += A2[m, :] * W[:, taps*(c0+c1):]; same row mapping, centre tap */
   const void* a2; int32_t lda2, c2;
+  /* LayerNorm by linearity (attention.py:83,102,118 without a normalisation pass):
+   *   producer: rowstats != NULL -> the epilogue stores (sum, sum of squares) of every RESULT row per 64-column slice:
+   *             fp32 [M][N/64][2], one writer per slot (nothing to zero; geglu == 0, N % 128 == 0);
+   *   consumer: ln_stats != NULL -> the A rows are the RAW x of LayerNorm(x) (gamma/beta folded into w/bias) and the
+   *             epilogue applies  out = rstd[m] * (acc[m][n] - mean[m] * ln_wsum[n]) + bias[n]  with mean/rstd over
+   *             ln_dim channels (128..512, multiple of 128) from the producer's [M][ln_dim/64][2] pairs; ln_wsum[n] = sum_k w[n][k]
+   *             of the packed, rounded weights (ns2vc_weight_rowsum). */
+  float* rowstats;
+  const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {
@@ -159,6 +168,7 @@ int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev)
 int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);
 int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
+int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev); /* [N] fp32: sum_k round_to_operand(rows[n][k]) */
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile (128|64 x 128|64) and LDS ring depth (2..4); 0,0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);

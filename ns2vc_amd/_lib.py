@@ -42,6 +42,8 @@ class GemmArgs(C.Structure):
         ("out_op", C.c_void_p), ("ldo_op", C.c_int32),
         ("stats", C.c_void_p),
         ("a2", C.c_void_p), ("lda2", C.c_int32), ("c2", C.c_int32),
+        ("rowstats", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
     ]
 
 
@@ -97,6 +99,7 @@ PROTOTYPES = {
     "ns2vc_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
     "ns2vc_pack_weight": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_k_gemm": (_I, [C.POINTER(GemmArgs), _I, _P]),
+    "ns2vc_weight_rowsum": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),

@@ -50,6 +50,7 @@ struct HostTensor {
 struct PackedW {     // device-resident packed GEMM weight
   void* w = nullptr;
   float* bias = nullptr;
+  float* wsum = nullptr;   // [N] row sums of the packed (rounded) weights: LayerNorm-by-linearity consumers only
   int N = 0, K = 0;
 };
 
@@ -120,6 +121,8 @@ struct ns2vc_unet {
   // the separate launches on MI355X (5.74-6.09 vs 5.61 ms/step, profiles/chain_ab_r01.txt): one workgroup per CU
   // serialises 4-5 dependent global round trips.  Off unless NS2VC_USE_CHAINS=1.
   bool use_chains = false;
+  // LayerNorm by linearity (csrc/gemm.hip): no normalisation pass; NS2VC_LN_LINEAR=0 restores the ln_apply kernels
+  bool ln_linear = true;
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -289,6 +292,21 @@ static void append_chain_tiles(std::vector<uint16_t>& stream, const float* rows,
         }
 }
 
+// sum_k of the operand-rounded weight row (what the MFMA will actually multiply), accumulated in double
+static std::vector<float> rounded_rowsum(const float* rows, int N, int K, int Np, int prec) {
+  std::vector<float> ws(Np, 0.f);
+  for (int n = 0; n < N; ++n) {
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) {
+      float v = rows[(size_t)n * K + k];
+      if (prec == PREC_BF16) v = bf16_bits_to_f32(f32_to_bf16_bits(v));
+      acc += (double)v;
+    }
+    ws[n] = (float)acc;
+  }
+  return ws;
+}
+
 struct Packer {
   ns2vc_unet* h;
   int err = 0;
@@ -315,10 +333,11 @@ struct Packer {
   }
 
   // rows: [N][K] fp32, bias: [N] or empty.  Pads N to a multiple of 128 with zero rows.
-  PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias) {
+  PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias, bool want_wsum = false) {
     PackedW p;
     const int Np = round_up(N, 128);
     p.N = Np; p.K = K;
+    if (want_wsum) p.wsum = upload_f32(rounded_rowsum(rows.data(), N, K, Np, h->prec));
     void* d = nullptr;
     if (h->prec == PREC_BF16) {
       std::vector<uint16_t> q((size_t)Np * K, 0);
@@ -458,14 +477,14 @@ int pack_all(ns2vc_unet* h) {
         std::vector<float> rows, bias;
         for (const char* nm : {"to_q", "to_k", "to_v"}) P.ln_fold(P.T(t + ".attn1." + nm + ".weight"), nullptr, P.T(t + ".norm1.weight"), P.T(t + ".norm1.bias"), rows, bias);
         if (P.err) return 1;
-        a.qkv = P.pack(rows, 3 * d, d, bias);
+        a.qkv = P.pack(rows, 3 * d, d, bias, true);
       }
       a.o1 = P.pack(P.T(t + ".attn1.to_out.0.weight").data, d, d, P.T(t + ".attn1.to_out.0.bias").data);
       {
         std::vector<float> rows, bias;
         P.ln_fold(P.T(t + ".attn2.to_q.weight"), nullptr, P.T(t + ".norm2.weight"), P.T(t + ".norm2.bias"), rows, bias);
         if (P.err) return 1;
-        a.q2 = P.pack(rows, d, d, bias);
+        a.q2 = P.pack(rows, d, d, bias, true);
       }
       a.o2 = P.pack(P.T(t + ".attn2.to_out.0.weight").data, d, d, P.T(t + ".attn2.to_out.0.bias").data);
       if (h->prec == PREC_BF16) {   // weight streams of the fused row chains
@@ -499,7 +518,7 @@ int pack_all(ns2vc_unet* h) {
             bias2[v_dst] = bias[v_src];
             bias2[g_dst] = bias[g_src];
           }
-        a.ff1 = P.pack(rows2, 8 * d, d, bias2);
+        a.ff1 = P.pack(rows2, 8 * d, d, bias2, true);
       }
       a.ff2 = P.pack(P.T(t + ".ff.net.2.weight").data, d, 4 * d, P.T(t + ".ff.net.2.bias").data);
       {  // cross-attention k|v of this block into the hoisted all-blocks projection
@@ -547,6 +566,7 @@ struct Planner {
   // scratch shared by all layers (stream-ordered)
   double* gn_partial = nullptr;
   void *xn = nullptr, *xr = nullptr;     // GroupNorm-applied / raw operand copies of a resnet input
+  float *rs1 = nullptr, *rs2 = nullptr, *rs3 = nullptr;   // LayerNorm-by-linearity row statistics [M][C/64][2] (norm1/2/3)
   int gn_rows = 64;
   // GroupNorm statistics accumulated by the producing GEMM's epilogue (int64 fixed point, [B][C/16][2]);
   // one zeroed slab per produced tensor, all carved from stats_pool (cleared by one memset per forward)
@@ -688,11 +708,16 @@ struct Planner {
       add(a.prefix + ".chainA[proj_in+norm1+qkv]", [=](hipStream_t s) { return launch_chain_ab(xn_, M, d, wsa, b1, nullptr, y, 1e-5f, b2, qkv, 3 * d, s); },
           1, 2.0 * M * d * (4.0 * d), M * d * wsz + 4.0 * d * d * wsz + 4.0 * M * d + 3.0 * M * d * wsz);
     } else {
-      g = base(xn, d, d, Tl, Tl, a.proj_in, y, nullptr, d);
+      // LayerNorm by linearity (h->ln_linear): the producer of every LayerNorm input also writes the raw operand copy
+      // `yn` and per-row statistics; the consumer GEMM reads yn and normalises in its epilogue -- no ln_apply pass
+      float* r1 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs1 : nullptr;
+      g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
+      g.rowstats = r1;
       gemm(a.prefix + ".proj_in", g);
       // self attention
-      layernorm(t + ".norm1");
+      if (!r1) layernorm(t + ".norm1");
       g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
+      if (r1) { g.ln_stats = r1; g.ln_wsum = a.qkv.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
       gemm(t + ".attn1.qkv", g);
     }
     attention(t + ".attn1.sdpa", qkv, 3 * d, op_off(qkv, d), 3 * d, op_off(qkv, 2 * d), 3 * d, Tl, Tl, nullptr, hd, ao, d);
@@ -702,24 +727,30 @@ struct Planner {
       add(t + ".chainB[attn1.to_out+norm2+to_q]", [=](hipStream_t s) { return launch_chain_ab(ao, M, d, wsb, b1, y, y, 1e-5f, b2, qb, d, s); },
           1, 2.0 * M * d * (2.0 * d), M * d * wsz + 2.0 * d * d * wsz + 8.0 * M * d + M * d * wsz);
     } else {
-      g = base(ao, d, d, Tl, Tl, a.o1, y, nullptr, d);
+      float* r2 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs2 : nullptr;
+      g = base(ao, d, d, Tl, Tl, a.o1, y, r2 ? yn : nullptr, d);
       g.res = y; g.ldres = d;
+      g.rowstats = r2;
       gemm(t + ".attn1.to_out", g);
-      layernorm(t + ".norm2");
+      if (!r2) layernorm(t + ".norm2");
       g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
+      if (r2) { g.ln_stats = r2; g.ln_wsum = a.q2.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
       gemm(t + ".attn2.to_q", g);
     }
     // cross attention (k|v hoisted into h->kv by set_condition)
     const int nkv = h->kv_all.N;
     attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
               h->has_mask ? h->maskbias : nullptr, hd, ao, d);
-    g = base(ao, d, d, Tl, Tl, a.o2, y, nullptr, d);
+    float* r3 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs3 : nullptr;
+    g = base(ao, d, d, Tl, Tl, a.o2, y, r3 ? yn : nullptr, d);
     g.res = y; g.ldres = d;
+    g.rowstats = r3;
     gemm(t + ".attn2.to_out", g);
     // feed-forward (GEGLU)
-    layernorm(t + ".norm3");
+    if (!r3) layernorm(t + ".norm3");
     g = base(yn, d, d, Tl, Tl, a.ff1, nullptr, ffh, 4 * d);
     g.geglu = 1;
+    if (r3) { g.ln_stats = r3; g.ln_wsum = a.ff1.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
     gemm(t + ".ff.geglu", g);
     g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ff2, nullptr, yn, d);     // y_final = y + ff(...) is only consumed by proj_out: operand copy only
     g.res = y; g.ldres = d;
@@ -781,6 +812,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   P.gn_rows = 32;
   P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
   P.xn = P.alloc_op(maxIn); P.xr = P.alloc_op(maxIn);
+  P.rs1 = P.alloc<float>(maxMC / 32); P.rs2 = P.alloc<float>(maxMC / 32); P.rs3 = P.alloc<float>(maxMC / 32);
   float* h1 = P.alloc<float>(maxMC);
   void* hn = P.alloc_op(maxMC);
   float* scb = P.alloc<float>(maxMC);
@@ -1012,6 +1044,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
   if (const char* e = getenv("NS2VC_USE_CHAINS")) h->use_chains = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1281,6 +1314,15 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
     HIPCHK(hipMemcpy(d, rows_host, (size_t)N * K * 4, hipMemcpyHostToDevice));
   }
   *out_dev = d;
+  return 0;
+}
+int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev) {
+  if (!rows_host || !out_dev || N <= 0 || K <= 0) return fail("bad argument");
+  const std::vector<float> ws = rounded_rowsum(rows_host, N, K, N, precision == NS2VC_PREC_BF16 ? PREC_BF16 : PREC_F32);
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, ws.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(d, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out_dev = (float*)d;
   return 0;
 }
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) { set_gemm_trace((unsigned long long*)dev_u64_blocks_x8); return 0; }

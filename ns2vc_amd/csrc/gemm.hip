@@ -48,11 +48,52 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 constexpr int TROW = 128;   // bytes of K per tile row (64 bf16 / 32 f32)
 
 // ---------------------------------------------------------------------------
+// LayerNorm by linearity.  LayerNorm(x) W^T = rstd * (x W^T - mean * rowsum(W)), so a GEMM whose input is a LayerNorm
+// reads the RAW x (the operand copy its producer writes anyway) and fixes the result up in the epilogue; the
+// producer's epilogue leaves (sum, sum of squares) per row and 64-column slice as plain fp32 stores (one writer per
+// slot: deterministic, nothing to zero).  No normalisation pass over HBM.
+// ---------------------------------------------------------------------------
+// consumer, part 1 (top of the kernel, so the cold-load latency hides under the K loop): this lane's row pairs, raw
+struct LnRaw { float4 v[4]; };                      // up to 8 slices of 64 channels = ln_dim 512
+__device__ __forceinline__ void ln_row_load(const GemmArgs& g, int m, bool valid, LnRaw& r) {
+  const int n4 = g.ln_stats ? (g.ln_dim >> 7) : 0;  // float4 = two (sum, sumsq) pairs = 128 channels
+  const float4* p = reinterpret_cast<const float4*>(g.ln_stats + (size_t)min(m, g.M - 1) * (g.ln_dim >> 6) * 2);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.v[i] = (valid && i < n4) ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// consumer, part 2 (epilogue): mean / rstd of the row
+__device__ __forceinline__ void ln_row_finish(const GemmArgs& g, const LnRaw& r, float& mean_f, float& rstd_f) {
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { s += r.v[i].x + r.v[i].z; q += r.v[i].y + r.v[i].w; }
+  const float inv = 1.0f / (float)max(g.ln_dim, 1);
+  const float mean = s * inv;
+  double var = (double)q * (double)inv - (double)mean * (double)mean;     // the one cancellation-prone step
+  if (var < 0.0) var = 0.0;
+  mean_f = mean;
+  rstd_f = 1.0f / sqrtf((float)var + g.ln_eps);
+}
+// sum over the 16 lanes (one DPP row) that hold one 64-column slice of a result row; no LDS traffic, all 16 get the total
+__device__ __forceinline__ float sum16_dpp(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
+  return x;
+}
+// producer (64-column wave tiles only): (sum, sumsq) of this row's 64-column slice -> rowstats[m][ncol/64]
+// (plain store: every slot has exactly one writer)
+__device__ __forceinline__ void ln_row_store(const GemmArgs& g, int m, int ncol, int cq, float ps, float pq) {
+  ps = sum16_dpp(ps); pq = sum16_dpp(pq);
+  if (cq == 0 && m < g.M) *reinterpret_cast<float2*>(g.rowstats + ((size_t)m * (g.N >> 6) + (ncol >> 6)) * 2) = make_float2(ps, pq);
+}
+
+// ---------------------------------------------------------------------------
 // shared epilogue (bias, GEGLU, residual, fp32 / operand stores, GroupNorm statistics)
 // ---------------------------------------------------------------------------
-template <typename TM, int BM, int BN>
+template <typename TM, int BM, int BN, bool LNC>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)[BM / 64][BN / 64], char* smem, int m0, int n0, int tid,
-                                              unsigned long long* tr) {
+                                              unsigned long long* tr, const LnRaw& lnraw) {
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -77,19 +118,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   float* of = g.out_f32;
   TM* oo = reinterpret_cast<TM*>(g.out_op);
   const int mw0 = m0 + wm * WM;
+  // LayerNorm-by-linearity consumer: lane l holds mean / rstd of row mw0 + l (l < WM; the pairs were loaded at the top
+  // of the kernel so the latency hid under the K loop), fetched per row by shuffle
+  constexpr bool lnc = LNC;           // compile-time: GEMMs that are not LayerNorm consumers carry none of this
+  float lmean = 0.f, lrstd = 1.f;
+  if constexpr (lnc) ln_row_finish(g, lnraw, lmean, lrstd);
   if (g.geglu) {
     if constexpr (NT == 2) {
       constexpr int LPR = 8, RPI = 8, NIT = WM / RPI;          // 32 output columns per row = 8 lanes x 4
       const int rsub = lane >> 3, cq = lane & 7;
       const int pcol = n0 + wn * WN + cq * 4;                  // packed column of the value quad; gate quad = +32
       const int ocol = ((n0 + wn * WN) >> 1) + cq * 4;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv, wsv = bv, wsg = bv;
       if (g.bias) { bv = *reinterpret_cast<const float4*>(g.bias + pcol); bg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
+      if constexpr (lnc) { wsv = *reinterpret_cast<const float4*>(g.ln_wsum + pcol); wsg = *reinterpret_cast<const float4*>(g.ln_wsum + pcol + 32); }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int row = it * RPI + rsub, m = mw0 + row;
-        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
-        const float4 t = *reinterpret_cast<const float4*>(et + row * EP + 32 + cq * 4);
+        float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        float4 t = *reinterpret_cast<const float4*>(et + row * EP + 32 + cq * 4);
+        if constexpr (lnc) {
+          const float mu = __shfl(lmean, row), rs = __shfl(lrstd, row);
+          a.x = rs * (a.x - mu * wsv.x); a.y = rs * (a.y - mu * wsv.y); a.z = rs * (a.z - mu * wsv.z); a.w = rs * (a.w - mu * wsv.w);
+          t.x = rs * (t.x - mu * wsg.x); t.y = rs * (t.y - mu * wsg.y); t.z = rs * (t.z - mu * wsg.z); t.w = rs * (t.w - mu * wsg.w);
+        }
         if (m < g.M) {
           float4 v;
           v.x = (a.x + bv.x) * gelu_erf_f(t.x + bg.x); v.y = (a.y + bv.y) * gelu_erf_f(t.y + bg.y);
@@ -108,8 +160,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
     constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;
     const int rsub = lane / LPR, cq = lane % LPR;
     const int ncol = n0 + wn * WN + cq * 4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), ws = bv;
     if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+    if constexpr (lnc) ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
     // optional GroupNorm statistics of the result: this wave's rows belong to batch b0 or b0+1 (Tout >= WM)
     const int b0 = min(mw0, g.M - 1) / g.Tout;
     const int mB = (b0 + 1) * g.Tout;                          // first row of the next batch item
@@ -126,15 +179,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
 #pragma unroll
       for (int k = 0; k < RB; ++k) {
         const int row = (it0 + k) * RPI + rsub, m = mw0 + row;
-        const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+        if constexpr (lnc) {
+          const float mu = __shfl(lmean, row), rs = __shfl(lrstd, row);
+          a.x = rs * (a.x - mu * ws.x); a.y = rs * (a.y - mu * ws.y); a.z = rs * (a.z - mu * ws.z); a.w = rs * (a.w - mu * ws.w);
+        }
+        float ps = 0.f, pq = 0.f;
         if (m < g.M) {
           float4 v;
           v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
           if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
           if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
-          const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
         }
+        if constexpr (LPR == 16) { if (g.rowstats) ln_row_store(g, m, ncol, cq, ps, pq); }
       }
     }
     if (g.stats) {
@@ -165,7 +224,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   NS2VC_STAMP(6);
 }
 
-template <typename TM, int BM, int BN, int STAGES>
+template <typename TM, int BM, int BN, int STAGES, bool LNC>
 __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int flags) {
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
@@ -196,6 +255,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
     tn = swz - tm * nb_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  LnRaw lnraw;                         // LayerNorm-by-linearity consumer: this lane's row pairs (see gemm_epilogue)
+  if constexpr (LNC) ln_row_load(g, m0 + wm * (BM / 2) + lane, lane < BM / 2, lnraw);
 
   // ---- per-thread DMA coordinates: piece i = tid + 256*j covers tile row i>>3, physical chunk i&7
   const int prow = tid >> 3;                 // row inside a 32-row pass
@@ -275,7 +336,6 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue_tile(ktile(s), s);
   NS2VC_STAMP(2);
-
   const int l31 = lane & 31, hi = lane >> 5;
   // fragment reads: row r = w*W? + i*32 + l31, logical chunk 2*ks+hi stored at chunk ^ ((r>>1)&7);
   // (r>>1)&7 == (l31>>1)&7 because every fragment row block starts at a multiple of 32
@@ -315,7 +375,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
     }
     if (++stage == STAGES) stage = 0;
   }
-  gemm_epilogue<TM, BM, BN>(g, acc, smem, m0, n0, tid, tr);
+  gemm_epilogue<TM, BM, BN, LNC>(g, acc, smem, m0, n0, tid, tr, lnraw);
 }
 
 // ---------------------------------------------------------------------------
@@ -472,7 +532,8 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
   }
   if (kt < nk) compute(0);                     // odd tail: tile nk-1 sits in stage 0
   NS2VC_STAMP(4);
-  gemm_epilogue<TM, BM, BN>(g, acc, smem, m0, n0, tid, tr);
+  LnRaw lnraw;                                 // (this experimental variant is not a LayerNorm consumer)
+  gemm_epilogue<TM, BM, BN, false>(g, acc, smem, m0, n0, tid, tr, lnraw);
 }
 
 // ---------------------------------------------------------------------------
@@ -492,7 +553,7 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
 //   * the two K halves meet in the epilogue: both stage their accumulators in LDS (32-row slabs, re-using the ring),
 //     then all eight waves add the pair while they transpose rows out -- every wave stores, nothing idles.
 // ---------------------------------------------------------------------------
-template <typename TM, int BM, int BN, int STAGES>
+template <typename TM, int BM, int BN, int STAGES, bool LNC>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
@@ -524,6 +585,8 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
     tn = swz - tm * nb_n;
   }
   const int m0 = tm * BM, n0 = tn * BN;
+  LnRaw lnraw;                         // LayerNorm-by-linearity consumer: pairs of the lane's epilogue row, in flight during the K loop
+  if constexpr (LNC) ln_row_load(g, m0 + wm * (BM / 2) + (lane >> 4) * 32 + kg * 16 + (lane & 15), lane < 16 * (BM / 64), lnraw);
 
   // ---- DMA coordinates: piece j of this thread = tile row j*64 + tid/8, physical 16-B chunk tid%8
   const int prow = tid >> 3, pchunk = tid & 7;
@@ -660,6 +723,15 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   const int ocol = ((n0 + wn * WN) >> 1) + gcq * 4;
   float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f), gbg = gbv;
   if (g.bias && g.geglu) { gbv = *reinterpret_cast<const float4*>(g.bias + pcol); gbg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
+  // LayerNorm-by-linearity consumer: lane l < 16*MT holds mean / rstd of the l-th row this wave will emit (loaded before the K loop)
+  constexpr bool lnc = LNC;
+  float lmean = 0.f, lrstd = 1.f;
+  float4 ws = make_float4(0.f, 0.f, 0.f, 0.f), wsv = ws, wsg = ws;
+  if constexpr (lnc) {
+    ln_row_finish(g, lnraw, lmean, lrstd);
+    if (g.geglu) { wsv = *reinterpret_cast<const float4*>(g.ln_wsum + pcol); wsg = *reinterpret_cast<const float4*>(g.ln_wsum + pcol + 32); }
+    else ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
+  }
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -679,10 +751,17 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
         const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + gcq * 4);
         const float4 t0 = *reinterpret_cast<const float4*>(et_a + row * EP + 32 + gcq * 4);
         const float4 t1 = *reinterpret_cast<const float4*>(et_b + row * EP + 32 + gcq * 4);
+        float4 a = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
+        if constexpr (lnc) {
+          const float mu = __shfl(lmean, mt * 16 + row), rs = __shfl(lrstd, mt * 16 + row);
+          a.x = rs * (a.x - mu * wsv.x); a.y = rs * (a.y - mu * wsv.y); a.z = rs * (a.z - mu * wsv.z); a.w = rs * (a.w - mu * wsv.w);
+          t.x = rs * (t.x - mu * wsg.x); t.y = rs * (t.y - mu * wsg.y); t.z = rs * (t.z - mu * wsg.z); t.w = rs * (t.w - mu * wsg.w);
+        }
         if (m < g.M) {
           float4 v;
-          v.x = (a0.x + a1.x + gbv.x) * gelu_erf_f(t0.x + t1.x + gbg.x); v.y = (a0.y + a1.y + gbv.y) * gelu_erf_f(t0.y + t1.y + gbg.y);
-          v.z = (a0.z + a1.z + gbv.z) * gelu_erf_f(t0.z + t1.z + gbg.z); v.w = (a0.w + a1.w + gbv.w) * gelu_erf_f(t0.w + t1.w + gbg.w);
+          v.x = (a.x + gbv.x) * gelu_erf_f(t.x + gbg.x); v.y = (a.y + gbv.y) * gelu_erf_f(t.y + gbg.y);
+          v.z = (a.z + gbv.z) * gelu_erf_f(t.z + gbg.z); v.w = (a.w + gbv.w) * gelu_erf_f(t.w + gbg.w);
           if (g.res) {
             const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
@@ -703,15 +782,21 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
         const int row = k * RPI + rsub, m = mrow0 + row;
         const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + cq * 4);
         const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + cq * 4);
+        float4 a = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        if constexpr (lnc) {
+          const float mu = __shfl(lmean, mt * 16 + row), rs = __shfl(lrstd, mt * 16 + row);
+          a.x = rs * (a.x - mu * ws.x); a.y = rs * (a.y - mu * ws.y); a.z = rs * (a.z - mu * ws.z); a.w = rs * (a.w - mu * ws.w);
+        }
+        float ps = 0.f, pq = 0.f;
         if (m < g.M) {
           float4 v;
-          v.x = (a0.x + a1.x) + bv.x + rr[k].x; v.y = (a0.y + a1.y) + bv.y + rr[k].y;
-          v.z = (a0.z + a1.z) + bv.z + rr[k].z; v.w = (a0.w + a1.w) + bv.w + rr[k].w;
+          v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
           if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
           if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
-          const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
         }
+        if (g.rowstats) ln_row_store(g, m, ncol, cq, ps, pq);
       }
     }
   }
@@ -755,7 +840,8 @@ template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
   const size_t lds = gemm_lds_bytes(BM, BN, STAGES);
-  hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(256), lds, s, g, g_gemm_flags);
+  if (g.ln_stats) hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(256), lds, s, g, g_gemm_flags);
+  else hipLaunchKernelGGL((gemm2_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(256), lds, s, g, g_gemm_flags);
   return hipGetLastError();
 }
 
@@ -776,7 +862,8 @@ static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
 template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
-  hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
   return hipGetLastError();
 }
 
@@ -792,7 +879,7 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
   const bool n128 = (g.N % 128) == 0;
   if (g_force_bm) {   // test / tuning hook (ns2vc_debug_set_gemm_tile)
     bm = g_force_bm; bn = g_force_bn; st = g_force_st ? g_force_st : 3;
-    if (g.N % bn || (g.geglu && bn != 128)) return hipErrorInvalidValue;
+    if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return hipErrorInvalidValue;
   } else {
     // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01.txt):
     // these GEMMs are short (7-35 us) and latency/occupancy-bound, so the small-LDS configurations that keep
@@ -801,7 +888,7 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
     if (g.geglu) {
       if (!n128) return hipErrorInvalidValue;
       bm = 64; bn = 128; st = 2;
-    } else if (n128 && g.N <= 512 && !(g.N == 384 && nk <= 6)) {
+    } else if (n128 && g.N <= 512 && (g.rowstats || !(g.N == 384 && nk <= 6))) {
       // narrow outputs (every conv and the to_out / proj / ff-out linears): the 8-wave K-split kernel, 3-deep ring.
       // Equal or a few % ahead at levels 0-2 and 20-25 % ahead at level 3 (profiles/gemm_sweep_r01c_ksplit.txt)
       bm = 64; bn = 128; st = 13;
@@ -819,6 +906,7 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
 #undef NS2VC_CASE4
     return hipErrorInvalidValue;
   }
+  if (st == 1 && g.ln_stats) return hipErrorInvalidValue;
   if (st == 1) {     // register-staged kernel (ring depth is fixed: 2 LDS stages + 2 register sets)
     if (bm == 128 && bn == 128) return launch_cfg3<TM, 128, 128>(g, s);
     if (bm == 64 && bn == 128) return launch_cfg3<TM, 64, 128>(g, s);
@@ -843,6 +931,9 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
   if (!g.out_f32 && !g.out_op) return hipErrorInvalidValue;
   if (g.stats && (g.geglu || g.Tout < 64 || (g.N & 15))) return hipErrorInvalidValue;
+  if (g.rowstats && g.geglu) return hipErrorInvalidValue;
+  if (g.ln_stats && (!g.ln_wsum || g.ln_dim <= 0 || (g.ln_dim & 127) || g.ln_dim > 512)) return hipErrorInvalidValue;
+  if (g.rowstats && (g.N & 127)) return hipErrorInvalidValue;
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
   if (prec == PREC_BF16) return launch_typed<bf16_t>(g, s);
   return launch_typed<float>(g, s);
@@ -854,7 +945,8 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
 
 #define NS2VC_SET(TM, BM, BN, ST)                                                                              \
   do {                                                                                                          \
-    hipError_t e = set_lds(gemm2_kernel<TM, BM, BN, ST>, gemm_lds_bytes(BM, BN, ST));                           \
+    hipError_t e = set_lds(gemm2_kernel<TM, BM, BN, ST, false>, gemm_lds_bytes(BM, BN, ST));                    \
+    if (e == hipSuccess) e = set_lds(gemm2_kernel<TM, BM, BN, ST, true>, gemm_lds_bytes(BM, BN, ST));           \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 
@@ -866,7 +958,8 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
   } while (0)
 #define NS2VC_SET4(TM, BM, ST)                                                                                  \
   do {                                                                                                          \
-    hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST>, gemm4_lds_bytes(BM, 128, ST));                        \
+    hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false>, gemm4_lds_bytes(BM, 128, ST));                 \
+    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true>, gemm4_lds_bytes(BM, 128, ST));        \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 hipError_t init_gemm_attributes() {

@@ -250,6 +250,91 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 2), (64, 64, 2), (64, 128, 13), (128, 128, 13)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+def test_gemm_layernorm_by_linearity(tile, prec, diag):
+    """LayerNorm(y) @ W'^T without a normalisation pass (attention.py:83,102,118): the producer GEMM leaves (sum, sumsq)
+    per row and 64-column slice and an operand copy of y; the consumer GEMM reads the raw copy and applies
+    rstd * (acc - mean * rowsum(W')) + b in its epilogue.  Checked against numpy LayerNorm -> matmul in fp64,
+    plain and GEGLU consumers, rows with a large mean (cancellation) included."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(11)
+    B, T, D = 3, 83, 256                      # M = 249: row tail in every tile
+    M = B * T
+    # ---- producer: y = a @ W1^T + b1 + res  (fp32 + operand copy + row statistics)
+    a = rnd(rng.standard_normal((M, D)), prec)
+    W1 = rnd(rng.standard_normal((D, D)) / np.sqrt(D), prec)
+    b1 = rng.standard_normal(D).astype(np.float32)
+    res = (rng.standard_normal((M, D)) + 3.0 * rng.standard_normal((M, 1))).astype(np.float32)   # per-row offsets: |mean| up to ~3 sigma
+    d_a, d_w1, d_b1, d_res = OpBuf(a, prec), _pack(W1, prec), _dev(b1), _dev(res)
+    d_y = DevBuf(M * D * 4)
+    d_yop = DevBuf(M * D * (2 if prec else 4))
+    d_rs = DevBuf.from_numpy(np.full((M, D // 64, 2), np.nan, dtype=np.float32))     # every slot must be written
+    g = GemmArgs()
+    g.a0 = d_a.ptr; g.lda0 = D; g.c0 = D
+    g.B, g.Tin, g.Tout, g.M = B, T, T, M
+    g.taps, g.tmode = 1, 0
+    g.w = d_w1.value; g.K = D; g.N = D; g.bias = d_b1.ptr
+    g.res = d_res.ptr; g.ldres = D
+    g.out_f32 = d_y.ptr; g.ldo_f32 = D
+    g.out_op = d_yop.ptr; g.ldo_op = D
+    g.rowstats = d_rs.ptr
+    try:
+        check(lib.ns2vc_debug_set_gemm_tile(*(tile if tile[1] != 64 else (0, 0, 0))), "tile")   # producers need 64-column wave tiles
+        check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "producer gemm")
+        sync()
+        check(lib.ns2vc_debug_set_gemm_tile(*tile), "tile")
+        y = d_y.to_numpy((M, D)).astype(np.float64)
+        st = d_rs.to_numpy((M, D // 64, 2)).astype(np.float64)
+        ys = y.reshape(M, D // 64, 64)
+        e_s = np.abs(st[..., 0] - ys.sum(2)).max() / np.abs(ys.sum(2)).max()
+        e_q = np.abs(st[..., 1] - (ys ** 2).sum(2)).max() / (ys ** 2).sum(2).max()
+        diag(f"ln-linear producer tile={tile} prec={prec}: slice sums {e_s:.2e} slice sumsq {e_q:.2e}")
+        assert e_s < 1e-5 and e_q < 1e-5
+        # ---- consumers
+        mu = y.mean(1, keepdims=True)
+        yn = (y - mu) / np.sqrt(y.var(1, keepdims=True) + 1e-5)
+        for geglu, N in ((0, 384), (1, 512)):
+            W2 = rnd(rng.standard_normal((N, D)) / np.sqrt(D), prec)
+            b2 = rng.standard_normal(N).astype(np.float32)
+            d_w2, d_b2 = _pack(W2, prec), _dev(b2)
+            ws = C.c_void_p()
+            W2c = np.ascontiguousarray(W2, dtype=np.float32)
+            check(lib.ns2vc_weight_rowsum(W2c.ctypes.data, N, D, prec, C.byref(ws)), "rowsum")
+            Nout = N // 2 if geglu else N
+            d_o = DevBuf(M * Nout * 4)
+            g2 = GemmArgs()
+            g2.a0 = d_yop.ptr; g2.lda0 = D; g2.c0 = D
+            g2.B, g2.Tin, g2.Tout, g2.M = B, T, T, M
+            g2.taps, g2.tmode = 1, 0
+            g2.w = d_w2.value; g2.K = D; g2.N = N; g2.bias = d_b2.ptr
+            g2.geglu = geglu
+            g2.out_f32 = d_o.ptr; g2.ldo_f32 = Nout
+            g2.ln_stats = d_rs.ptr; g2.ln_wsum = ws.value; g2.ln_eps = 1e-5; g2.ln_dim = D
+            if geglu and tile[1] not in (0, 128):
+                continue
+            check(lib.ns2vc_k_gemm(C.byref(g2), prec, None), "consumer gemm")
+            sync()
+            out = d_o.to_numpy((M, Nout)).astype(np.float64)
+            pre = yn @ W2.astype(np.float64).T + b2
+            if geglu:   # packed layout: groups of (32 value | 32 gate) columns
+                from scipy.special import erf
+                pg = pre.reshape(M, N // 64, 2, 32)
+                ref = (pg[:, :, 0] * 0.5 * pg[:, :, 1] * (1.0 + erf(pg[:, :, 1] / np.sqrt(2.0)))).reshape(M, Nout)
+            else:
+                ref = pre
+            e = rel_l2(out, ref)
+            diag(f"ln-linear consumer tile={tile} prec={prec} geglu={geglu}: rel_l2 {e:.3e}")
+            # fp32: exact up to rounding; bf16: the raw operand copy is rounded BEFORE normalisation (2^-9 of |y|, not of |y - mean|)
+            assert e < (2e-5 if prec == 0 else 1.5e-2)
+            lib.ns2vc_dev_free(d_w2); lib.ns2vc_dev_free(ws)
+    finally:
+        lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+    lib.ns2vc_dev_free(d_w1)
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 def test_gemm_fused_shortcut_segment(prec, diag):
     """conv3(hn) + conv1x1(x) in one launch: K = 3*c0 + c2 with the second segment on another operand tensor."""
     from ns2vc_amd._lib import GemmArgs, check
