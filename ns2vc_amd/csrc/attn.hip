@@ -76,21 +76,46 @@ __device__ __forceinline__ float half_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// operand-type helpers of the softmax reference shift
+template <typename TM> __device__ __forceinline__ float round_op(float x);
+template <> __device__ __forceinline__ float round_op<float>(float x) { return x; }
+template <> __device__ __forceinline__ float round_op<bf16_t>(float x) { return __uint_as_float(pack_bf16x2(0.f, x) & 0xffff0000u); }
+// first 16-B chunk of a K/Q "aux" k-slab: {e0, e1, 0, ...}
+template <typename TM> __device__ __forceinline__ u32x4_t aux_chunk(float e0, float e1);
+template <> __device__ __forceinline__ u32x4_t aux_chunk<float>(float e0, float e1) { return u32x4_t{__float_as_uint(e0), __float_as_uint(e1), 0u, 0u}; }
+template <> __device__ __forceinline__ u32x4_t aux_chunk<bf16_t>(float e0, float e1) { return u32x4_t{pack_bf16x2(e0, e1), 0u, 0u, 0u}; }
+template <typename TM> __device__ __forceinline__ TM op_from_float(float x);
+template <> __device__ __forceinline__ float op_from_float<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t op_from_float<bf16_t>(float x) { bf16_t r; r.v = (uint16_t)pack_bf16x2(x, 0.f); return r; }
+
+// The attention kernel is VALU-bound on MI355X (v_exp_f32 is quarter rate and every score used to cost a scale-fma,
+// a max, a subtract, an exp, a sum-add and half a convert), while its MFMA pipe idles.  So everything except max / exp /
+// convert is pushed INTO the MFMAs:
+//   * the softmax scale (in log2 units) is folded into Q once, at load;
+//   * every K row carries an extra "aux" k-slab {1, bias(key), 0...} and every Q fragment the matching {-m_ref, 1, 0...}:
+//     the score MFMA returns  s*scale*log2e + bias - m_ref  directly (mask bias and tail-key -inf included);
+//   * m_ref is a per-query REFERENCE, not the running maximum: probabilities are exp2(score - m_ref) for a whole run of
+//     tiles and only when some score exceeds m_ref by 2^12 are accumulators and reference moved (softmax is
+//     shift-invariant, so any common reference is exact; it is kept representable in the operand type so the shift done
+//     by the MFMA is exact too);
+//   * V^T carries a row of ones, so the PV MFMA also accumulates the denominator (of the SAME rounded probabilities
+//     that build the numerator): no per-score add, no separate running sum.
 template <typename TM, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
-  constexpr int NS = HD * SZ / 32;        // 32-B d-slabs per key row (QK^T k-steps)
-  constexpr int KROWB = HD * SZ + 16;     // K tile row bytes   (stride = 4*odd dwords)
+  constexpr int NS = HD * SZ / 32;        // 32-B d-slabs per key row (QK^T k-steps), + 1 aux slab
+  constexpr int KROWB = HD * SZ + 48;     // K tile row bytes: HD elements, 32-B aux slab, pad (stride = 4*odd dwords)
   constexpr int VROWB = 64 * SZ + 16;     // V^T tile row bytes (64 keys)
-  constexpr int HDP = (HD + 31) / 32 * 32;
-  constexpr int DT = HDP / 32;
+  constexpr int HDX = (HD + 1 + 31) / 32 * 32;   // V^T rows: HD value rows + the ones row (row HD), padded to 32
+  constexpr int DT = HDX / 32;
   constexpr int NSL = SZ;                 // 32-B key-slabs per 32-key sub-tile (f32: 4x8 keys, bf16: 2x16 keys)
-  constexpr int KBYTES = 64 * KROWB, VBYTES = HDP * VROWB;
-  constexpr int STAGE = KBYTES + VBYTES + 64 * 4;
+  constexpr int KBYTES = 64 * KROWB, VBYTES = HDX * VROWB;
+  constexpr int STAGE = KBYTES + VBYTES;
   constexpr int PPR = HD * SZ / 16;       // 16-B pieces per key row
   constexpr int NPIECE = 64 * PPR;        // pieces per K (or V) tile
   constexpr int UPT = (NPIECE + 255) / 256;
+  constexpr float THRESH = 12.0f;         // move the reference when a score exceeds it by more than this (log2 units)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,21 +137,40 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   }
   const int q = qb * 128 + wave * 32 + l31;
   const float LOG2E = 1.4426950408889634f;
-  const float sc2 = a.scale * LOG2E;      // scores are kept in log2 units: t = s*sc2 (+ bias*log2e)
+  const float sc2 = a.scale * LOG2E;      // scores are kept in log2 units
 
-  // zero both stages once (V^T pad rows d >= HD must read as 0)
+  // zero both stages once (V^T pad rows and the aux slabs' tails must read as 0), then the constants
   for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4_t*>(smem + i) = u32x4_t{0, 0, 0, 0};
+  __syncthreads();
+  if (tid < 128) {                         // K aux element 0 = 1 for every key row of both stages
+    char* Ks = smem + (tid >> 6) * STAGE;
+    *reinterpret_cast<TM*>(Ks + (tid & 63) * KROWB + HD * SZ) = op_from_float<TM>(1.0f);
+  } else {                                 // V^T row HD = ones (64 keys) in both stages
+    const int st = (tid - 128) >> 6, key = tid & 63;
+    *reinterpret_cast<TM*>(smem + st * STAGE + KBYTES + HD * VROWB + key * SZ) = op_from_float<TM>(1.0f);
+  }
 
-  // ---- Q fragments (B operand of S^T = K Q^T): lane (q, hi) holds d = s*2*EPC + hi*EPC .. +EPC
+  // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2e: lane (q, hi) holds d = s*2*EPC + hi*EPC .. +EPC
   u32x4_t qf[NS];
   {
     const TM* qp = reinterpret_cast<const TM*>(a.q) + ((size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldq + h * HD);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      qf[s] = *reinterpret_cast<const u32x4_t*>(qp + s * 2 * EPC + hi * EPC);
+      const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(qp + s * 2 * EPC + hi * EPC);
+      if constexpr (SZ == 4) {
+        qf[s] = u32x4_t{__float_as_uint(__uint_as_float(raw.x) * sc2), __float_as_uint(__uint_as_float(raw.y) * sc2),
+                        __float_as_uint(__uint_as_float(raw.z) * sc2), __float_as_uint(__uint_as_float(raw.w) * sc2)};
+      } else {
+        auto sc = [&](uint32_t w) __attribute__((always_inline)) {
+          return pack_bf16x2(__uint_as_float(w << 16) * sc2, __uint_as_float(w & 0xffff0000u) * sc2);
+        };
+        qf[s] = u32x4_t{sc(raw.x), sc(raw.y), sc(raw.z), sc(raw.w)};
+      }
       if (q >= a.Lq) qf[s] = u32x4_t{0, 0, 0, 0};
     }
   }
+  float m_ref = 0.f;                       // softmax reference of this lane's query (operand-representable)
+  u32x4_t qaux = hi == 0 ? aux_chunk<TM>(-m_ref, 1.0f) : u32x4_t{0, 0, 0, 0};
 
   const TM* kbase = reinterpret_cast<const TM*>(a.k) + (size_t)b * a.Lk * a.ldk + h * HD;
   const TM* vbase = reinterpret_cast<const TM*>(a.v) + (size_t)b * a.Lk * a.ldv + h * HD;
@@ -159,7 +203,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   auto store_tile = [&](int stage) __attribute__((always_inline)) {
     char* Ks = smem + stage * STAGE;
     char* Vs = Ks + KBYTES;
-    float* Bs = reinterpret_cast<float*>(Vs + VBYTES);
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + 256 * i;
@@ -175,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         }
       }
     }
-    if (tid < 64) Bs[tid] = braw;
+    if (tid < 64) *reinterpret_cast<TM*>(Ks + tid * KROWB + HD * SZ + SZ) = op_from_float<TM>(braw);   // K aux element 1 = bias(key)
   };
 
   f32x16_t o[DT];
@@ -183,11 +226,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
 
   const int ntile = (a.Lk + 63) / 64;
-  __syncthreads();          // zero-fill done
   load_tile(0);
+  __syncthreads();          // constants written
   store_tile(0);
   __syncthreads();
 
@@ -195,72 +237,50 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     if (t + 1 < ntile) load_tile(t + 1);
     const char* Ks = smem + (t & 1) * STAGE;
     const char* Vs = Ks + KBYTES;
-    const float* Bs = reinterpret_cast<const float*>(Vs + VBYTES);
 
-    // ---- S^T[key][q] = sum_d K[key][d] * Q[q][d]   (two 32-key sub-tiles)
+    // ---- S'^T[key][q] = sum_d K[key][d] * (Q[q][d]*scale*log2e) + 1*(-m_ref[q]) + bias[key]*1   (two 32-key sub-tiles)
     f32x16_t s[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[k2][r] = 0.f;
+      const char* kr = Ks + (k2 * 32 + l31) * KROWB + hi * 16;
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) {
-        const u32x4_t kf = *reinterpret_cast<const u32x4_t*>(Ks + (k2 * 32 + l31) * KROWB + sl * 32 + hi * 16);
-        AMma<TM>::mma(s[k2], kf, qf[sl]);
-      }
+      for (int sl = 0; sl < NS; ++sl) AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + sl * 32), qf[sl]);
+      AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + NS * 32), qaux);
     }
-    // ---- to log2 units, additive bias (mask) and tail-key masking; lane's keys: k2*32 + 8*g + 4*hi + i
-    const bool need_bias = (bias != nullptr) || (t * 64 + 64 > a.Lk);
-    if (need_bias) {
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          const float4 bb = *reinterpret_cast<const float4*>(Bs + k2 * 32 + 8 * gq + 4 * hi);
-          s[k2][4 * gq + 0] = fmaf(s[k2][4 * gq + 0], sc2, bb.x); s[k2][4 * gq + 1] = fmaf(s[k2][4 * gq + 1], sc2, bb.y);
-          s[k2][4 * gq + 2] = fmaf(s[k2][4 * gq + 2], sc2, bb.z); s[k2][4 * gq + 3] = fmaf(s[k2][4 * gq + 3], sc2, bb.w);
-        }
-    }
-    // ---- online softmax (base-2), state per query = per lane (both lane halves agree on m)
+    // ---- reference check (per query = per lane; both lane halves agree): lane's keys are k2*32 + 8*g + 4*hi + i
     float mx = s[0][0];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
-    if (!need_bias) mx *= sc2;                       // sc2 > 0: max commutes with the scaling
     mx = half_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float psum = 0.f;
-    if (need_bias) {
+    if (t == 0 || __any(mx > THRESH)) {                 // wave-uniform; after the first tile this is rare
+      float target = t == 0 ? mx : fmaxf(mx, 0.f);
+      if (!(target > -INFINITY)) target = 0.f;          // nothing but masked keys so far
+      const float m_new = round_op<TM>(m_ref + target);
+      const float dsh = m_new - m_ref;
+      if (t > 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-dsh);    // dsh >= 0
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[k2][r] - m_new);
-          s[k2][r] = p;
-          psum += p;
-        }
-    } else {
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[k2][r], sc2, -m_new));
-          s[k2][r] = p;
-          psum += p;
-        }
+        for (int r = 0; r < 16; ++r) s[k2][r] -= dsh;
+      m_ref = m_new;
+      if (hi == 0) qaux = aux_chunk<TM>(-m_ref, 1.0f);
     }
-    l_run = l_run * alpha + psum;
-    if (__any(m_new > m_run)) {                      // wave-uniform: once the running max has settled alpha == 1 exactly
 #pragma unroll
-      for (int d = 0; d < DT; ++d)
+    for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-    }
-    m_run = m_new;
+      for (int r = 0; r < 16; ++r) s[k2][r] = __builtin_amdgcn_exp2f(s[k2][r]);
 
-    // ---- O^T[d][q] += sum_key V^T[d][key] * P^T[key][q]
+    // ---- [O^T ; l][d][q] += sum_key [V^T ; 1][d][key] * P^T[key][q]
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
 #pragma unroll
@@ -284,8 +304,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     __syncthreads();
   }
 
-  // ---- normalise and store O[q][h*HD + d]; lane holds d = dt*32 + 8*g + 4*hi + i
-  const float l_tot = half_sum(l_run);
+  // ---- normalise and store O[q][h*HD + d]; lane holds d = dt*32 + 8*g + 4*hi + i.  The denominator is row HD of the
+  // accumulator: block HD/32, register ((HD%32)/8)*4, lane half 0 -> broadcast to both halves
+  constexpr int LB = HD / 32, LR = ((HD % 32) / 8) * 4;
+  static_assert(HD % 32 == 0 || HD % 32 == 16, "ones row must sit at row 0 or 16 of its 32-row block");
+  const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[LB][LR]), __float_as_uint(o[LB][LR]), false, false);
+  const float l_tot = __uint_as_float(lsw[0]);
   const float inv = 1.0f / l_tot;
   if (q < a.Lq) {
     TM* op = reinterpret_cast<TM*>(a.out) + ((size_t)(b * a.Lq + q) * a.ldo + h * HD);
@@ -301,8 +325,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
 template <typename TM, int HD> static constexpr size_t attn_lds() {
   constexpr int SZ = AMma<TM>::SZ;
-  constexpr int HDP = (HD + 31) / 32 * 32;
-  return 2 * (size_t)(64 * (HD * SZ + 16) + HDP * (64 * SZ + 16) + 64 * 4);
+  constexpr int HDX = (HD + 1 + 31) / 32 * 32;
+  return 2 * (size_t)(64 * (HD * SZ + 48) + HDX * (64 * SZ + 16));
 }
 
 template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
