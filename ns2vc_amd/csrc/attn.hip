@@ -30,6 +30,13 @@ template <> struct AMma<float> {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
   }
+  __device__ static __forceinline__ f32x16_t mma0(const u32x4_t& a, const u32x4_t& b) {   // acc = a*b (srcC = inline 0)
+    f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    return acc;
+  }
   // position (in elements) of key `key` (0..31) inside a 32-key V^T sub-row
   __device__ static __forceinline__ int vpos(int key) { return key; }
 };
@@ -40,6 +47,12 @@ template <> struct AMma<bf16_t> {
     U ua, ub;
     ua.u = a; ub.u = b;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x16_t mma0(const u32x4_t& a, const u32x4_t& b) {   // acc = a*b (srcC = inline 0)
+    union U { u32x4_t u; bf16x8_t v; };
+    U ua, ub;
+    ua.u = a; ub.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
   // swap key bits 2 and 3 so that the 8 keys one lane-half contributes to a
   // 16-key MFMA k-slab are contiguous (see header comment of attn_kernel)
@@ -242,12 +255,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     f32x16_t s[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[k2][r] = 0.f;
       const char* kr = Ks + (k2 * 32 + l31) * KROWB + hi * 16;
+      s[k2] = AMma<TM>::mma0(*reinterpret_cast<const u32x4_t*>(kr + NS * 32), qaux);      // aux slab first: no zero-init movs
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + sl * 32), qf[sl]);
-      AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + NS * 32), qaux);
     }
     // ---- reference check (per query = per lane; both lane halves agree): lane's keys are k2*32 + 8*g + 4*hi + i
     float mx = s[0][0];
