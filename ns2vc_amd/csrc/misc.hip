@@ -137,12 +137,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
     if (lane == 0) {
-      const double n = (double)T * (double)Cg;
-      const double mean = ds / n;
-      double var = dq / n - mean * mean;
+      // double only where it matters (E[x^2] - mean^2 cancels); reciprocal and rsqrt in fp32 (+1 Newton step): a double
+      // divide / sqrt is a ~300-cycle software sequence and every workgroup sits on this chain before it can store
+      const float inv_nf = 1.0f / ((float)T * (float)Cg);
+      const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));   // refine to ~double accuracy
+      const double mean = ds * inv_n;
+      double var = dq * inv_n - mean * mean;
       if (var < 0.0) var = 0.0;
+      const float ve = (float)var + eps;
+      float r = rsqrtf(ve);
+      r = r * (1.5f - 0.5f * ve * r * r);
       s_mean[g] = (float)mean;
-      s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+      s_rstd[g] = r;
     }
   }
   __syncthreads();
