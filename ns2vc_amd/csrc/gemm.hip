@@ -588,56 +588,87 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   LnRaw lnraw;                         // LayerNorm-by-linearity consumer: pairs of the lane's epilogue row, in flight during the K loop
   if constexpr (LNC) ln_row_load(g, m0 + wm * (BM / 2) + (lane >> 4) * 32 + kg * 16 + (lane & 15), lane < 16 * (BM / 64), lnraw);
 
-  // ---- DMA coordinates: piece j of this thread = tile row j*64 + tid/8, physical 16-B chunk tid%8
+  // ---- DMA coordinates: piece j of this thread = tile row j*64 + tid/8, physical 16-B chunk tid%8.
+  // Everything per-lane is a 32-bit byte offset computed ONCE (per piece, tap and source tensor); the K position of a
+  // tile is a scalar added by the hardware (buffer addressing), rows in the zero padding / past M are out-of-range
+  // offsets that the DMA turns into zeros.  The K loop carries no address arithmetic.
   const int prow = tid >> 3, pchunk = tid & 7;
   const int Ctot = g.c0 + g.c1;
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
   const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
   const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
-  int rt0[LA], rt1[LA], rt2[LA];
-  const int acol = (pchunk ^ ((prow >> 1) & 7)) * EPC;          // source-side swizzle (row j*64+prow: same (row>>1)&7)
+  constexpr unsigned SZB = sizeof(TM);
+  const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;      // source-side swizzle, bytes
+  unsigned p0t0[LA], p0t1[LA], p0t2[LA], p1t0[LA], p1t1[LA], p1t2[LA], p2c[LA];    // [source tensor][tap] byte offsets
 #pragma unroll
   for (int j = 0; j < LA; ++j) {
     const int m = m0 + j * 64 + prow;
     const bool mok = m < g.M;
     const int b = mok ? m / g.Tout : 0;
     const int t = m - b * g.Tout;
-    auto src_row = [&](int tp) __attribute__((always_inline)) {
+    auto src_row = [&](int tp) __attribute__((always_inline)) {       // source row of tap tp, or -1 (zero padding / past M)
       const int u = t * smul + tp - toff;
       const bool ok = mok && (tp < g.taps) && (u >= 0) && (u < ulim);
       return ok ? b * g.Tin + min(u >> ushr, g.Tin - 1) : -1;
     };
-    rt0[j] = src_row(0); rt1[j] = src_row(1); rt2[j] = src_row(2);
+    auto off = [&](int row, int ld) __attribute__((always_inline)) { return row >= 0 ? (unsigned)row * (unsigned)ld * SZB + acolb : DMA_OOB; };
+    const int r0 = src_row(0), r1 = src_row(1), r2 = src_row(2);
+    p0t0[j] = off(r0, g.lda0); p0t1[j] = off(r1, g.lda0); p0t2[j] = off(r2, g.lda0);
+    p1t0[j] = off(r0, g.lda1); p1t1[j] = off(r1, g.lda1); p1t2[j] = off(r2, g.lda1);
+    p2c[j] = off(toff == 0 ? r0 : r1, g.lda2);                         // the fused 1x1 segment reads the centre tap's rows
   }
-  const TM* wrow[LB];
+  unsigned vw[LB];
 #pragma unroll
-  for (int j = 0; j < LB; ++j) wrow[j] = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + j * 64 + prow) * g.K + acol);
-  const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
+  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * 64 + prow) * (unsigned)g.K) * SZB + acolb;
+  const unsigned long long rowsA = (unsigned long long)g.B * g.Tin;
+  const i32x4_t rA0 = make_rsrc(g.a0, rowsA * g.lda0 * SZB);
+  const i32x4_t rA1 = make_rsrc(g.c1 ? g.a1 : g.a0, rowsA * (g.c1 ? g.lda1 : g.lda0) * SZB);
+  const i32x4_t rA2 = make_rsrc(g.c2 ? g.a2 : g.a0, rowsA * (g.c2 ? g.lda2 : g.lda0) * SZB);
+  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
 
+  // K-order walk state (tiles are issued strictly in order): tap, channel offset inside the tap, position in K
+  int is_tap = 0, is_cc = 0, is_k = 0;
   const int K1 = g.taps * Ctot;
-  auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
-    const int k0 = kt * BKE;
-    const bool seg2 = k0 >= K1;
-    const int k1 = seg2 ? 0 : k0;
-    const int tapq = k1 / Ctot;
-    const int tap = seg2 ? toff : tapq;
-    const int cc = k1 - tapq * Ctot;
-    const bool first = cc < g.c0;
-    const unsigned long long src = reinterpret_cast<unsigned long long>(seg2 ? g.a2 : (first ? g.a0 : g.a1));
-    const int ld = seg2 ? g.lda2 : (first ? g.lda0 : g.lda1);
-    const int csrc = (seg2 ? k0 - K1 : (first ? cc : cc - g.c0)) + acol;
+  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
     const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
+    // every branch below is wave-uniform: one fixed descriptor and one fixed offset register per DMA instruction
+    if (is_k >= K1) {
+      const unsigned so = (unsigned)(is_k - K1) * SZB;
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-      const int r = tap == 0 ? rt0[j] : (tap == 1 ? rt1[j] : rt2[j]);
-      const unsigned eoff = (unsigned)max(r, 0) * (unsigned)ld + (unsigned)csrc;
-      const unsigned long long pa = src + (unsigned long long)eoff * sizeof(TM);
-      glds16(reinterpret_cast<const void*>(r >= 0 ? pa : zero), sbase + j * 8192);
+      for (int j = 0; j < LA; ++j) blds16(rA2, p2c[j], so, sbase + j * 8192);
+    } else if (is_cc < g.c0) {
+      const unsigned so = (unsigned)is_cc * SZB;
+      if (is_tap == 0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t0[j], so, sbase + j * 8192);
+      } else if (is_tap == 1) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t1[j], so, sbase + j * 8192);
+      } else {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t2[j], so, sbase + j * 8192);
+      }
+    } else {
+      const unsigned so = (unsigned)(is_cc - g.c0) * SZB;
+      if (is_tap == 0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t0[j], so, sbase + j * 8192);
+      } else if (is_tap == 1) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t1[j], so, sbase + j * 8192);
+      } else {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t2[j], so, sbase + j * 8192);
+      }
     }
     const unsigned bbase = sbase + BM * TROW;
+    const unsigned soffW = (unsigned)is_k * SZB;
 #pragma unroll
-    for (int j = 0; j < LB; ++j) glds16(wrow[j] + k0, bbase + j * 8192);
+    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * 8192);
+    is_k += BKE;
+    is_cc += BKE;
+    if (is_cc >= Ctot) { is_cc = 0; ++is_tap; }
   };
 
   f32x16_t acc[MT][NT];
@@ -652,7 +683,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   NS2VC_STAMP(1);
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_tile(s, s);
+    if (s < nk) issue_tile(s);
   NS2VC_STAMP(2);
 
   const int l31 = lane & 31, hi = lane >> 5;
@@ -670,7 +701,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
       if (kt + STAGES - 1 < nk) {
         int st2 = stage + STAGES - 1;
         if (st2 >= STAGES) st2 -= STAGES;
-        issue_tile(kt + STAGES - 1, st2);
+        issue_tile(st2);
       }
     };
     auto multiply = [&]() __attribute__((always_inline)) {
@@ -694,7 +725,9 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
     };
     // The two K halves run the step in opposite order, so the CU's load path and its MFMA pipes are both busy all
     // the time instead of alternating (the refill target, the stage of tile kt-1, is free for everyone after the barrier).
-    if (kg == 0) { refill(); multiply(); } else { multiply(); refill(); }
+    if (kg == 0) refill();       // (one copy of the MFMA block: two would make hipcc shuffle the accumulators between register sets)
+    multiply();
+    if (kg != 0) refill();
     if (++stage == STAGES) stage = 0;
   }
 

@@ -124,6 +124,28 @@ __global__ __launch_bounds__(256) void probe_tiles(const Args a) {
   if (lane == 0) { a.out[2 * gw] = t0; a.out[2 * gw + 1] = t1; }
 }
 
+// semantics check: what does an out-of-range lane of `buffer_load_dwordx4 ... lds` leave in LDS?  (the GEMM relies on it
+// writing zeros for padded / out-of-bounds rows); also checks the SGPR soffset form
+__global__ void oob_check(const char* src, unsigned nbytes, unsigned* out) {
+  __shared__ __attribute__((aligned(16))) unsigned buf[256 * 4];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 1024; i += 64) buf[i] = 0xAAAAAAAAu;
+  __syncthreads();
+  i32x4_t rsrc;
+  const unsigned long long p = reinterpret_cast<unsigned long long>(src);
+  rsrc.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p); rsrc.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(p >> 32));
+  rsrc.z = (int)nbytes; rsrc.w = 0x00020000;
+  const unsigned voff = (lane & 1) ? 0xFFFFFFF0u : (unsigned)lane * 16u;     // odd lanes out of range
+  const unsigned lds = (unsigned)(size_t)buf;
+  const unsigned soff = 1024;                                                // scalar offset: second KB of the source
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds), "s"(soff) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int i = lane; i < 256; i += 64) out[i] = buf[i];
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 template <int MODE, int INF>
@@ -190,7 +212,28 @@ static void run_tiles(char* pool, size_t pool_bytes, unsigned stride, int blocks
   fflush(stdout);
 }
 
+static void run_oob() {
+  char* src; unsigned* out;
+  CK(hipMalloc(&src, 4096)); CK(hipMalloc(&out, 1024));
+  std::vector<unsigned> h(1024);
+  for (int i = 0; i < 1024; ++i) h[i] = 0x1000u + i;
+  CK(hipMemcpy(src, h.data(), 4096, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(oob_check, dim3(1), dim3(64), 0, 0, src, 4096u, out);
+  std::vector<unsigned> r(256);
+  CK(hipMemcpy(r.data(), out, 1024, hipMemcpyDeviceToHost));
+  int ok_valid = 0, zero_oob = 0, stale_oob = 0;
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < 4; ++e) {
+      const unsigned v = r[l * 4 + e];
+      if (l & 1) { zero_oob += v == 0; stale_oob += v == 0xAAAAAAAAu; }
+      else ok_valid += v == 0x1000u + 256 + l * 4 + e;         // soffset 1024 B = 256 dwords
+    }
+  printf("buffer_load..lds out-of-range lanes: %d/128 dwords zero, %d/128 stale; in-range lanes with SGPR soffset: %d/128 correct\n", zero_oob, stale_oob, ok_valid);
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
+  run_oob();
   const size_t pool_bytes = (size_t)786432 * 1024;   // 768 MB: 2048 pieces at the largest stride, or a pool beyond the 256 MB Infinity Cache
   char* pool;
   unsigned long long* dout;

@@ -15,7 +15,12 @@ cases = [("L0.conv3", 30016, 128, 384, 3, 0, "f32", (64, 128, 2)), ("L1.geglu", 
          ("L0.conv3", 30016, 128, 384, 3, 0, "f32", (128, 128, 13)), ("L0.ff_out", 30016, 128, 512, 1, 0, "f32", (128, 128, 13)),
          ("L1.geglu", 15008, 2048, 256, 1, 1, "op", (128, 128, 12)), ("L1.ff_out", 15008, 256, 1024, 1, 0, "f32", (128, 128, 13)),
          ("L1.ff_out", 15008, 256, 1024, 1, 0, "f32", (64, 128, 13)), ("L1.ff_out", 15008, 256, 1024, 1, 0, "f32", (64, 128, 2)),
-         ("L3.conv3big", 3776, 512, 3072, 3, 0, "f32", (64, 128, 13))]
+         ("L3.conv3big", 3776, 512, 3072, 3, 0, "f32", (64, 128, 13)),
+         # latency floor: a handful of workgroups on an otherwise idle chip
+         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 13)), ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 12)),
+         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 14)),
+         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 2)), ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 3)),
+         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 64, 4)), ("tiny.lin", 192, 128, 128, 1, 0, "f32", (64, 128, 13))]
 for name, M, N, K, taps, geglu, outk, cfg in cases:
     Cin = K // taps; Tt = M // 32; Bb = 32; M = Bb * Tt
     A = DevBuf(M * Cin * 2 + 4096); W = DevBuf(N * K * 2); bias = DevBuf.from_numpy(np.zeros(N, np.float32))
