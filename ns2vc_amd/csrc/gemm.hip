@@ -258,22 +258,23 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
   LnRaw lnraw;                         // LayerNorm-by-linearity consumer: this lane's row pairs (see gemm_epilogue)
   if constexpr (LNC) ln_row_load(g, m0 + wm * (BM / 2) + lane, lane < BM / 2, lnraw);
 
-  // ---- per-thread DMA coordinates: piece i = tid + 256*j covers tile row i>>3, physical chunk i&7
+  // ---- per-thread DMA coordinates: piece i = tid + 256*j covers tile row i>>3, physical chunk i&7.  Buffer-descriptor
+  // DMA as in gemm4_kernel: per-lane byte offsets computed once per (piece, tap, source tensor), the K position of a
+  // tile in an SGPR, padded taps / rows past M as out-of-range offsets (the DMA writes zeros).
   const int prow = tid >> 3;                 // row inside a 32-row pass
   const int pchunk = tid & 7;
   const int Ctot = g.c0 + g.c1;
-  // Source row index per (piece, tap), or -1 when the tap falls into the zero padding / past M.
-  // Unified index math: u = t*smul + tap - toff; valid iff 0 <= u < ulim; row = min(u >> ushr, Tin-1).
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
   const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
   const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
-  int rt0[LA], rt1[LA], rt2[LA], acol[LA];
+  constexpr unsigned SZB = sizeof(TM);
+  unsigned p0t0[LA], p0t1[LA], p0t2[LA], p1t0[LA], p1t1[LA], p1t2[LA], p2c[LA];    // [source tensor][tap] byte offsets
 #pragma unroll
   for (int j = 0; j < LA; ++j) {
     const int row = j * 32 + prow;
     const int m = m0 + row;
-    acol[j] = (pchunk ^ ((row >> 1) & 7)) * EPC;      // logical chunk this lane fetches (source-side swizzle)
+    const unsigned acolb = (unsigned)((pchunk ^ ((row >> 1) & 7)) * EPC) * SZB;     // source-side swizzle, bytes
     const bool mok = m < g.M;
     const int b = mok ? m / g.Tout : 0;
     const int t = m - b * g.Tout;
@@ -282,40 +283,65 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
       const bool ok = mok && (tp < g.taps) && (u >= 0) && (u < ulim);
       return ok ? b * g.Tin + min(u >> ushr, g.Tin - 1) : -1;
     };
-    rt0[j] = src_row(0); rt1[j] = src_row(1); rt2[j] = src_row(2);
+    auto off = [&](int r, int ld) __attribute__((always_inline)) { return r >= 0 ? (unsigned)r * (unsigned)ld * SZB + acolb : DMA_OOB; };
+    const int r0 = src_row(0), r1 = src_row(1), r2 = src_row(2);
+    p0t0[j] = off(r0, g.lda0); p0t1[j] = off(r1, g.lda0); p0t2[j] = off(r2, g.lda0);
+    p1t0[j] = off(r0, g.lda1); p1t1[j] = off(r1, g.lda1); p1t2[j] = off(r2, g.lda1);
+    p2c[j] = off(toff == 0 ? r0 : r1, g.lda2);
   }
-  const TM* wrow[LB];
+  unsigned vw[LB];
 #pragma unroll
   for (int j = 0; j < LB; ++j) {
     const int row = j * 32 + prow;
-    wrow[j] = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + row) * g.K + (pchunk ^ ((row >> 1) & 7)) * EPC);
+    vw[j] = ((unsigned)(n0 + row) * (unsigned)g.K + (unsigned)((pchunk ^ ((row >> 1) & 7)) * EPC)) * SZB;
   }
-  const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
+  const unsigned long long rowsA = (unsigned long long)g.B * g.Tin;
+  const i32x4_t rA0 = make_rsrc(g.a0, rowsA * g.lda0 * SZB);
+  const i32x4_t rA1 = make_rsrc(g.c1 ? g.a1 : g.a0, rowsA * (g.c1 ? g.lda1 : g.lda0) * SZB);
+  const i32x4_t rA2 = make_rsrc(g.c2 ? g.a2 : g.a0, rowsA * (g.c2 ? g.lda2 : g.lda0) * SZB);
+  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
 
   const int K1 = g.taps * Ctot;                      // K of the main (conv / linear) segment; the rest is the fused 1x1 segment
   auto issue_tile = [&](int kt, int stage) __attribute__((always_inline)) {
     const int k0 = kt * BKE;
-    const bool seg2 = k0 >= K1;                      // block-uniform
+    const bool seg2 = k0 >= K1;                      // every branch here is wave-uniform
     const int k1 = seg2 ? 0 : k0;
-    const int tapq = k1 / Ctot;
-    const int tap = seg2 ? toff : tapq;              // the fused 1x1 segment reads the centre tap's rows
-    const int cc = k1 - tapq * Ctot;
-    const bool first = cc < g.c0;
-    const unsigned long long src = reinterpret_cast<unsigned long long>(seg2 ? g.a2 : (first ? g.a0 : g.a1));
-    const int ld = seg2 ? g.lda2 : (first ? g.lda0 : g.lda1);
-    const int csrc = seg2 ? k0 - K1 : (first ? cc : cc - g.c0);
+    const int tap = k1 / Ctot;
+    const int cc = k1 - tap * Ctot;
     const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
+    if (seg2) {
+      const unsigned so = (unsigned)(k0 - K1) * SZB;
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-      const int r = tap == 0 ? rt0[j] : (tap == 1 ? rt1[j] : rt2[j]);
-      const unsigned eoff = (unsigned)max(r, 0) * (unsigned)ld + (unsigned)(csrc + acol[j]);
-      const unsigned long long pa = src + (unsigned long long)eoff * sizeof(TM);
-      const unsigned long long p = r >= 0 ? pa : zero;
-      glds16(reinterpret_cast<const void*>(p), sbase + j * 4096);
+      for (int j = 0; j < LA; ++j) blds16(rA2, p2c[j], so, sbase + j * 4096);
+    } else if (cc < g.c0) {
+      const unsigned so = (unsigned)cc * SZB;
+      if (tap == 0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t0[j], so, sbase + j * 4096);
+      } else if (tap == 1) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t1[j], so, sbase + j * 4096);
+      } else {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t2[j], so, sbase + j * 4096);
+      }
+    } else {
+      const unsigned so = (unsigned)(cc - g.c0) * SZB;
+      if (tap == 0) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t0[j], so, sbase + j * 4096);
+      } else if (tap == 1) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t1[j], so, sbase + j * 4096);
+      } else {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t2[j], so, sbase + j * 4096);
+      }
     }
     const unsigned bbase = sbase + BM * TROW;
+    const unsigned soffW = (unsigned)k0 * SZB;
 #pragma unroll
-    for (int j = 0; j < LB; ++j) glds16(wrow[j] + k0, bbase + j * 4096);
+    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * 4096);
   };
 
   f32x16_t acc[MT][NT];
@@ -914,19 +940,24 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
     bm = g_force_bm; bn = g_force_bn; st = g_force_st ? g_force_st : 3;
     if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return hipErrorInvalidValue;
   } else {
-    // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01.txt):
-    // these GEMMs are short (7-35 us) and latency/occupancy-bound, so the small-LDS configurations that keep
-    // 3-5 workgroups resident per CU win; deeper rings only pay for long K at small M.
     (void)blocks;
+    // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01d_bufferdma.txt).
+    // The 8-wave K-split kernel with buffer-descriptor DMA (stages 12..14 = ring 2..4) wins everywhere except the
+    // narrowest GEGLU; 128-row tiles pay off once K is long (>= 12 tiles) or N is wide, and only while the grid still
+    // covers the chip (M >= ~7000 rows).
+    const bool big_m = g.M >= 7000;
     if (g.geglu) {
       if (!n128) return hipErrorInvalidValue;
-      bm = 64; bn = 128; st = 2;
-    } else if (n128 && g.N <= 512 && (g.rowstats || !(g.N == 384 && nk <= 6))) {
-      // narrow outputs (every conv and the to_out / proj / ff-out linears): the 8-wave K-split kernel, 3-deep ring.
-      // Equal or a few % ahead at levels 0-2 and 20-25 % ahead at level 3 (profiles/gemm_sweep_r01c_ksplit.txt)
-      bm = 64; bn = 128; st = 13;
-    } else if (n128 && (g.M >= 12000 || g.N >= 1024)) {
-      bm = 64; bn = 128; st = nk >= 24 ? 3 : 2;
+      if (g.N >= 2048) { bm = 128; bn = 128; st = 12; }
+      else { bm = 64; bn = 128; st = 2; }
+    } else if (n128 && g.N <= 512) {
+      // narrow outputs: every conv and the to_out / proj / ff-out linears (and all LayerNorm-statistics producers)
+      bn = 128; st = 13;
+      bm = (big_m && nk >= 12) ? 128 : 64;
+      if (g.M >= 12000 && g.N > 128 && nk <= 2) { bm = 128; st = 12; }     // level-0 q|k|v: short K, wide-ish N
+    } else if (n128) {
+      bn = 128;
+      if (g.M >= 12000) { bm = 128; st = 12; } else { bm = 64; st = 13; }
     } else {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
