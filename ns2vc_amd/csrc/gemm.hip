@@ -164,8 +164,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
     if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
     if constexpr (lnc) ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
     // optional GroupNorm statistics of the result: this wave's rows belong to batch b0 or b0+1 (Tout >= WM)
-    const int b0 = min(mw0, g.M - 1) / g.Tout;
-    const int mB = (b0 + 1) * g.Tout;                          // first row of the next batch item
+    const int b0 = g.stats ? min(mw0, g.M - 1) / g.Tout : 0;     // (division only when the statistics are wanted)
+    const int mB = g.stats ? (b0 + 1) * g.Tout : 0x7fffffff;    // first row of the next batch item
     float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
     constexpr int RB = NIT < 8 ? NIT : 8;                      // residual rows fetched per batch (before any store:
 #pragma unroll                                                 //  res may alias out_f32 element-for-element)
@@ -270,12 +270,18 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
   const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
   constexpr unsigned SZB = sizeof(TM);
   unsigned p0t0[LA], p0t1[LA], p0t2[LA], p1t0[LA], p1t1[LA], p1t2[LA], p2c[LA];    // [source tensor][tap] byte offsets
+  const bool plain = g.taps == 1 && g.tmode == TMODE_SAME && g.c1 == 0 && g.c2 == 0;   // a linear: source row == output row
 #pragma unroll
   for (int j = 0; j < LA; ++j) {
     const int row = j * 32 + prow;
     const int m = m0 + row;
     const unsigned acolb = (unsigned)((pchunk ^ ((row >> 1) & 7)) * EPC) * SZB;     // source-side swizzle, bytes
     const bool mok = m < g.M;
+    if (plain) {          // (wave-uniform) no integer division, one offset instead of seven
+      p0t0[j] = mok ? (unsigned)m * (unsigned)g.lda0 * SZB + acolb : DMA_OOB;
+      p0t1[j] = p0t2[j] = p1t0[j] = p1t1[j] = p1t2[j] = p2c[j] = DMA_OOB;
+      continue;
+    }
     const int b = mok ? m / g.Tout : 0;
     const int t = m - b * g.Tout;
     auto src_row = [&](int tp) __attribute__((always_inline)) {
@@ -627,10 +633,16 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   constexpr unsigned SZB = sizeof(TM);
   const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;      // source-side swizzle, bytes
   unsigned p0t0[LA], p0t1[LA], p0t2[LA], p1t0[LA], p1t1[LA], p1t2[LA], p2c[LA];    // [source tensor][tap] byte offsets
+  const bool plain = g.taps == 1 && g.tmode == TMODE_SAME && g.c1 == 0 && g.c2 == 0;   // a linear: source row == output row
 #pragma unroll
   for (int j = 0; j < LA; ++j) {
     const int m = m0 + j * 64 + prow;
     const bool mok = m < g.M;
+    if (plain) {          // (wave-uniform) skips the integer division and six of the seven offsets: most launches are linears
+      p0t0[j] = mok ? (unsigned)m * (unsigned)g.lda0 * SZB + acolb : DMA_OOB;
+      p0t1[j] = p0t2[j] = p1t0[j] = p1t1[j] = p1t2[j] = p2c[j] = DMA_OOB;
+      continue;
+    }
     const int b = mok ? m / g.Tout : 0;
     const int t = m - b * g.Tout;
     auto src_row = [&](int tp) __attribute__((always_inline)) {       // source row of tap tp, or -1 (zero padding / past M)
@@ -768,8 +780,8 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   float* of = g.out_f32;
   TM* oo = reinterpret_cast<TM*>(g.out_op);
   const int mw0 = m0 + wm * WM;                     // first row of the wave tile (both K halves)
-  const int b0 = min(mw0, g.M - 1) / g.Tout;
-  const int mB = (b0 + 1) * g.Tout;
+  const int b0 = g.stats ? min(mw0, g.M - 1) / g.Tout : 0;       // (division only when the statistics are wanted)
+  const int mB = g.stats ? (b0 + 1) * g.Tout : 0x7fffffff;
   float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
   constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = 16 / RPI;    // 16 lanes per row, 4 rows per pass, 4 passes
   const int rsub = lane / LPR, cq = lane % LPR;
