@@ -220,7 +220,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if NS2VC_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only so that the last stamp includes the store drain)
+#endif
   NS2VC_STAMP(6);
 }
 
@@ -892,7 +894,9 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if NS2VC_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only so that the last stamp includes the store drain)
+#endif
   NS2VC_STAMP(6);
 }
 
