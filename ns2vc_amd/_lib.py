@@ -54,6 +54,8 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("bias", C.c_void_p), ("scale", C.c_float),
         ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("xq", C.c_void_p), ("ldx", C.c_int32), ("xdim", C.c_int32), ("wq", C.c_void_p), ("bq", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
     ]
 
 

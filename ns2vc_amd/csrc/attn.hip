@@ -113,7 +113,7 @@ template <> __device__ __forceinline__ bf16_t op_from_float<bf16_t>(float x) { b
 //     by the MFMA is exact too);
 //   * V^T carries a row of ones, so the PV MFMA also accumulates the denominator (of the SAME rounded probabilities
 //     that build the numerator): no per-score add, no separate running sum.
-template <typename TM, int HD>
+template <typename TM, int HD, bool QPROJ>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
   // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2e: lane (q, hi) holds d = s*2*EPC + hi*EPC .. +EPC
   u32x4_t qf[NS];
-  {
+  if constexpr (!QPROJ) {
     const TM* qp = reinterpret_cast<const TM*>(a.q) + ((size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldq + h * HD);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -180,6 +180,89 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         qf[s] = u32x4_t{sc(raw.x), sc(raw.y), sc(raw.z), sc(raw.w)};
       }
       if (q >= a.Lq) qf[s] = u32x4_t{0, 0, 0, 0};
+    }
+  } else {
+    // Fused query projection: Q^T[d][q] = sum_c Wq[h*HD + d][c] * x[q][c] on the MFMA (A = weight rows, B = this wave's
+    // 32 input rows, both straight from global memory / L2 -- the launch of a separate to_q GEMM is gone), then bias,
+    // LayerNorm-by-linearity fix-up and the softmax scale in registers, and a half-wave exchange turns the
+    // accumulator layout (4 consecutive d per lane half) into the B-operand layout (EPC consecutive d).
+    constexpr int DB = (HD + 31) / 32;
+    f32x16_t qa[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
+    const TM* xr = reinterpret_cast<const TM*>(a.xq) + (size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldx + hi * EPC;
+    const TM* wr = reinterpret_cast<const TM*>(a.wq) + (size_t)(h * HD + l31) * a.xdim + hi * EPC;
+    const int nks = a.xdim / (2 * EPC);
+    for (int k0 = 0; k0 < nks; k0 += 4) {
+      u32x4_t xf[4], wf[4][DB];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = k0 + u < nks;
+        xf[u] = in ? *reinterpret_cast<const u32x4_t*>(xr + (k0 + u) * 2 * EPC) : u32x4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+          wf[u][db] = (in && db * 32 + l31 < HD) ? *reinterpret_cast<const u32x4_t*>(wr + (size_t)db * 32 * a.xdim + (k0 + u) * 2 * EPC)
+                                                 : u32x4_t{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) AMma<TM>::mma(qa[db], wf[u][db], xf[u]);
+    }
+    // this lane's query row statistics (both lane halves hold the same query)
+    float mu = 0.f, rs = 1.f;
+    if (a.ln_stats) {
+      const int n4 = a.ln_dim >> 7;
+      const float4* p = reinterpret_cast<const float4*>(a.ln_stats + (size_t)(b * a.Lq + min(q, a.Lq - 1)) * (a.ln_dim >> 6) * 2);
+      float sm = 0.f, sq = 0.f;
+      for (int i = 0; i < n4; ++i) { const float4 v = p[i]; sm += v.x + v.z; sq += v.y + v.w; }
+      const float inv = 1.0f / (float)a.ln_dim;
+      mu = sm * inv;
+      double var = (double)sq * (double)inv - (double)mu * (double)mu;
+      if (var < 0.0) var = 0.0;
+      rs = 1.0f / sqrtf((float)var + a.ln_eps);
+    }
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int d0 = db * 32 + 8 * gq + 4 * hi;                 // rows of registers 4*gq .. 4*gq+3
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), ww = bb;
+        if (d0 < HD) {
+          if (a.bq) bb = *reinterpret_cast<const float4*>(a.bq + h * HD + d0);
+          if (a.ln_stats) ww = *reinterpret_cast<const float4*>(a.ln_wsum + h * HD + d0);
+        }
+        const float bbv[4] = {bb.x, bb.y, bb.z, bb.w}, wwv[4] = {ww.x, ww.y, ww.z, ww.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = rs * (qa[db][4 * gq + i] - mu * wwv[i]) + bbv[i];
+          qa[db][4 * gq + i] = (d0 < HD && q < a.Lq) ? round_op<TM>(v) * sc2 : 0.f;       // (the separate GEMM rounded Q to the operand type)
+        }
+      }
+    if constexpr (SZ == 4) {        // fp32: slab s = 8 d's, lane half hi owns d = 8s + 4hi .. +4 = registers 4*(s%4) .. +3 of block s/4
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const f32x16_t& blk = qa[s / 4];
+        const int r0 = 4 * (s % 4);
+        qf[s] = u32x4_t{__float_as_uint(blk[r0]), __float_as_uint(blk[r0 + 1]), __float_as_uint(blk[r0 + 2]), __float_as_uint(blk[r0 + 3])};
+      }
+    } else {                        // bf16: slab s = 16 d's = registers 8*(s%2) .. +7 of block s/2; exchange 4 of them with lane^32
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const f32x16_t& blk = qa[s / 2];
+        const int r0 = 8 * (s % 2);
+        float lo[4], hi4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          // vdst = rows 16ls+0..3 (+4hi), vsrc = rows 16ls+8..11 (+4hi): swap(vdst.upper, vsrc.lower)
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(blk[r0 + i]), __float_as_uint(blk[r0 + 4 + i]), false, false);
+          lo[i] = __uint_as_float(sw[0]);      // lower half: d 0..3        upper half: d 8..11
+          hi4[i] = __uint_as_float(sw[1]);     // lower half: d 4..7        upper half: d 12..15
+        }
+        qf[s] = u32x4_t{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi4[0], hi4[1]), pack_bf16x2(hi4[2], hi4[3])};
+      }
     }
   }
   float m_ref = 0.f;                       // softmax reference of this lane's query (operand-representable)
@@ -343,7 +426,8 @@ template <typename TM, int HD> static constexpr size_t attn_lds() {
 template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);
   const size_t lds = attn_lds<TM, HD>();
-  hipLaunchKernelGGL((attn_kernel<TM, HD>), grid, dim3(256), lds, s, a);
+  if (a.q) hipLaunchKernelGGL((attn_kernel<TM, HD, false>), grid, dim3(256), lds, s, a);
+  else hipLaunchKernelGGL((attn_kernel<TM, HD, true>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
@@ -358,7 +442,10 @@ template <typename TM> static hipError_t launch_tm(const AttnArgs& a, int hd, hi
 }
 
 template <typename TM, int HD> static hipError_t set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)attn_lds<TM, HD>());
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)attn_lds<TM, HD>());
 }
 hipError_t init_attn_attributes() {
@@ -376,7 +463,12 @@ hipError_t init_attn_attributes() {
 
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s) {
   const int al = prec == PREC_BF16 ? 7 : 3;      // rows must start 16-B aligned
-  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldq & al) || (a.ldk & al) || (a.ldv & al) || (a.ldo & 3)) return hipErrorInvalidValue;
+  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldk & al) || (a.ldv & al) || (a.ldo & 3)) return hipErrorInvalidValue;
+  if (a.q) { if (a.ldq & al) return hipErrorInvalidValue; }
+  else {     // fused query projection
+    if (!a.xq || !a.wq || (a.ldx & al) || a.xdim <= 0 || (a.xdim & 15)) return hipErrorInvalidValue;
+    if (a.ln_stats && (!a.ln_wsum || a.ln_dim <= 0 || (a.ln_dim & 127) || a.ln_dim > 512)) return hipErrorInvalidValue;
+  }
   return prec == PREC_BF16 ? launch_tm<bf16_t>(a, head_dim, s) : launch_tm<float>(a, head_dim, s);
 }
 

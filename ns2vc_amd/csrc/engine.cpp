@@ -123,6 +123,10 @@ struct ns2vc_unet {
   bool use_chains = false;
   // LayerNorm by linearity (csrc/gemm.hip): no normalisation pass; NS2VC_LN_LINEAR=0 restores the ln_apply kernels
   bool ln_linear = true;
+  // cross-attention to_q computed inside the attention kernel (csrc/attn.hip, NS2VC_FUSE_TOQ=1).  Correct and tested,
+  // but measured SLOWER on MI355X (attention +0.21 ms, GEMMs -0.16 ms per step): every head's workgroup re-reads the
+  // same input rows through the load path, 8x the bytes of the separate GEMM.  Off by default.
+  bool fuse_toq = false;
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -677,17 +681,21 @@ struct Planner {
     gemm(r.prefix + ".conv2", g2);
   }
 
+  // `proj` (optional): fused query projection -- only its xq/ldx/xdim/wq/bq/ln_* fields are read
   void attention(const std::string& name, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int Lq, int Lk,
-                 const float* bias, int hd, void* out, int ldo) {
+                 const float* bias, int hd, void* out, int ldo, const AttnArgs* proj = nullptr) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
+    if (proj) a = *proj;
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.B = B; a.H = h->cfg.heads; a.Lq = Lq; a.Lk = Lk; a.bias = bias;
     a.scale = 1.0f / std::sqrt((float)hd);
     a.out = out; a.ldo = ldo;
     const int pr = prec;
-    add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd,
-        (double)opsz * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
+    const double pf = proj ? 2.0 * B * (double)Lq * a.xdim * (a.H * hd) : 0.0;       // fused to_q projection
+    const double pb = proj ? (double)opsz * (B * (double)Lq * a.xdim + (double)a.xdim * a.H * hd) : (double)opsz * B * a.H * hd * Lq;
+    add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd + pf,
+        (double)opsz * B * a.H * hd * (Lq + 2.0 * Lk) + pb);
   }
 
   // Transformer2DModel + BasicTransformerBlock (transformer_1d.py:256-295, attention.py:130-203)
@@ -697,6 +705,8 @@ struct Planner {
     const std::string t = a.prefix + ".transformer_blocks.0";
     groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
     GemmArgs g;
+    AttnArgs qproj;
+    bool fuse_q = false;
     auto layernorm = [&](const std::string& nm) {
       add(nm, [=](hipStream_t s) { return launch_ln_apply_op(y, d, M, d, 1e-5f, yn, pr, s); }, 3, 8.0 * M * d, (4.0 + opsz) * M * d);
     };
@@ -733,14 +743,21 @@ struct Planner {
       g.rowstats = r2;
       gemm(t + ".attn1.to_out", g);
       if (!r2) layernorm(t + ".norm2");
-      g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
-      if (r2) { g.ln_stats = r2; g.ln_wsum = a.q2.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
-      gemm(t + ".attn2.to_q", g);
+      fuse_q = h->fuse_toq && (d % 16 == 0);
+      if (fuse_q) {          // attn2.to_q runs inside the cross-attention kernel (no launch, Q never touches HBM)
+        memset(&qproj, 0, sizeof(qproj));
+        qproj.xq = yn; qproj.ldx = d; qproj.xdim = d; qproj.wq = a.q2.w; qproj.bq = a.q2.bias;
+        if (r2) { qproj.ln_stats = r2; qproj.ln_wsum = a.q2.wsum; qproj.ln_eps = 1e-5f; qproj.ln_dim = d; }
+      } else {
+        g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
+        if (r2) { g.ln_stats = r2; g.ln_wsum = a.q2.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
+        gemm(t + ".attn2.to_q", g);
+      }
     }
     // cross attention (k|v hoisted into h->kv by set_condition)
     const int nkv = h->kv_all.N;
-    attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
-              h->has_mask ? h->maskbias : nullptr, hd, ao, d);
+    attention(t + (fuse_q ? ".attn2.to_q+sdpa" : ".attn2.sdpa"), fuse_q ? nullptr : qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
+              h->has_mask ? h->maskbias : nullptr, hd, ao, d, fuse_q ? &qproj : nullptr);
     float* r3 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs3 : nullptr;
     g = base(ao, d, d, Tl, Tl, a.o2, y, r3 ? yn : nullptr, d);
     g.res = y; g.ldres = d;
@@ -1045,6 +1062,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   h->cfg = *cfg;
   if (const char* e = getenv("NS2VC_USE_CHAINS")) h->use_chains = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_TOQ")) h->fuse_toq = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;

@@ -505,6 +505,71 @@ def test_attention(case, prec, diag):
     assert e < tol, (name, e)
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("ln", [False, True], ids=["plain", "ln_linear"])
+@pytest.mark.parametrize("hd,Lq,Lk", [(16, 150, 69), (32, 70, 130), (48, 33, 21), (64, 40, 200)])
+def test_attention_fused_query_projection(hd, Lq, Lk, ln, prec, diag):
+    """Cross-attention whose to_q projection (attention_processor.py:1013) runs inside the attention kernel:
+    Q = x @ Wq^T + bq, optionally with x the RAW input of a LayerNorm (statistics pairs + rowsum fix-up), against
+    numpy LayerNorm -> matmul -> masked softmax attention in fp64."""
+    from ns2vc_amd._lib import AttnArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    B, H = 2, 8
+    D = H * hd
+    rng = np.random.default_rng(hd * 1000 + Lq)
+    x = (rng.standard_normal((B, Lq, D)) + (1.5 * rng.standard_normal((B, Lq, 1)) if ln else 0.0)).astype(np.float32)
+    Wq = rnd(rng.standard_normal((D, D)) / np.sqrt(D), prec)
+    bq = (0.3 * rng.standard_normal(D)).astype(np.float32)
+    k = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    v = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    keep = rng.random((B, Lk)) > 0.3
+    keep[:, 0] = True
+    bias = np.where(keep, 0.0, -10000.0).astype(np.float32)
+    xr = rnd(x, prec).astype(np.float64)
+    if ln:
+        x64 = x.astype(np.float64)
+        xin = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5)
+    else:
+        xin = xr
+    q = xin @ Wq.astype(np.float64).T + bq
+    ref = ref_attention(rnd(q, prec), rnd(k, prec), rnd(v, prec), bias, H, prec)
+    esz = 2 if prec == 1 else 4
+    a = AttnArgs()
+    d_x, d_w = OpBuf(x, prec), _pack(Wq, prec)
+    d_bq = _dev(bq)
+    kv = np.concatenate([k, v], axis=-1)
+    d_kv = OpBuf(kv, prec)
+    a.k, a.v = d_kv.ptr, d_kv.ptr + D * esz
+    a.ldk = a.ldv = 2 * D
+    a.B, a.H, a.Lq, a.Lk = B, H, Lq, Lk
+    d_bias = _dev(bias)
+    a.bias = d_bias.ptr
+    a.scale = 1.0 / np.sqrt(hd)
+    d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
+    a.out, a.ldo = d_out.ptr, D
+    a.xq, a.ldx, a.xdim, a.wq, a.bq = d_x.ptr, D, D, d_w.value, d_bq.ptr
+    keepalive = []
+    if ln:
+        x64 = x.astype(np.float64).reshape(B * Lq, D // 64, 64)
+        st = np.stack([x64.sum(-1), (x64 ** 2).sum(-1)], axis=-1).astype(np.float32)
+        d_st = _dev(st)
+        ws = C.c_void_p()
+        Wc = np.ascontiguousarray(Wq, dtype=np.float32)
+        check(lib.ns2vc_weight_rowsum(Wc.ctypes.data, D, D, prec, C.byref(ws)), "rowsum")
+        a.ln_stats, a.ln_wsum, a.ln_eps, a.ln_dim = d_st.ptr, ws.value, 1e-5, D
+        keepalive += [d_st]
+    check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention (fused to_q)")
+    sync()
+    out = d_out.read((B, Lq, D))
+    e = rel_l2(out, ref)
+    diag(f"attn fused-to_q hd={hd} ln={ln} prec={prec} rel_l2={e:.3e} nan={int(np.isnan(out).sum())}")
+    assert e < (3e-5 if prec == 0 else 2e-2), e
+    lib.ns2vc_dev_free(d_w)
+    if ln:
+        lib.ns2vc_dev_free(ws)
+
+
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 128, 0), (2, 90, 512, 384), (3, 200, 384, 256), (1, 5, 128, 128), (2, 938, 128, 0)], ids=str)
