@@ -165,7 +165,7 @@ typedef struct ns2vc_attn_args {
    *   Q[m][h*hd + d] = sum_c xq[m][c] * wq[h*hd + d][c] + bq[h*hd + d]
    * is computed by the kernel itself (xq operand-typed [B*Lq][ldx], wq packed [H*hd][xdim] from ns2vc_pack_weight,
    * xdim % 16 == 0); with ln_stats != NULL, xq is the RAW input of a LayerNorm and the projection gets the same
-   * LayerNorm-by-linearity fix-up as ns2vc_gemm_args (ln_stats [B*Lq][ln_dim/64][2], ln_wsum [H*hd]). */
+   * LayerNorm-by-linearity fix-up as in the GEMM arguments: ln_stats [B*Lq][ln_dim/64][2], ln_wsum [H*hd]. */
   const void* xq; int32_t ldx, xdim; const void* wq; const float* bq;
   const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
 } ns2vc_attn_args;
