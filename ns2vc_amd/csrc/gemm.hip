@@ -9,11 +9,14 @@
 //
 // A is an "operand tensor": channels-last [B][Tin][C] already in the MFMA operand
 // type (bf16, or fp32 in parity mode) and already normalised/activated by the
-// producing kernel, so BOTH operands stream HBM/L2 -> LDS with global_load_lds
-// (16 B per lane, no VGPR round trip, no VALU in the main loop):
-//   * conv taps, stride 2 and nearest-upsample are per-lane SOURCE row indices
-//     (zero padding = a lane pointed at a zero page); the skip-connection concat
-//     is a two-pointer K loop (no torch.cat copy);
+// producing kernel (or raw, with the LayerNorm applied by linearity in the epilogue),
+// so BOTH operands stream HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B
+// per lane, no VGPR round trip, no VALU in the main loop):
+//   * conv taps, stride 2 and nearest-upsample are per-lane SOURCE row offsets computed
+//     once per (piece, tap, source tensor); zero padding / rows past M are out-of-range
+//     offsets of the buffer descriptor (the DMA writes zeros); the K position of a tile
+//     is the instruction's scalar offset; the skip-connection concat is a K loop over
+//     two descriptors (no torch.cat copy), a fused 1x1 shortcut a third;
 //   * the LDS image is lane-linear (DMA constraint), so the bank-conflict swizzle is
 //     applied to the source address: 16-B chunk c of tile row r is stored at chunk
 //     position c ^ ((r>>1)&7) and read back with the same XOR -> conflict-free
@@ -21,11 +24,14 @@
 //   * STAGES-deep LDS ring, counted s_waitcnt vmcnt(N) (never 0 in steady state),
 //     one raw s_barrier per K tile; the DMA is issued through inline asm so the
 //     compiler does not drain it in front of every ds_read.
-// 256 threads = 2x2 waves, each wave (BM/2)x(BN/2) from 32x32 MFMA tiles:
+// Kernels: gemm4_kernel (default; 512 threads, two wave groups on opposite halves of every
+// K tile, see its header), gemm2_kernel (256 threads = 2x2 waves), gemm3_kernel
+// (register-staged experiment).  Wave tiles are built from 32x32 MFMA tiles:
 //   bf16: v_mfma_f32_32x32x16_bf16 (one per 32-B k-slab)
 //   f32 : v_mfma_f32_32x32x2_f32   (four per 32-B k-slab; exact fp32 parity mode)
-// Epilogue: bias, GEGLU (value * gelu_erf(gate)), fp32 residual add, fp32 store
-// (residual stream) and/or operand-typed store (feeds the next GEMM / attention).
+// Epilogue: bias, GEGLU (value * gelu_erf(gate)), LayerNorm fix-up, fp32 residual add,
+// fp32 store (residual stream) and/or operand-typed store (feeds the next GEMM /
+// attention), GroupNorm / LayerNorm partial statistics of the result.
 #include "common.h"
 #include "mma.h"
 

@@ -232,6 +232,36 @@ static void run_oob() {
   fflush(stdout);
 }
 
+// Does data read by one kernel stay in the XCD L2s for the next kernel on the same stream?  Launch A streams a 2 MB
+// region once (each workgroup a different slice); launch B re-reads the same slices (same workgroup -> same XCD) or a
+// region nobody touched.  Short kernels, so the cold-start cost is what is measured.
+static void run_reuse(char* pool, size_t pool_bytes, unsigned long long* dout) {
+  Args a;
+  a.src = pool; a.bytes = pool_bytes; a.row_stride = 128; a.npool = 2048; a.pieces = 8; a.shared = 0; a.out = dout;
+  Args b2 = a; b2.src = pool + (64u << 20);            // untouched region
+  const size_t lds = 64 * 1024;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(probe<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e[4];
+  for (auto& x : e) CK(hipEventCreate(&x));
+  for (int rep = 0; rep < 3; ++rep) {
+    // evict: stream 512 MB through the caches
+    Args ev = a; ev.src = pool + (128u << 20); ev.npool = 524288; ev.pieces = 256;
+    hipLaunchKernelGGL((probe<0, 8>), dim3(512), dim3(256), lds, 0, ev);
+    CK(hipEventRecord(e[0], 0));
+    hipLaunchKernelGGL((probe<0, 8>), dim3(256), dim3(256), lds, 0, a);      // A: first touch
+    CK(hipEventRecord(e[1], 0));
+    hipLaunchKernelGGL((probe<0, 8>), dim3(256), dim3(256), lds, 0, a);      // B: same data, next kernel
+    CK(hipEventRecord(e[2], 0));
+    hipLaunchKernelGGL((probe<0, 8>), dim3(256), dim3(256), lds, 0, b2);     // C: cold data
+    CK(hipEventRecord(e[3], 0));
+    CK(hipEventSynchronize(e[3]));
+    float t1, t2, t3;
+    CK(hipEventElapsedTime(&t1, e[0], e[1])); CK(hipEventElapsedTime(&t2, e[1], e[2])); CK(hipEventElapsedTime(&t3, e[2], e[3]));
+    printf("cross-kernel reuse (2 MB, 8 pieces/wave): first touch %.1f us, same data in the next kernel %.1f us, untouched data %.1f us\n", t1 * 1e3, t2 * 1e3, t3 * 1e3);
+  }
+  fflush(stdout);
+}
+
 int main(int argc, char** argv) {
   run_oob();
   const size_t pool_bytes = (size_t)786432 * 1024;   // 768 MB: 2048 pieces at the largest stride, or a pool beyond the 256 MB Infinity Cache
@@ -240,6 +270,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&pool, pool_bytes + 65536));
   CK(hipMemset(pool, 1, pool_bytes + 65536));
   CK(hipMalloc(&dout, 2 * 8 * 256 * 16 * 8));
+  run_reuse(pool, pool_bytes, dout);
   // cold streams: pool larger than the 4 MB L2 of an XCD (-> Infinity Cache) and larger than the Infinity Cache (-> HBM)
   for (unsigned np : {2048u, 65536u, 786432u})
     for (int bpc : {1, 2, 3}) {
