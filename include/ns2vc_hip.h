@@ -154,6 +154,23 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
 } ns2vc_gemm_args;
 
+/* GroupNorm(+time scale/shift)(+SiLU) fused INTO a 3-tap conv (resnet.py:591-641: conv(act(norm(x)))): the kernel reads the
+ * fp32 stream rows (+1 halo row each side) itself, normalises them in registers and keeps them as an operand panel in
+ * LDS for all three taps -- no normalisation pass, no operand tensor in HBM.  g.a0/g.a1 are ignored (the fp32 sources
+ * x0/x1 take their place, channel split g.c0 | g.c1); g.taps must be 3, g.tmode 0, g.Tin == g.Tout >= 66,
+ * g.c0 + g.c1 <= 512 and a multiple of 64, groups == 8; everything else (a2 segment, bias, residual, outputs,
+ * statistics of the result) as in ns2vc_gemm_args. */
+typedef struct ns2vc_convgn_args {
+  ns2vc_gemm_args g;
+  const float* x0; const float* x1; int32_t ldx0, ldx1;   /* fp32 concat sources, channels-last */
+  const long long* st0; const long long* st1;             /* their epilogue statistics [B][c/16][2] (see ns2vc_gemm_args.stats) */
+  const float* gamma; const float* beta;                  /* [c0 + c1] */
+  const float* temb; int32_t ldtemb, temb_off;            /* optional (1 + scale | shift) rows [B][ldtemb], or NULL */
+  int32_t groups; float eps; int32_t silu;
+  void* raw_op;                                           /* optional operand-typed copy of the raw concat rows [M][c0 + c1] */
+} ns2vc_convgn_args;
+int ns2vc_k_convgn(const ns2vc_convgn_args* a, int precision, void* stream);
+
 typedef struct ns2vc_attn_args {
   const void* q; const void* k; const void* v; /* operand-typed rows; head h lives at columns [h*hd, (h+1)*hd) */
   int32_t ldq, ldk, ldv;

@@ -47,6 +47,18 @@ class GemmArgs(C.Structure):
     ]
 
 
+class ConvGnArgs(C.Structure):
+    _fields_ = [
+        ("g", GemmArgs),
+        ("x0", C.c_void_p), ("x1", C.c_void_p), ("ldx0", C.c_int32), ("ldx1", C.c_int32),
+        ("st0", C.c_void_p), ("st1", C.c_void_p),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("temb", C.c_void_p), ("ldtemb", C.c_int32), ("temb_off", C.c_int32),
+        ("groups", C.c_int32), ("eps", C.c_float), ("silu", C.c_int32),
+        ("raw_op", C.c_void_p),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
@@ -102,6 +114,7 @@ PROTOTYPES = {
     "ns2vc_pack_weight": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_k_gemm": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "ns2vc_weight_rowsum": (_I, [_P, _I, _I, _I, _PP]),
+    "ns2vc_k_convgn": (_I, [C.POINTER(ConvGnArgs), _I, _P]),
     "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),

@@ -86,6 +86,7 @@ enum { PRO_NONE = 0, PRO_BC = 1, PRO_ROW = 2 };
 
 typedef ::ns2vc_gemm_args GemmArgs;   // public POD, include/ns2vc_hip.h
 typedef ::ns2vc_attn_args AttnArgs;
+typedef ::ns2vc_convgn_args ConvGnArgs;
 
 enum Precision { PREC_F32 = 0, PREC_BF16 = 1 };
 // fixed-point scales of the epilogue GroupNorm statistics (order-independent int64 atomics => deterministic)
@@ -94,6 +95,8 @@ constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
+hipError_t launch_convgn(const ConvGnArgs& a, int prec, hipStream_t s);
+bool convgn_eligible(const ConvGnArgs& a, int prec);
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
 // fused row-panel chains (chain.hip), bf16 operand type only

@@ -127,6 +127,11 @@ struct ns2vc_unet {
   // but measured SLOWER on MI355X (attention +0.21 ms, GEMMs -0.16 ms per step): every head's workgroup re-reads the
   // same input rows through the load path, 8x the bytes of the separate GEMM.  Off by default.
   bool fuse_toq = false;
+  // GroupNorm(+scale/shift)+SiLU computed inside the 3-tap conv that consumes it (conv3gn_kernel, NS2VC_FUSE_GN=1).
+  // Correct and tested, 37 launches fewer, but measured SLOWER on MI355X (4.91 vs 4.63 ms/step): the panel build (cold
+  // fp32 rows + SiLU) sits serially in front of every workgroup's K loop and is redone by each of the N/128 column
+  // workgroups, while the separate pass does the same work at full-chip parallelism.  Off by default.
+  bool fuse_gn = false;
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -664,12 +669,29 @@ struct Planner {
   void resnet(const ResnetW& r, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float* h1, void* hn,
               float* sc, float* out, void* out_op) {
     const int cin = c0 + c1;
-    groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
+    const int pr = prec, Gq = G, ldt = h->temb_all.N;
+    // ---- conv1(act(norm1(x))): GroupNorm fused into the conv when the kernel can take it (csrc/gemm.hip conv3gn_kernel)
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
+    ConvGnArgs f1;
+    memset(&f1, 0, sizeof(f1));
+    f1.x0 = a0; f1.ldx0 = lda0; f1.x1 = a1; f1.ldx1 = lda1;
+    f1.st0 = find_stats(a0); f1.st1 = a1 ? find_stats(a1) : nullptr;
+    f1.gamma = r.n1g; f1.beta = r.n1b; f1.groups = Gq; f1.eps = 1e-5f; f1.silu = 1;
+    f1.raw_op = r.shortcut ? xr : nullptr;
+    f1.g = g; f1.g.a0 = nullptr; f1.g.c0 = c0; f1.g.c1 = c1; f1.g.lda0 = 0;
+    const bool fuse1 = h->fuse_gn && convgn_eligible(f1, pr);
+    if (!fuse1) groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
     g.stats = new_stats(h1, Tl, r.cout);
-    gemm(r.prefix + ".conv1", g);
-    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
+    if (fuse1) {
+      f1.g.stats = g.stats;
+      const double n = (double)B * Tl * cin;
+      add(r.prefix + ".norm1+conv1", [=](hipStream_t s) { return launch_convgn(f1, pr, s); }, 1, 2.0 * g.M * (double)g.N * g.K,
+          4.0 * n + (double)g.N * g.K * opsz + 4.0 * g.M * g.N + (f1.raw_op ? n * opsz : 0.0));
+    } else {
+      gemm(r.prefix + ".conv1", g);
+    }
+    // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3;
     if (r.shortcut) {      // out = conv2(hn) + conv_shortcut(x): the 1x1 conv rides along as a second K segment
@@ -677,8 +699,26 @@ struct Planner {
     } else {
       g2.res = a0; g2.ldres = lda0;
     }
+    ConvGnArgs f2;
+    memset(&f2, 0, sizeof(f2));
+    f2.x0 = h1; f2.ldx0 = r.cout;
+    f2.st0 = g.stats;
+    f2.gamma = r.n2g; f2.beta = r.n2b; f2.groups = Gq; f2.eps = 1e-5f; f2.silu = 1;
+    f2.temb = h->temb; f2.ldtemb = ldt; f2.temb_off = r.temb_off;
+    f2.g = g2; f2.g.a0 = nullptr; f2.g.c0 = r.cout; f2.g.c1 = 0;
+    const bool fuse2 = h->fuse_gn && convgn_eligible(f2, pr);
+    if (!fuse2) groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
     g2.stats = new_stats(out, Tl, r.cout);
-    gemm(r.prefix + ".conv2", g2);
+    if (fuse2) {
+      f2.g.stats = g2.stats;
+      const double n = (double)B * Tl * r.cout;
+      add(r.prefix + ".norm2+conv2", [=](hipStream_t s) { return launch_convgn(f2, pr, s); }, 1, 2.0 * g2.M * (double)g2.N * g2.K,
+          4.0 * n + (double)g2.N * g2.K * opsz + (double)B * Tl * g2.c2 * opsz + 4.0 * g2.M * g2.N + (g2.out_op ? (double)g2.M * g2.N * opsz : 0.0) +
+              (g2.res ? 4.0 * g2.M * g2.N : 0.0));
+    } else {
+      gemm(r.prefix + ".conv2", g2);
+    }
+    (void)sc;
   }
 
   // `proj` (optional): fused query projection -- only its xq/ldx/xdim/wq/bq/ln_* fields are read
@@ -1063,6 +1103,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_USE_CHAINS")) h->use_chains = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_TOQ")) h->fuse_toq = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_GN")) h->fuse_gn = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1349,6 +1390,12 @@ int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_gemm(*a, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("launch_gemm: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_convgn(const ns2vc_convgn_args* a, int precision, void* stream) {
+  if (!a) return fail("null args");
+  hipError_t e = launch_convgn(*a, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_convgn: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream) {

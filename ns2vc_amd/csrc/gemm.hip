@@ -577,6 +577,150 @@ __global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
+// epilogue of the 8-wave K-split kernels (gemm4_kernel, conv3gn_kernel): per 32-row slab, both K halves stage their
+// partial tile in LDS (re-using the operand ring), then each of the eight waves adds the pair for 16 rows and moves
+// whole rows out (16-B fp32 / 8-B bf16 stores, coalesced); bias, GEGLU, LayerNorm fix-up, residual, statistics.
+// ---------------------------------------------------------------------------
+template <typename TM, int BM, bool LNC>
+__device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc)[BM / 64][2], char* smem, int m0, int n0, int tid,
+                                               unsigned long long* tr, const LnRaw& lnraw) {
+  constexpr int WM = BM / 2, WN = 64, MT = WM / 32, NT = 2;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, wq = wave & 3;
+  const int wm = wq >> 1, wn = wq & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  (void)NT;
+  NS2VC_STAMP(4);
+  // ---- epilogue: per 32-row slab, both K halves stage their partial tile, then each of the eight waves adds the
+  // pair for 16 rows and moves whole rows out (16-B fp32 / 8-B bf16 stores, coalesced)
+  constexpr int EP = WN + 4;                        // staging pitch in floats
+  constexpr int SLAB = 32 * EP;                     // floats per staged 32 x 64 slab
+  float* const et_mine = reinterpret_cast<float*>(smem) + wave * SLAB;
+  const float* const et_a = reinterpret_cast<const float*>(smem) + wq * SLAB + kg * 16 * EP;        // K half 0, my 16 rows
+  const float* const et_b = et_a + 4 * SLAB;                                                          // K half 1
+  float* of = g.out_f32;
+  TM* oo = reinterpret_cast<TM*>(g.out_op);
+  const int mw0 = m0 + wm * WM;                     // first row of the wave tile (both K halves)
+  const int b0 = g.stats ? min(mw0, g.M - 1) / g.Tout : 0;       // (division only when the statistics are wanted)
+  const int mB = g.stats ? (b0 + 1) * g.Tout : 0x7fffffff;
+  float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+  constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = 16 / RPI;    // 16 lanes per row, 4 rows per pass, 4 passes
+  const int rsub = lane / LPR, cq = lane % LPR;
+  const int ncol = n0 + wn * WN + cq * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias && !g.geglu) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+  // GEGLU: 32 output columns per row = 8 lanes x 4, 8 rows per pass
+  const int grsub = lane >> 3, gcq = lane & 7;
+  const int pcol = n0 + wn * WN + gcq * 4;          // packed column of the value quad; gate quad = +32
+  const int ocol = ((n0 + wn * WN) >> 1) + gcq * 4;
+  float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f), gbg = gbv;
+  if (g.bias && g.geglu) { gbv = *reinterpret_cast<const float4*>(g.bias + pcol); gbg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
+  // LayerNorm-by-linearity consumer: lane l < 16*MT holds mean / rstd of the l-th row this wave will emit (loaded before the K loop)
+  constexpr bool lnc = LNC;
+  float lmean = 0.f, lrstd = 1.f;
+  float4 ws = make_float4(0.f, 0.f, 0.f, 0.f), wsv = ws, wsg = ws;
+  if constexpr (lnc) {
+    ln_row_finish(g, lnraw, lmean, lrstd);
+    if (g.geglu) { wsv = *reinterpret_cast<const float4*>(g.ln_wsum + pcol); wsg = *reinterpret_cast<const float4*>(g.ln_wsum + pcol + 32); }
+    else ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    __syncthreads();                                // ring (or the previous slab) is free
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) et_mine[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
+    __syncthreads();
+    if (mt == 0) NS2VC_STAMP(5);
+    const int mrow0 = mw0 + mt * 32 + kg * 16;      // first of my 16 rows
+    if (g.geglu) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int row = it * 8 + grsub, m = mrow0 + row;
+        const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + gcq * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + gcq * 4);
+        const float4 t0 = *reinterpret_cast<const float4*>(et_a + row * EP + 32 + gcq * 4);
+        const float4 t1 = *reinterpret_cast<const float4*>(et_b + row * EP + 32 + gcq * 4);
+        float4 a = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
+        if constexpr (lnc) {
+          const float mu = __shfl(lmean, mt * 16 + row), rs = __shfl(lrstd, mt * 16 + row);
+          a.x = rs * (a.x - mu * wsv.x); a.y = rs * (a.y - mu * wsv.y); a.z = rs * (a.z - mu * wsv.z); a.w = rs * (a.w - mu * wsv.w);
+          t.x = rs * (t.x - mu * wsg.x); t.y = rs * (t.y - mu * wsg.y); t.z = rs * (t.z - mu * wsg.z); t.w = rs * (t.w - mu * wsg.w);
+        }
+        if (m < g.M) {
+          float4 v;
+          v.x = (a.x + gbv.x) * gelu_erf_f(t.x + gbg.x); v.y = (a.y + gbv.y) * gelu_erf_f(t.y + gbg.y);
+          v.z = (a.z + gbv.z) * gelu_erf_f(t.z + gbg.z); v.w = (a.w + gbv.w) * gelu_erf_f(t.w + gbg.w);
+          if (g.res) {
+            const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
+        }
+      }
+    } else {
+      float4 rr[NIT];                               // residual rows first (res may alias out_f32 element-for-element)
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int m = mrow0 + k * RPI + rsub;
+        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int row = k * RPI + rsub, m = mrow0 + row;
+        const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + cq * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + cq * 4);
+        float4 a = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
+        if constexpr (lnc) {
+          const float mu = __shfl(lmean, mt * 16 + row), rs = __shfl(lrstd, mt * 16 + row);
+          a.x = rs * (a.x - mu * ws.x); a.y = rs * (a.y - mu * ws.y); a.z = rs * (a.z - mu * ws.z); a.w = rs * (a.w - mu * ws.w);
+        }
+        float ps = 0.f, pq = 0.f;
+        if (m < g.M) {
+          float4 v;
+          v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
+          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
+          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
+          ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+          if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
+        }
+        if (g.rowstats) ln_row_store(g, m, ncol, cq, ps, pq);
+      }
+    }
+  }
+  if (g.stats) {
+    double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
+    }
+    if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
+      const int blk = ncol >> 4, nblk = g.N >> 4;
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
+      atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
+      atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
+      if (mB < g.M && mB < mw0 + WM) {
+        atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
+        atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
+      }
+    }
+  }
+#if NS2VC_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only so that the last stamp includes the store drain)
+#endif
+  NS2VC_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------
 // 8-wave variant with an intra-workgroup K split.
 //
 // tools/dma_probe.hip (profiles/dma_probe_r01_*.txt) measured what feeds a CU on MI355X: one wave lands one 1-KB
@@ -777,133 +921,286 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
     if (++stage == STAGES) stage = 0;
   }
 
-  NS2VC_STAMP(4);
-  // ---- epilogue: per 32-row slab, both K halves stage their partial tile, then each of the eight waves adds the
-  // pair for 16 rows and moves whole rows out (16-B fp32 / 8-B bf16 stores, coalesced)
-  constexpr int EP = WN + 4;                        // staging pitch in floats
-  constexpr int SLAB = 32 * EP;                     // floats per staged 32 x 64 slab
-  float* const et_mine = reinterpret_cast<float*>(smem) + wave * SLAB;
-  const float* const et_a = reinterpret_cast<const float*>(smem) + wq * SLAB + kg * 16 * EP;        // K half 0, my 16 rows
-  const float* const et_b = et_a + 4 * SLAB;                                                          // K half 1
-  float* of = g.out_f32;
-  TM* oo = reinterpret_cast<TM*>(g.out_op);
-  const int mw0 = m0 + wm * WM;                     // first row of the wave tile (both K halves)
-  const int b0 = g.stats ? min(mw0, g.M - 1) / g.Tout : 0;       // (division only when the statistics are wanted)
-  const int mB = g.stats ? (b0 + 1) * g.Tout : 0x7fffffff;
-  float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
-  constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = 16 / RPI;    // 16 lanes per row, 4 rows per pass, 4 passes
-  const int rsub = lane / LPR, cq = lane % LPR;
-  const int ncol = n0 + wn * WN + cq * 4;
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (g.bias && !g.geglu) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
-  // GEGLU: 32 output columns per row = 8 lanes x 4, 8 rows per pass
-  const int grsub = lane >> 3, gcq = lane & 7;
-  const int pcol = n0 + wn * WN + gcq * 4;          // packed column of the value quad; gate quad = +32
-  const int ocol = ((n0 + wn * WN) >> 1) + gcq * 4;
-  float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f), gbg = gbv;
-  if (g.bias && g.geglu) { gbv = *reinterpret_cast<const float4*>(g.bias + pcol); gbg = *reinterpret_cast<const float4*>(g.bias + pcol + 32); }
-  // LayerNorm-by-linearity consumer: lane l < 16*MT holds mean / rstd of the l-th row this wave will emit (loaded before the K loop)
-  constexpr bool lnc = LNC;
-  float lmean = 0.f, lrstd = 1.f;
-  float4 ws = make_float4(0.f, 0.f, 0.f, 0.f), wsv = ws, wsg = ws;
-  if constexpr (lnc) {
-    ln_row_finish(g, lnraw, lmean, lrstd);
-    if (g.geglu) { wsv = *reinterpret_cast<const float4*>(g.ln_wsum + pcol); wsg = *reinterpret_cast<const float4*>(g.ln_wsum + pcol + 32); }
-    else ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
+  gemm4_epilogue<TM, BM, LNC>(g, acc, smem, m0, n0, tid, tr, lnraw);
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm(+time scale/shift)(+SiLU) fused into the 3-tap conv that consumes it (resnet.py:591-641).
+//
+// A normalisation pass costs a launch (~4.5 us of fixed latency on this chip) plus a read of the fp32 stream and a
+// write + three L2 reads of the operand tensor.  Here the workgroup that owns 64 output rows loads those rows and one
+// halo row each side straight from the fp32 stream, finalises mean / rstd from the producers' epilogue statistics,
+// applies affine (+ time scale/shift) + SiLU in registers and writes the result ONCE into an LDS panel laid out as
+// the K tiles the MFMA fragments want (same XOR swizzle as the DMA image).  The three taps are the same panel read at
+// row offsets 0/1/2; rows that fall off the sequence ends are masked per fragment lane.  Only the weights (and the
+// optional fused 1x1 shortcut operand) still stream through the LDS ring, 16 KB per K step instead of 24.
+// Structure otherwise as gemm4_kernel (512 threads, K split across the two wave groups, shared epilogue).
+// ---------------------------------------------------------------------------
+template <typename TM, int CT64>      // CT64 = input channels / 64 (2, 4, 6, 8): fixes the thread -> (row, channel quad) map at compile time
+__global__ __launch_bounds__(512) void conv3gn_kernel(const ConvGnArgs a) {
+  const GemmArgs& g = a.g;
+  constexpr int EPC = MmaT<TM>::EPC;
+  constexpr int BKE = 8 * EPC;
+  constexpr int BM = 64, BN = 128, STAGES = 3;
+  constexpr int WM = BM / 2, WN = BN / 2, MT = 1, NT = 2;
+  constexpr int LB = BN / 64;
+  constexpr int STAGE = (BM + BN) * TROW;                 // [fused-shortcut A tile 8 KB][W tile 16 KB]
+  constexpr int PROWS = BM + 2;                           // panel rows: output rows -1 .. BM
+  constexpr int PTILE = PROWS * TROW;                     // bytes of one K tile of the panel
+  constexpr unsigned SZB = sizeof(TM);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float s_mean[2][8], s_rstd[2][8];
+  char* const panel = smem + STAGES * STAGE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = wave >> 2, wq = wave & 3;
+  const int wm = wq >> 1, wn = wq & 1;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned long long* tr = NS2VC_TRACE_PTR();
+  NS2VC_STAMP(0);
+
+  const int nb_n = g.N / BN;
+  const int nb_m = (g.M + BM - 1) / BM;
+  const int nwg = nb_n * nb_m;
+  int tm, tn;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tm = swz / nb_n;
+    tn = swz - tm * nb_n;
+  }
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int T = g.Tout;
+  const int Ctot = g.c0 + g.c1;
+  const int nct = Ctot / BKE;                             // K tiles per tap
+  const int nk = g.K / BKE;                               // 3 * nct (+ fused 1x1 segment)
+  const int K1 = 3 * Ctot;
+
+  // ---- weight (and shortcut operand) stream: buffer-descriptor DMA as in gemm4_kernel
+  const int prow = tid >> 3, pchunk = tid & 7;
+  const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;
+  unsigned vw[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * 64 + prow) * (unsigned)g.K) * SZB + acolb;
+  const unsigned va2 = (m0 + prow < g.M) ? (unsigned)(m0 + prow) * (unsigned)g.lda2 * SZB + acolb : DMA_OOB;
+  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
+  const i32x4_t rA2 = make_rsrc(g.c2 ? g.a2 : g.w, g.c2 ? (unsigned long long)g.M * g.lda2 * SZB : 16ull);
+  int is_k = 0;
+  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+    const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
+    if (is_k >= K1) blds16(rA2, va2, (unsigned)(is_k - K1) * SZB, sbase);
+    const unsigned bbase = sbase + BM * TROW;
+    const unsigned soffW = (unsigned)is_k * SZB;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * 8192);
+    is_k += BKE;
+  };
+  NS2VC_STAMP(1);
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) issue_tile(s);                            // the first weight tiles fly while the panel is built
+  NS2VC_STAMP(2);
+
+  // ---- GroupNorm statistics of the (at most two) batch items this panel touches: wave w finalises group w
+  const int mfirst = max(m0 - 1, 0);
+  const int bA = mfirst / T;
+  const int mSplit = (bA + 1) * T;                        // first global row of batch item bA + 1
+  const int G = a.groups, Cg = Ctot / G;
+  {
+    const int nb = Cg >> 4, nblk0 = g.c0 >> 4, nblk1 = g.c1 >> 4;
+    const int nB = g.M / T;
+    for (int which = 0; which < 2; ++which) {
+      const int b = min(bA + which, nB - 1);
+      double ds = 0.0, dq = 0.0;
+      if (wave < G && lane < nb) {
+        const int blk = wave * nb + lane;
+        const long long* p = blk < nblk0 ? a.st0 + ((size_t)b * nblk0 + blk) * 2 : a.st1 + ((size_t)b * nblk1 + (blk - nblk0)) * 2;
+        ds = (double)p[0] * (1.0 / GN_SUM_SCALE);
+        dq = (double)p[1] * (1.0 / GN_SQ_SCALE);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
+      if (wave < G && lane == 0) {
+        const float inv_nf = 1.0f / ((float)T * (float)Cg);
+        const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
+        const double mean = ds * inv_n;
+        double var = dq * inv_n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float ve = (float)var + a.eps;
+        float r = rsqrtf(ve);
+        r = r * (1.5f - 0.5f * ve * r * r);
+        s_mean[which][wave] = (float)mean;
+        s_rstd[which][wave] = r;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- build the panel: thread = (channel quad, row lane); rows p = 0 .. 65 are global rows m0 - 1 + p
+  {
+    constexpr int nq = CT64 * 16;                         // channel quads per row
+    constexpr int rl = 512 / nq;                          // row lanes: 16, 8, 5, 4
+    constexpr int NR = (PROWS + rl - 1) / rl;             // rows per thread: 5, 9, 14, 17 -- ALL loaded before any is used,
+    const int quad = tid % nq, rlane = tid / nq;          // so the panel costs one (cold) memory round trip, not NR/4
+    const bool active = rlane < rl;
+    const int c = quad * 4;
+    const float* src; int ld, cs;
+    if (c < g.c0) { src = a.x0; ld = a.ldx0; cs = c; } else { src = a.x1; ld = a.ldx1; cs = c - g.c0; }
+    float4 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int p = rlane + k * rl;
+      const int mg = m0 - 1 + p;
+      v[k] = (active && p < PROWS && mg >= 0 && mg < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)mg * ld + cs)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float sc[2][4], sh[2][4];
+    {
+      const int gi = c / Cg;
+      const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
+      const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
+      const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+      const int nB = g.M / T;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        const int b = min(bA + which, nB - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float s1 = s_rstd[which][gi] * gam[e];
+          float s2 = bet[e] - s_mean[which][gi] * s1;
+          if (a.temb) {
+            const float ts = 1.0f + a.temb[(size_t)b * a.ldtemb + a.temb_off + c + e];
+            const float tf = a.temb[(size_t)b * a.ldtemb + a.temb_off + Ctot + c + e];
+            s1 *= ts;
+            s2 = s2 * ts + tf;
+          }
+          sc[which][e] = s1; sh[which][e] = s2;
+        }
+      }
+    }
+    // LDS position of this quad inside a panel row: K tile, 16-B chunk, offset inside the chunk
+    const int ct = (c * (int)SZB) / TROW;
+    const int cbyte = (c * (int)SZB) % TROW;
+    const int chunk = cbyte >> 4, sub = cbyte & 15;
+    TM* const rawp = reinterpret_cast<TM*>(a.raw_op);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int p = rlane + k * rl;
+      if (!active || p >= PROWS) continue;
+      const int mg = m0 - 1 + p;
+      const bool ok = mg >= 0 && mg < g.M;
+      const int w = mg >= mSplit ? 1 : 0;
+      float y0 = v[k].x * sc[w][0] + sh[w][0], y1 = v[k].y * sc[w][1] + sh[w][1];
+      float y2 = v[k].z * sc[w][2] + sh[w][2], y3 = v[k].w * sc[w][3] + sh[w][3];
+      if (a.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+      if (!ok) { y0 = y1 = y2 = y3 = 0.f; }
+      store_op4<TM>(reinterpret_cast<TM*>(panel + ct * PTILE + p * TROW + ((chunk ^ ((p >> 1) & 7)) << 4) + sub), y0, y1, y2, y3);
+      if (rawp && tn == 0 && ok && p >= 1 && p <= BM) store_op4<TM>(rawp + (size_t)mg * Ctot + c, v[k].x, v[k].y, v[k].z, v[k].w);
+    }
   }
 
+  f32x16_t acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    __syncthreads();                                // ring (or the previous slab) is free
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+  // per-lane validity of the three taps for this lane's output row (sequence ends: zero padding)
+  const int l31 = lane & 31, hi = lane >> 5;
+  bool tapok[3];
+  {
+    const int m = m0 + wm * WM + l31;
+    const int t = m % T;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) et_mine[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
-    __syncthreads();
-    if (mt == 0) NS2VC_STAMP(5);
-    const int mrow0 = mw0 + mt * 32 + kg * 16;      // first of my 16 rows
-    if (g.geglu) {
+    for (int tp = 0; tp < 3; ++tp) tapok[tp] = m < g.M && (t + tp - 1) >= 0 && (t + tp - 1) < T;
+  }
+  LnRaw lnraw;
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int row = it * 8 + grsub, m = mrow0 + row;
-        const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + gcq * 4);
-        const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + gcq * 4);
-        const float4 t0 = *reinterpret_cast<const float4*>(et_a + row * EP + 32 + gcq * 4);
-        const float4 t1 = *reinterpret_cast<const float4*>(et_b + row * EP + 32 + gcq * 4);
-        float4 a = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-        float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
-        if constexpr (lnc) {
-          const float mu = __shfl(lmean, mt * 16 + row), rs = __shfl(lrstd, mt * 16 + row);
-          a.x = rs * (a.x - mu * wsv.x); a.y = rs * (a.y - mu * wsv.y); a.z = rs * (a.z - mu * wsv.z); a.w = rs * (a.w - mu * wsv.w);
-          t.x = rs * (t.x - mu * wsg.x); t.y = rs * (t.y - mu * wsg.y); t.z = rs * (t.z - mu * wsg.z); t.w = rs * (t.w - mu * wsg.w);
-        }
-        if (m < g.M) {
-          float4 v;
-          v.x = (a.x + gbv.x) * gelu_erf_f(t.x + gbg.x); v.y = (a.y + gbv.y) * gelu_erf_f(t.y + gbg.y);
-          v.z = (a.z + gbv.z) * gelu_erf_f(t.z + gbg.z); v.w = (a.w + gbv.w) * gelu_erf_f(t.w + gbg.w);
-          if (g.res) {
-            const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
-            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-          }
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
-        }
-      }
+  for (int i = 0; i < 4; ++i) lnraw.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();                                         // panel complete
+  NS2VC_STAMP(3);
+
+  int stage = 0, tap = 0, ctile = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed when only the pieces of tile kt+1 are still in flight (2 weight pieces, +1 in the 1x1 segment)
+    if (kt + 1 < nk) {
+      if ((kt + 1) * BKE >= K1) wait_vmcnt<LB + 1>(); else wait_vmcnt<LB>();
     } else {
-      float4 rr[NIT];                               // residual rows first (res may alias out_f32 element-for-element)
-#pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int m = mrow0 + k * RPI + rsub;
-        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wait_vmcnt<0>();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto refill = [&]() __attribute__((always_inline)) {
+      if (kt + STAGES - 1 < nk) {
+        int st2 = stage + STAGES - 1;
+        if (st2 >= STAGES) st2 -= STAGES;
+        issue_tile(st2);
       }
+    };
+    if (kg == 0) refill();
+    {
+      const char* Ws = smem + stage * STAGE + BM * TROW;
+      const char* bp = Ws + (wn * WN + l31) * TROW;
+      const bool seg2 = kt * BKE >= K1;                    // wave-uniform
+      const int R = wm * WM + l31 + tap;                   // panel row of this lane's A fragment
+      const char* ap = seg2 ? smem + stage * STAGE + (wm * WM + l31) * TROW : panel + ctile * PTILE + R * TROW;
+      const int swa = seg2 ? (l31 >> 1) & 7 : (R >> 1) & 7;
+      const int swb = (l31 >> 1) & 7;
+      const bool aok = seg2 || (tap == 0 ? tapok[0] : (tap == 1 ? tapok[1] : tapok[2]));
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int row = k * RPI + rsub, m = mrow0 + row;
-        const float4 a0 = *reinterpret_cast<const float4*>(et_a + row * EP + cq * 4);
-        const float4 a1 = *reinterpret_cast<const float4*>(et_b + row * EP + cq * 4);
-        float4 a = make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w);
-        if constexpr (lnc) {
-          const float mu = __shfl(lmean, mt * 16 + row), rs = __shfl(lrstd, mt * 16 + row);
-          a.x = rs * (a.x - mu * ws.x); a.y = rs * (a.y - mu * ws.y); a.z = rs * (a.z - mu * ws.z); a.w = rs * (a.w - mu * ws.w);
-        }
-        float ps = 0.f, pq = 0.f;
-        if (m < g.M) {
-          float4 v;
-          v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
-          ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-          if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
-        }
-        if (g.rowstats) ln_row_store(g, m, ncol, cq, ps, pq);
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = 2 * (2 * kg + kk) + hi;
+        u32x4_t af = *reinterpret_cast<const u32x4_t*>(ap + ((ch ^ swa) << 4));
+        if (!aok) af = u32x4_t{0, 0, 0, 0};
+        u32x4_t bf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + ((ch ^ swb) << 4));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[0][j], af, bf[j]);
       }
     }
+    if (kg != 0) refill();
+    if (++stage == STAGES) stage = 0;
+    if (++ctile == nct) { ctile = 0; ++tap; }
   }
-  if (g.stats) {
-    double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
-#pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-      d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
-    }
-#pragma unroll
-    for (int o = LPR; o < 64; o <<= 1) {
-      d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o);
-    }
-    if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
-      const int blk = ncol >> 4, nblk = g.N >> 4;
-      unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
-      atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
-      atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
-      if (mB < g.M && mB < mw0 + WM) {
-        atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
-        atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
-      }
-    }
+  gemm4_epilogue<TM, BM, false>(g, acc, smem, m0, n0, tid, tr, lnraw);
+}
+
+static size_t convgn_lds_bytes(int ctot, int prec) {
+  const size_t ring = (size_t)3 * (64 + 128) * TROW;
+  const size_t panel = (size_t)(ctot / (prec == PREC_BF16 ? 64 : 32)) * 66 * TROW;
+  return ring + panel;                                     // the epilogue's 69.6 KB staging fits in the 72 KB ring
+}
+constexpr size_t CONVGN_LDS_MAX = 160 * 1024 - 512;       // (the kernel also has 128 B of static LDS)
+bool convgn_eligible(const ConvGnArgs& a, int prec) {
+  const GemmArgs& g = a.g;
+  const int ctot = g.c0 + g.c1;
+  if (ctot <= 0 || convgn_lds_bytes(ctot, prec) > CONVGN_LDS_MAX) return false;      // bf16: up to 512 channels, fp32: up to 320
+  return g.taps == 3 && g.tmode == TMODE_SAME && g.Tin == g.Tout && g.Tout >= 66 && (g.N % 128) == 0 && ctot <= 512 && (ctot % 128) == 0 &&
+         (g.c0 % 16) == 0 && a.groups == 8 && ((ctot / 8) % 16) == 0 && a.st0 && (!g.c1 || a.st1) && !g.geglu && !g.ln_stats && (g.M % g.Tout) == 0;
+}
+hipError_t launch_convgn(const ConvGnArgs& a, int prec, hipStream_t s) {
+  const GemmArgs& g = a.g;
+  if (!convgn_eligible(a, prec) || !a.x0 || !a.gamma || !a.beta) return hipErrorInvalidValue;
+  const int bke = prec == PREC_BF16 ? 64 : 32;
+  if (g.K != 3 * (g.c0 + g.c1) + g.c2 || (g.c2 % bke) || (g.c2 && (!g.a2 || (g.lda2 % (bke / 8))))) return hipErrorInvalidValue;
+  if ((a.ldx0 & 3) || (g.c1 && (a.ldx1 & 3)) || (!g.out_f32 && !g.out_op)) return hipErrorInvalidValue;
+  if (g.stats && (g.Tout < 64 || (g.N & 15))) return hipErrorInvalidValue;
+  if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;
+  const size_t lds = convgn_lds_bytes(g.c0 + g.c1, prec);
+  const int nb = (g.N / 128) * ((g.M + 63) / 64);
+  const int ct64 = (g.c0 + g.c1) / 64;
+#define NS2VC_CGN(TM_, CT_) case CT_: hipLaunchKernelGGL((conv3gn_kernel<TM_, CT_>), dim3(nb), dim3(512), lds, s, a); break
+  if (prec == PREC_BF16) {
+    switch (ct64) { NS2VC_CGN(bf16_t, 2); NS2VC_CGN(bf16_t, 4); NS2VC_CGN(bf16_t, 6); NS2VC_CGN(bf16_t, 8); default: return hipErrorInvalidValue; }
+  } else {
+    switch (ct64) { NS2VC_CGN(float, 2); NS2VC_CGN(float, 4); default: return hipErrorInvalidValue; }
   }
-#if NS2VC_GEMM_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only so that the last stamp includes the store drain)
-#endif
-  NS2VC_STAMP(6);
+#undef NS2VC_CGN
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
@@ -1049,6 +1346,15 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 hipError_t init_gemm_attributes() {
+  {
+    hipError_t e = set_lds(conv3gn_kernel<bf16_t, 2>, CONVGN_LDS_MAX);
+    if (e == hipSuccess) e = set_lds(conv3gn_kernel<bf16_t, 4>, CONVGN_LDS_MAX);
+    if (e == hipSuccess) e = set_lds(conv3gn_kernel<bf16_t, 6>, CONVGN_LDS_MAX);
+    if (e == hipSuccess) e = set_lds(conv3gn_kernel<bf16_t, 8>, CONVGN_LDS_MAX);
+    if (e == hipSuccess) e = set_lds(conv3gn_kernel<float, 2>, CONVGN_LDS_MAX);
+    if (e == hipSuccess) e = set_lds(conv3gn_kernel<float, 4>, CONVGN_LDS_MAX);
+    if (e != hipSuccess) return e;
+  }
   NS2VC_SET4(float, 128, 2); NS2VC_SET4(float, 128, 3); NS2VC_SET4(float, 128, 4);
   NS2VC_SET4(float, 64, 2); NS2VC_SET4(float, 64, 3); NS2VC_SET4(float, 64, 4);
   NS2VC_SET4(bf16_t, 128, 2); NS2VC_SET4(bf16_t, 128, 3); NS2VC_SET4(bf16_t, 128, 4);

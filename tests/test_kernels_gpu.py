@@ -335,6 +335,110 @@ def test_gemm_layernorm_by_linearity(tile, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("case", [("plain", 128, 0, 128, False, False, False), ("concat_raw_shortcut", 128, 128, 256, True, False, True),
+                                  ("temb_res", 256, 0, 256, False, True, False), ("wide_c384", 384, 0, 128, False, True, False),
+                                  ("c512", 512, 0, 128, False, False, False)], ids=lambda c: c[0])
+def test_conv3_fused_groupnorm(case, prec, diag):
+    """conv3(act(GroupNorm(x) [* (1 + scale) + shift])) in ONE launch (resnet.py:591-641): the kernel reads the fp32 rows,
+    normalises from the producers' int64 statistics, keeps the operand panel in LDS for all three taps.  Sequence
+    ends inside a 64-row tile (T = 70), concat input, raw operand copy, fused 1x1 shortcut segment, residual, result
+    statistics -- against numpy in fp64."""
+    from ns2vc_amd._lib import ConvGnArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    name, c0, c1, N, shortcut, use_temb, want_raw = case
+    if prec == 0 and c0 + c1 > 320:
+        pytest.skip("fp32 panel of > 320 channels does not fit LDS: the engine falls back to gn_apply + GEMM there")
+    lib = _lib()
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    B, T, G = 3, 70, 8
+    C_ = c0 + c1
+    M = B * T
+    x0 = (rng.standard_normal((B, T, c0)) * 1.5 + 0.3).astype(np.float32)
+    x1 = (rng.standard_normal((B, T, c1)) - 0.2).astype(np.float32) if c1 else None
+    x = np.concatenate([x0, x1], axis=-1) if c1 else x0
+    gamma = (1.0 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+    temb = (0.2 * rng.standard_normal((B, 2 * C_ + 8))).astype(np.float32) if use_temb else None
+    c2 = 192 if shortcut else 0
+    K = 3 * C_ + c2
+    W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
+    bias = rng.standard_normal(N).astype(np.float32)
+    res = None if shortcut else rng.standard_normal((M, N)).astype(np.float32)
+    a2 = rnd(rng.standard_normal((B, T, c2)), prec) if shortcut else None
+
+    def stats_of(t):          # what a producing GEMM's epilogue leaves: int64 fixed point per (batch item, 16-channel block)
+        blk = t.astype(np.float64).reshape(B, T, t.shape[-1] // 16, 16)
+        return np.stack([np.rint(blk.sum(axis=(1, 3)) * 2 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2 ** 16)], axis=-1).astype(np.int64)
+
+    x64 = x.astype(np.float64)
+    xg = x64.reshape(B, T, G, C_ // G)
+    mean, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+    y = ((xg - mean) / np.sqrt(var + 1e-5)).reshape(B, T, C_) * gamma + beta
+    if use_temb:
+        y = y * (1.0 + temb[:, None, 4:4 + C_]) + temb[:, None, 4 + C_:4 + 2 * C_]
+    y = y / (1.0 + np.exp(-y))
+    yb = rnd(y, prec).astype(np.float64)
+    ypad = np.pad(yb, ((0, 0), (1, 1), (0, 0)))
+    Wd = W.astype(np.float64)
+    ref = np.zeros((B, T, N))
+    for tap in range(3):
+        ref += ypad[:, tap:tap + T, :] @ Wd[:, tap * C_:(tap + 1) * C_].T
+    if shortcut:
+        ref += a2.astype(np.float64) @ Wd[:, 3 * C_:].T
+    ref = ref.reshape(M, N) + bias
+    if res is not None:
+        ref += res
+
+    a = ConvGnArgs()
+    d_x0, d_x1 = _dev(x0), (_dev(x1) if c1 else None)
+    d_s0, d_s1 = _dev(stats_of(x0)), (_dev(stats_of(x1)) if c1 else None)
+    d_g, d_b, d_w, d_bias = _dev(gamma), _dev(beta), _pack(W, prec), _dev(bias)
+    d_o = DevBuf(M * N * 4)
+    d_st = DevBuf.from_numpy(np.zeros((B, N // 16, 2), dtype=np.int64))
+    a.x0, a.ldx0 = d_x0.ptr, c0
+    if c1:
+        a.x1, a.ldx1 = d_x1.ptr, c1
+        a.st1 = d_s1.ptr
+    a.st0 = d_s0.ptr
+    a.gamma, a.beta, a.groups, a.eps, a.silu = d_g.ptr, d_b.ptr, G, 1e-5, 1
+    if use_temb:
+        d_t = _dev(temb)
+        a.temb, a.ldtemb, a.temb_off = d_t.ptr, temb.shape[1], 4
+    d_raw = None
+    if want_raw:
+        d_raw = OpBuf(np.full((M, C_), np.nan, np.float32), prec)
+        a.raw_op = d_raw.ptr
+    g = a.g
+    g.c0, g.c1 = c0, c1
+    g.B, g.Tin, g.Tout, g.M = B, T, T, M
+    g.taps, g.tmode = 3, 0
+    g.w, g.K, g.N, g.bias = d_w.value, K, N, d_bias.ptr
+    if shortcut:
+        d_a2 = OpBuf(a2, prec)
+        g.a2, g.lda2, g.c2 = d_a2.ptr, c2, c2
+    else:
+        d_res = _dev(res)
+        g.res, g.ldres = d_res.ptr, N
+    g.out_f32, g.ldo_f32 = d_o.ptr, N
+    g.stats = d_st.ptr
+    check(lib.ns2vc_k_convgn(C.byref(a), prec, None), "k_convgn")
+    sync()
+    out = d_o.to_numpy((M, N))
+    e = rel_l2(out, ref)
+    diag(f"conv3+groupnorm {name} prec={prec}: rel_l2 {e:.3e} nan={int(np.isnan(out).sum())}")
+    if not e < (3e-5 if prec == 0 else 6e-3):
+        err = np.abs(out - ref)
+        diag(f"  FAIL rows {sorted(set(np.argwhere(err > 0.05)[:, 0].tolist()))[:24]} cols {sorted(set(np.argwhere(err > 0.05)[:, 1].tolist()))[:12]}")
+    assert e < (3e-5 if prec == 0 else 6e-3), e          # bf16: the normalised activations are rounded to bf16 (as gn_apply does)
+    st = d_st.to_numpy((B, N // 16, 2), dtype=np.int64).astype(np.float64)
+    ob = out.astype(np.float64).reshape(B, T, N // 16, 16)
+    assert np.abs(st[..., 0] / 2 ** 28 - ob.sum(axis=(1, 3))).max() / np.abs(ob.sum(axis=(1, 3))).max() < 1e-5
+    if want_raw:
+        assert np.array_equal(d_raw.read((M, C_)), rnd(x.reshape(M, C_), prec))
+    lib.ns2vc_dev_free(d_w)
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 def test_gemm_fused_shortcut_segment(prec, diag):
     """conv3(hn) + conv1x1(x) in one launch: K = 3*c0 + c2 with the second segment on another operand tensor."""
     from ns2vc_amd._lib import GemmArgs, check
