@@ -610,6 +610,46 @@ def test_attention(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
+def test_attention_reference_shift_extremes(prec, diag):
+    """The kernel keeps a per-query softmax REFERENCE instead of the running max (moved only when a score exceeds it by
+    2^12): large logits, a sharply growing maximum, and a first key tile that is entirely masked must all stay exact."""
+    from ns2vc_amd._lib import AttnArgs, check
+    from ns2vc_amd.engine import sync
+    lib = _lib()
+    rng = np.random.default_rng(77)
+    B, H, hd, Lq, Lk = 2, 4, 32, 96, 300
+    D = H * hd
+    q = (4.0 * rng.standard_normal((B, Lq, D))).astype(np.float32)          # logits of +-60 and more
+    k = (3.0 * rng.standard_normal((B, Lk, D))).astype(np.float32)
+    k *= np.linspace(0.2, 2.5, Lk, dtype=np.float32)[None, :, None]          # later keys produce ever larger scores
+    v = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    keep = np.ones((B, Lk), dtype=bool)
+    keep[0, :70] = False                                                       # the whole first 64-key tile is masked
+    keep[1, 200:] = False
+    bias = np.where(keep, 0.0, -10000.0).astype(np.float32)
+    qr, kr, vr = (rnd(t, prec) for t in (q, k, v))
+    ref = ref_attention(qr, kr, vr, bias, H, prec)
+    esz = 2 if prec == 1 else 4
+    a = AttnArgs()
+    d_q, d_kv = OpBuf(q, prec), OpBuf(np.concatenate([k, v], axis=-1), prec)
+    a.q, a.k, a.v = d_q.ptr, d_kv.ptr, d_kv.ptr + D * esz
+    a.ldq, a.ldk, a.ldv = D, 2 * D, 2 * D
+    a.B, a.H, a.Lq, a.Lk = B, H, Lq, Lk
+    d_bias = _dev(bias)
+    a.bias = d_bias.ptr
+    a.scale = 1.0 / np.sqrt(hd)
+    d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
+    a.out, a.ldo = d_out.ptr, D
+    check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
+    sync()
+    out = d_out.read((B, Lq, D))
+    e = rel_l2(out, ref)
+    diag(f"attn reference-shift extremes prec={prec}: rel_l2={e:.3e} nan={int(np.isnan(out).sum())} inf={int(np.isinf(out).sum())}")
+    assert np.isfinite(out).all()
+    assert e < (3e-5 if prec == 0 else 3e-2), e        # bf16: near one-hot softmax over bf16-rounded P
+
+
+@pytest.mark.parametrize("prec", [0, 1], ids=["fp32", "bf16"])
 @pytest.mark.parametrize("ln", [False, True], ids=["plain", "ln_linear"])
 @pytest.mark.parametrize("hd,Lq,Lk", [(16, 150, 69), (32, 70, 130), (48, 33, 21), (64, 40, 200)])
 def test_attention_fused_query_projection(hd, Lq, Lk, ln, prec, diag):
