@@ -1318,6 +1318,13 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.ln_stats && (!g.ln_wsum || g.ln_dim <= 0 || (g.ln_dim & 127) || g.ln_dim > 512)) return hipErrorInvalidValue;
   if (g.rowstats && (g.N & 127)) return hipErrorInvalidValue;
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
+  {   // the DMA addresses rows by 32-bit byte offsets from each tensor's base: every operand must stay below 4 GB
+    const unsigned long long sz = prec == PREC_BF16 ? 2 : 4, lim = 0xFFF00000ull;
+    const unsigned long long rows = (unsigned long long)g.B * g.Tin;
+    if (rows * g.lda0 * sz > lim || (g.c1 && rows * g.lda1 * sz > lim) || (g.c2 && rows * g.lda2 * sz > lim) ||
+        (unsigned long long)g.N * g.K * sz > lim)
+      return hipErrorInvalidValue;
+  }
   if (prec == PREC_BF16) return launch_typed<bf16_t>(g, s);
   return launch_typed<float>(g, s);
 }
