@@ -137,7 +137,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("NS2VC_LIB") or LIB_PATH      # NS2VC_LIB: A/B a variant build (make OUT=../lib/variants/x)
     if not os.path.exists(p):
         raise Ns2vcError(f"{p} not found: the HIP engine is not built. Run __graft_entry__.build() "
                          f"(or `make -C ns2vc_amd/csrc`). There is no CPU fallback.")
