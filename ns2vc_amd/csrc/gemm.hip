@@ -156,8 +156,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
             const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
+          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ocol, v.x, v.y, v.z, v.w);
+          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
         }
       }
       (void)LPR;
@@ -194,8 +194,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
         if (m < g.M) {
           float4 v;
           v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
+          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ncol, v.x, v.y, v.z, v.w);
+          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
           ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
         }
@@ -659,8 +659,8 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
             const float4 rr = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ocol);
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ocol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
+          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ocol, v.x, v.y, v.z, v.w);
+          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ocol, v.x, v.y, v.z, v.w);
         }
       }
     } else {
@@ -684,8 +684,8 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
         if (m < g.M) {
           float4 v;
           v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
-          if (of) *reinterpret_cast<float4*>(of + (size_t)m * g.ldo_f32 + ncol) = v;
-          if (oo) store_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
+          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ncol, v.x, v.y, v.z, v.w);
+          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
           ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
         }

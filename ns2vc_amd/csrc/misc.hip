@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const size_t row = (size_t)b * T + r;
         float y0 = w[k].x * sc[0] + sh[0], y1 = w[k].y * sc[1] + sh[1], y2 = w[k].z * sc[2] + sh[2], y3 = w[k].w * sc[3] + sh[3];
         if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-        store_op4<TM>(out + row * C + c, y0, y1, y2, y3);
-        if (raw) store_op4<TM>(raw + row * C + c, w[k].x, w[k].y, w[k].z, w[k].w);
+        out_op4<TM>(out + row * C + c, y0, y1, y2, y3);
+        if (raw) out_op4<TM>(raw + row * C + c, w[k].x, w[k].y, w[k].z, w[k].w);
       }
     }
   }
@@ -505,11 +505,11 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
   }
     NS2VC_UPD(x) NS2VC_UPD(y) NS2VC_UPD(z) NS2VC_UPD(w)
 #undef NS2VC_UPD
-    reinterpret_cast<float4*>(xe)[i] = oxe;
-    store_op4<TM>(xe_op + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
-    reinterpret_cast<float4*>(xbar)[i] = oxb;
-    reinterpret_cast<float4*>(d1)[i] = od1;
-    reinterpret_cast<float4*>(mprev)[i] = om;
+    out_f4(xe + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
+    out_op4<TM>(xe_op + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
+    out_f4(xbar + 4 * i, oxb.x, oxb.y, oxb.z, oxb.w);
+    out_f4(d1 + 4 * i, od1.x, od1.y, od1.z, od1.w);
+    out_f4(mprev + 4 * i, om.x, om.y, om.z, om.w);
   }
 }
 __global__ void step_advance_kernel(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1; }
