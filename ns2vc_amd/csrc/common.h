@@ -60,10 +60,13 @@ template <> __device__ __forceinline__ void store_op4<bf16_t>(bf16_t* p, float a
 #ifndef NS2VC_WT_STORES
 #define NS2VC_WT_STORES 1
 #endif
+#ifndef NS2VC_WT_MOD
+#define NS2VC_WT_MOD "sc1"
+#endif
 __device__ __forceinline__ void out_store16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
 #if NS2VC_WT_STORES
   const u32x4_t v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off " NS2VC_WT_MOD "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
 #endif
@@ -72,7 +75,7 @@ __device__ __forceinline__ void out_store8(void* p, uint32_t a, uint32_t b) {
 #if NS2VC_WT_STORES
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
   const u32x2_t v = {a, b};
-  asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, off " NS2VC_WT_MOD "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #else
   *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
 #endif
