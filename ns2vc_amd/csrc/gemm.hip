@@ -733,7 +733,7 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 //     64-wide K tile (ks 0,1 / ks 2,3), so a wave issues half the DMA pieces (3-4 per tile instead of 6-8), eight
 //     waves keep the CU's load path full, and fragment reads drop to 0.5-0.75 KB per MFMA;
 //   * BM x 128 tiles with BM = 128 where the grid still covers the chip (one workgroup per CU) and 64 otherwise;
-//   * 3-deep ring by default: the DMA queue never drains between K tiles;
+//   * 3-deep ring: the DMA queue never drains between K tiles;
 //   * the two K halves meet in the epilogue: both stage their accumulators in LDS (32-row slabs, re-using the ring),
 //     then all eight waves add the pair while they transpose rows out -- every wave stores, nothing idles.
 // ---------------------------------------------------------------------------
@@ -913,11 +913,11 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
           for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
       }
     };
-    // The two K halves run the step in opposite order, so the CU's load path and its MFMA pipes are both busy all
-    // the time instead of alternating (the refill target, the stage of tile kt-1, is free for everyone after the barrier).
-    if (kg == 0) refill();       // (one copy of the MFMA block: two would make hipcc shuffle the accumulators between register sets)
+    // The refill target (the stage of tile kt-1) is free for everyone after the barrier.
+    // (Running the two K halves in opposite order -- one refills first, the other multiplies first -- is 1 % faster for
+    // an isolated launch but 0.5 % slower inside the captured step (same-box A/B), so both refill first.)
+    refill();
     multiply();
-    if (kg != 0) refill();
     if (++stage == STAGES) stage = 0;
   }
 
