@@ -141,6 +141,13 @@ def load(path: Optional[str] = None) -> C.CDLL:
     if not os.path.exists(p):
         raise Ns2vcError(f"{p} not found: the HIP engine is not built. Run __graft_entry__.build() "
                          f"(or `make -C ns2vc_amd/csrc`). There is no CPU fallback.")
+    # PyTorch-ROCm wheels bundle their own libamdhip64; if this library pulled in the system one first, a later
+    # `import torch` would bring a second HIP runtime into the process and torch would see no devices.  Let torch (when
+    # present) load its runtime first -- the engine then binds to the already-loaded HIP symbols.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(p)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported

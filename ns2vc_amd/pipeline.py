@@ -82,3 +82,64 @@ class Denoiser:
         pm = None if prompt_mask is None else prompt_mask[lo:hi]
         local = self.sample(content[lo:hi], prompt[lo:hi], pm, noise[lo:hi], **kw)
         return _dist.gather_latents(local, n)
+
+
+class OverlappedPipeline:
+    """Three-stage utterance-batch pipeline on three HIP streams: the PyTorch-ROCm front end (ContentVec / ``Pre_model.infer``,
+    reference ``model.py:359-376``) and back end (``vocos.decode``, ``model.py:689-696``) overlap the denoiser instead of
+    running before / after it (BASELINE.json north_star):
+
+        pre(k+1)   |   denoise(k)   |   post(k-1)
+
+    ``pre_fn(item)`` runs on the front-end stream and returns a dict with torch CUDA tensors ``content`` (B,256,T),
+    ``prompt`` (B,Lp,256) and optionally ``prompt_mask`` (B,Lp) bool and ``noise`` (B,100,T); ``post_fn(latent, item)``
+    runs on the back-end stream with the sampled latent (B,100,T) fp32.  Ordering is by events only -- the host never
+    blocks until the end of ``run`` -- and the denoiser still replays one captured hipGraph per step on its own stream.
+    """
+
+    def __init__(self, denoiser: Denoiser, pre_fn, post_fn, solver: str = "unipc", steps: int = 20, order: int = 2,
+                 use_graph: bool = True):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("OverlappedPipeline needs a ROCm device (there is no CPU path)")
+        self.denoiser, self.pre_fn, self.post_fn = denoiser, pre_fn, post_fn
+        self.kw = dict(solver=solver, steps=steps, order=order, use_graph=use_graph)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self.s_pre, self.s_den, self.s_post = (torch.cuda.Stream(dev) for _ in range(3))
+
+    def _launch_pre(self, item):
+        import torch
+        with torch.cuda.stream(self.s_pre):
+            cond = self.pre_fn(item)
+            ev = torch.cuda.Event()
+            ev.record(self.s_pre)
+        return item, cond, ev
+
+    def run(self, items):
+        """Process an iterable of work items; returns ``[post_fn(latent_k, item_k) for k]`` (all streams drained)."""
+        import torch
+        it = iter(items)
+        first = next(it, None)
+        cur = self._launch_pre(first) if first is not None else None
+        results = []
+        while cur is not None:
+            item, cond, ev_pre = cur
+            nxt = next(it, None)
+            nxt_pre = self._launch_pre(nxt) if nxt is not None else None     # front end of batch k+1 under denoise(k)
+            with torch.cuda.stream(self.s_den):
+                self.s_den.wait_event(ev_pre)
+                for v in cond.values():
+                    if isinstance(v, torch.Tensor):
+                        v.record_stream(self.s_den)
+                latent = self.denoiser.sample(cond["content"], cond["prompt"], cond.get("prompt_mask"), cond.get("noise"), **self.kw)
+                ev_den = torch.cuda.Event()
+                ev_den.record(self.s_den)
+            with torch.cuda.stream(self.s_post):
+                self.s_post.wait_event(ev_den)
+                latent.record_stream(self.s_post)
+                results.append(self.post_fn(latent, item))                   # back end of batch k under denoise(k+1)
+            cur = nxt_pre
+        self.s_post.synchronize()
+        self.s_den.synchronize()
+        return results
