@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NS2VC_ABI_VERSION 1
+#define NS2VC_ABI_VERSION 2
 #define NS2VC_MAX_LEVELS 8
 #define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
 
@@ -49,8 +49,13 @@ typedef struct ns2vc_unet_cfg {
   int32_t pool_heads;         /* 64 (addition_embed_type_num_heads)               */
 } ns2vc_unet_cfg;
 
-enum { NS2VC_PREC_F32 = 0,  /* fp32 storage, exact-fp32 MFMA: parity mode (<= 1e-3 gate) */
-       NS2VC_PREC_BF16 = 1  /* bf16 MFMA operands, fp32 accumulate / norm stats / solver state */ };
+/* Operand precision = what the MFMAs read (activations as GEMM / attention operands, packed weights).  In every mode the
+ * residual stream, GroupNorm / LayerNorm statistics, softmax state, accumulators and the solver state are fp32.
+ * Measured end-to-end error of the predicted latent vs the reference fp32 CPU path (tests/test_engine_gpu.py):
+ *   F32 1e-6, F16 8e-4 (inside the 1e-3 parity gate: the default 16-bit mode), BF16 6.5e-3 (same speed as F16). */
+enum { NS2VC_PREC_F32 = 0,  /* fp32 operands, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) */
+       NS2VC_PREC_BF16 = 1, /* bf16 operands (v_mfma_f32_32x32x16_bf16) */
+       NS2VC_PREC_F16 = 2   /* fp16 operands (v_mfma_f32_32x32x16_f16); stores saturate at +-65504 */ };
 
 /* ---- library ----------------------------------------------------------------------- */
 int ns2vc_abi_version(void);
@@ -71,6 +76,16 @@ int ns2vc_unet_load_weight(ns2vc_unet* h, const char* key, const void* data, con
 int ns2vc_unet_finalize_weights(ns2vc_unet* h, int precision);
 int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int buflen);
 
+/* Plan options, by name; call before ns2vc_unet_prepare (an existing plan / workspace is dropped):
+ *   "ln_linear" 1|0  LayerNorm by linearity (default 1) vs explicit normalisation passes
+ *   "fold_ff"   1|0  ff.net.2 folded into proj_out at pack time (default 1) vs two launches
+ * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF set the defaults at ns2vc_unet_create. */
+int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value);
+/* LayerNorm-by-linearity health: the largest |mean| / std over every LayerNorm input row seen since the last call
+ * (or since prepare).  The 16-bit modes round the raw row before centring, so their error on a row grows ~linearly
+ * with this ratio (1 at ratio <~ 1; use "ln_linear" 0 when it is >> 10).  Synchronises the device; resets the maximum. */
+int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio);
+
 /* Allocate workspace and build the launch plan for a (batch, frames, prompt frames) shape. */
 int ns2vc_unet_prepare(ns2vc_unet* h, int B, int T, int Lp);
 int ns2vc_unet_workspace_bytes(ns2vc_unet* h, size_t* out);
@@ -81,6 +96,14 @@ int ns2vc_unet_workspace_bytes(ns2vc_unet* h, size_t* out);
  * (model.py:409, unet_1d_condition.py:943) and the mask -> bias conversion (:816-818).
  * content (B, content_channels, T); prompt (B, Lp, cross_dim); mask (B, Lp) or NULL. */
 int ns2vc_unet_set_condition(ns2vc_unet* h, const float* content_bct, const float* prompt_blc, const uint8_t* mask_bl, void* stream);
+/* The two halves of set_condition, for callers whose content and prompt change at different rates (the drop-in
+ * nn.Module receives cat([x, content]) anew on every solver step, model.py:409, while the prompt tensor persists):
+ * set_content = content half of conv_in only; set_prompt = cross-attention K/V, add_embedding (+ set_mask);
+ * set_mask = the (B, Lp) keep-mask -> additive bias conversion only (NULL = no mask), for a mask tensor that is rebuilt
+ * per call (model.py:412) over an unchanged prompt. */
+int ns2vc_unet_set_content(ns2vc_unet* h, const float* content_bct, void* stream);
+int ns2vc_unet_set_prompt(ns2vc_unet* h, const float* prompt_blc, const uint8_t* mask_bl, void* stream);
+int ns2vc_unet_set_mask(ns2vc_unet* h, const uint8_t* mask_bl, void* stream);
 
 /* One denoiser evaluation = Diffusion_Encoder.forward (model.py:403-415) ->
  * UNet1DConditionModel.forward (unet_1d_condition.py:743-1037) for the condition set above.
@@ -96,7 +119,7 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host);
 int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* stream);
 
 /* ---- introspection for tests / profiling -------------------------------------------- */
-int ns2vc_unet_set_debug(ns2vc_unet* h, int enable);  /* before prepare(): keep a copy of every block output */
+int ns2vc_unet_set_debug(ns2vc_unet* h, int enable);  /* keep a copy of every block output; drops the plan: call before prepare() */
 int ns2vc_unet_num_taps(ns2vc_unet* h);
 int ns2vc_unet_tap_info(ns2vc_unet* h, int idx, char* name, int buflen, int* rows, int* cols);
 int ns2vc_unet_tap_read(ns2vc_unet* h, int idx, float* host_dst);   /* synchronous, [rows][cols] channels-last */
@@ -124,7 +147,7 @@ int ns2vc_event_elapsed_ms(void* start, void* stop, float* ms);  /* synchronises
 
 /* ---- kernel-level entry points (unit-tested one by one through this ABI) -------------- */
 typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stride 2, nearest-up), linear */
-  /* "operand" tensors are stored in the engine's MFMA operand type: bf16 (precision 1) or fp32 (precision 0) */
+  /* "operand" tensors are stored in the engine's MFMA operand type: fp32 (precision 0), bf16 (1) or fp16 (2) */
   const void* a0; const void* a1; /* channels-last operand-typed sources; a1 = second half of a no-copy concat or NULL */
   int32_t lda0, lda1, c0, c1;
   int32_t B, Tin, Tout, M;        /* M = B*Tout output rows */
@@ -152,24 +175,8 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    *             of the packed, rounded weights (ns2vc_weight_rowsum). */
   float* rowstats;
   const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
+  unsigned* ln_health;            /* optional (consumer): atomicMax of the bits of |mean| * rstd over the rows, or NULL */
 } ns2vc_gemm_args;
-
-/* GroupNorm(+time scale/shift)(+SiLU) fused INTO a 3-tap conv (resnet.py:591-641: conv(act(norm(x)))): the kernel reads the
- * fp32 stream rows (+1 halo row each side) itself, normalises them in registers and keeps them as an operand panel in
- * LDS for all three taps -- no normalisation pass, no operand tensor in HBM.  g.a0/g.a1 are ignored (the fp32 sources
- * x0/x1 take their place, channel split g.c0 | g.c1); g.taps must be 3, g.tmode 0, g.Tin == g.Tout >= 66,
- * g.c0 + g.c1 <= 512 and a multiple of 64, groups == 8; everything else (a2 segment, bias, residual, outputs,
- * statistics of the result) as in ns2vc_gemm_args. */
-typedef struct ns2vc_convgn_args {
-  ns2vc_gemm_args g;
-  const float* x0; const float* x1; int32_t ldx0, ldx1;   /* fp32 concat sources, channels-last */
-  const long long* st0; const long long* st1;             /* their epilogue statistics [B][c/16][2] (see ns2vc_gemm_args.stats) */
-  const float* gamma; const float* beta;                  /* [c0 + c1] */
-  const float* temb; int32_t ldtemb, temb_off;            /* optional (1 + scale | shift) rows [B][ldtemb], or NULL */
-  int32_t groups; float eps; int32_t silu;
-  void* raw_op;                                           /* optional operand-typed copy of the raw concat rows [M][c0 + c1] */
-} ns2vc_convgn_args;
-int ns2vc_k_convgn(const ns2vc_convgn_args* a, int precision, void* stream);
 
 typedef struct ns2vc_attn_args {
   const void* q; const void* k; const void* v; /* operand-typed rows; head h lives at columns [h*hd, (h+1)*hd) */
@@ -178,32 +185,19 @@ typedef struct ns2vc_attn_args {
   const float* bias;              /* additive [B][Lk] or NULL */
   float scale;
   void* out; int32_t ldo;         /* operand-typed */
-  /* optional fused query projection (cross-attention to_q, attention_processor.py:1013): when q == NULL,
-   *   Q[m][h*hd + d] = sum_c xq[m][c] * wq[h*hd + d][c] + bq[h*hd + d]
-   * is computed by the kernel itself (xq operand-typed [B*Lq][ldx], wq packed [H*hd][xdim] from ns2vc_pack_weight,
-   * xdim % 16 == 0); with ln_stats != NULL, xq is the RAW input of a LayerNorm and the projection gets the same
-   * LayerNorm-by-linearity fix-up as in the GEMM arguments: ln_stats [B*Lq][ln_dim/64][2], ln_wsum [H*hd]. */
-  const void* xq; int32_t ldx, xdim; const void* wq; const float* bq;
-  const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
 } ns2vc_attn_args;
 
 /* operand-typed conversions for tests: fp32 host [n] -> device operand buffer and back */
 int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev);
 int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);
+/* the host-side rounding used for weight packing (round to nearest even; fp16 overflow -> inf): host in, host out, no GPU needed */
+int ns2vc_round_to_operand(const float* host_in, size_t n, int precision, float* host_out);
 int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
 int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev); /* [N] fp32: sum_k round_to_operand(rows[n][k]) */
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
-int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile (128|64 x 128|64) and LDS ring depth (2..4); 0,0,0 = heuristic */
+int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile: stages 2..4 = 4-wave kernel ring depth, 12|13 = 8-wave K-split kernel ring 2|3; 0,0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
-/* Fused transformer row chains (bf16 operand type only).  A chain's weights are ONE device buffer of 16 KB tiles
- * ([128 rows][64 k] bf16 in the kernel's swizzled LDS image, in consumption order) built by ns2vc_pack_chain_stream
- * from `count` row-major fp32 matrices [Ns[i]][Ks[i]] (Ns multiple of 128, Ks multiple of 64).
- * ns2vc_k_chain_ab:  y = A*W1^T + bias1 (+res) [fp32, M x D]; out2 = LayerNorm(y)*W2^T + bias2 [bf16, M x N2]
- * (LayerNorm without affine: gamma/beta are folded into W2/bias2 by the caller). */
-int ns2vc_pack_chain_stream(const float* const* mats_host, const int* Ns, const int* Ks, int count, void** out_dev);
-int ns2vc_k_chain_ab(const void* a_op, int M, int D, const void* wstream, const float* bias1, const float* res, float* y, float eps,
-                     const float* bias2, void* out2_op, int N2, void* stream);
 /* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,
  * written as an operand tensor [B*T][c0+c1]; raw_op (optional) receives the un-normalised concat. Synchronous. */
 int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
 NCOEF = 12
 MAX_LEVELS = 8
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+ABI_VERSION = 2
 
 
 class Ns2vcError(RuntimeError):
@@ -44,18 +45,7 @@ class GemmArgs(C.Structure):
         ("a2", C.c_void_p), ("lda2", C.c_int32), ("c2", C.c_int32),
         ("rowstats", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
-    ]
-
-
-class ConvGnArgs(C.Structure):
-    _fields_ = [
-        ("g", GemmArgs),
-        ("x0", C.c_void_p), ("x1", C.c_void_p), ("ldx0", C.c_int32), ("ldx1", C.c_int32),
-        ("st0", C.c_void_p), ("st1", C.c_void_p),
-        ("gamma", C.c_void_p), ("beta", C.c_void_p),
-        ("temb", C.c_void_p), ("ldtemb", C.c_int32), ("temb_off", C.c_int32),
-        ("groups", C.c_int32), ("eps", C.c_float), ("silu", C.c_int32),
-        ("raw_op", C.c_void_p),
+        ("ln_health", C.c_void_p),
     ]
 
 
@@ -66,8 +56,6 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("bias", C.c_void_p), ("scale", C.c_float),
         ("out", C.c_void_p), ("ldo", C.c_int32),
-        ("xq", C.c_void_p), ("ldx", C.c_int32), ("xdim", C.c_int32), ("wq", C.c_void_p), ("bq", C.c_void_p),
-        ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
     ]
 
 
@@ -89,10 +77,15 @@ PROTOTYPES = {
     "ns2vc_unet_prepare": (_I, [_P, _I, _I, _I]),
     "ns2vc_unet_workspace_bytes": (_I, [_P, C.POINTER(C.c_size_t)]),
     "ns2vc_unet_set_condition": (_I, [_P, _P, _P, _P, _P]),
+    "ns2vc_unet_set_content": (_I, [_P, _P, _P]),
+    "ns2vc_unet_set_prompt": (_I, [_P, _P, _P, _P]),
+    "ns2vc_unet_set_mask": (_I, [_P, _P, _P]),
     "ns2vc_unet_forward": (_I, [_P, _P, _P, _P, _P]),
     "ns2vc_sampler_load": (_I, [_P, _I, C.POINTER(C.c_float)]),
     "ns2vc_sampler_run": (_I, [_P, _P, _I, _P]),
     "ns2vc_unet_set_debug": (_I, [_P, _I]),
+    "ns2vc_unet_set_option": (_I, [_P, C.c_char_p, _I]),
+    "ns2vc_unet_ln_ratio": (_I, [_P, C.POINTER(C.c_float)]),
     "ns2vc_unet_num_taps": (_I, [_P]),
     "ns2vc_unet_tap_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ns2vc_unet_tap_read": (_I, [_P, _I, _P]),
@@ -114,16 +107,14 @@ PROTOTYPES = {
     "ns2vc_pack_weight": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_k_gemm": (_I, [C.POINTER(GemmArgs), _I, _P]),
     "ns2vc_weight_rowsum": (_I, [_P, _I, _I, _I, _PP]),
-    "ns2vc_k_convgn": (_I, [C.POINTER(ConvGnArgs), _I, _P]),
     "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
-    "ns2vc_pack_chain_stream": (_I, [C.POINTER(C.c_void_p), C.POINTER(_I), C.POINTER(_I), _I, _PP]),
-    "ns2vc_k_chain_ab": (_I, [_P, _I, _I, _P, _P, _P, _P, C.c_float, _P, _P, _I, _P]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),
     "ns2vc_from_operand": (_I, [_P, C.c_size_t, _I, _P]),
+    "ns2vc_round_to_operand": (_I, [_P, C.c_size_t, _I, _P]),
     "ns2vc_k_nct_to_btc": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "ns2vc_k_btc_to_nct": (_I, [_P, _I, _I, _I, _I, _P, _P]),
 }
@@ -153,8 +144,8 @@ def load(path: Optional[str] = None) -> C.CDLL:
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.ns2vc_abi_version() != 1:
-        raise Ns2vcError(f"ABI version mismatch: library reports {lib.ns2vc_abi_version()}, binding expects 1")
+    if lib.ns2vc_abi_version() != ABI_VERSION:
+        raise Ns2vcError(f"ABI version mismatch: library reports {lib.ns2vc_abi_version()}, binding expects {ABI_VERSION}")
     if path is None:
         _lib = lib
     return lib

@@ -18,6 +18,7 @@
 // head_dim in {16,32,48,64} (NS2VC: C_l/8 for C_l in {128,256,384,512}).
 // q/k/v/out are operand-typed tensors (bf16, or fp32 in parity mode): no conversions while staging.
 #include "common.h"
+#include "mma.h"
 
 namespace ns2vc {
 
@@ -40,24 +41,20 @@ template <> struct AMma<float> {
   // position (in elements) of key `key` (0..31) inside a 32-key V^T sub-row
   __device__ static __forceinline__ int vpos(int key) { return key; }
 };
-template <> struct AMma<bf16_t> {
+template <typename TM> struct AMma16 {     // bf16_t / f16_t: one v_mfma_f32_32x32x16_{bf16,f16} per 32-B k-slab
   static constexpr int SZ = 2;
-  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
-    union U { u32x4_t u; bf16x8_t v; };
-    U ua, ub;
-    ua.u = a; ub.u = b;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
-  }
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) { MmaT<TM>::mma(acc, a, b); }
   __device__ static __forceinline__ f32x16_t mma0(const u32x4_t& a, const u32x4_t& b) {   // acc = a*b (srcC = inline 0)
-    union U { u32x4_t u; bf16x8_t v; };
-    U ua, ub;
-    ua.u = a; ub.u = b;
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, f32x16_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    f32x16_t acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    MmaT<TM>::mma(acc, a, b);
+    return acc;
   }
   // swap key bits 2 and 3 so that the 8 keys one lane-half contributes to a
   // 16-key MFMA k-slab are contiguous (see header comment of attn_kernel)
   __device__ static __forceinline__ int vpos(int key) { return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1); }
 };
+template <> struct AMma<bf16_t> : AMma16<bf16_t> {};
+template <> struct AMma<f16_t> : AMma16<f16_t> {};
 
 // scatter the EPC elements of one 16-B piece (one key, EPC consecutive d) down a V^T column
 template <typename TM> __device__ __forceinline__ void vt_scatter(char* vp, int rowb, const u32x4_t& v);
@@ -67,7 +64,7 @@ template <> __device__ __forceinline__ void vt_scatter<float>(char* vp, int rowb
   *reinterpret_cast<uint32_t*>(vp + 2 * rowb) = v.z;
   *reinterpret_cast<uint32_t*>(vp + 3 * rowb) = v.w;
 }
-template <> __device__ __forceinline__ void vt_scatter<bf16_t>(char* vp, int rowb, const u32x4_t& v) {
+__device__ __forceinline__ void vt_scatter16(char* vp, int rowb, const u32x4_t& v) {
   *reinterpret_cast<uint16_t*>(vp) = (uint16_t)v.x;
   *reinterpret_cast<uint16_t*>(vp + rowb) = (uint16_t)(v.x >> 16);
   *reinterpret_cast<uint16_t*>(vp + 2 * rowb) = (uint16_t)v.y;
@@ -77,6 +74,8 @@ template <> __device__ __forceinline__ void vt_scatter<bf16_t>(char* vp, int row
   *reinterpret_cast<uint16_t*>(vp + 6 * rowb) = (uint16_t)v.w;
   *reinterpret_cast<uint16_t*>(vp + 7 * rowb) = (uint16_t)(v.w >> 16);
 }
+template <> __device__ __forceinline__ void vt_scatter<bf16_t>(char* vp, int rowb, const u32x4_t& v) { vt_scatter16(vp, rowb, v); }
+template <> __device__ __forceinline__ void vt_scatter<f16_t>(char* vp, int rowb, const u32x4_t& v) { vt_scatter16(vp, rowb, v); }
 
 // combine a value with its partner lane (lane ^ 32) without an LDS round trip: v_permlane32_swap puts the lower
 // half's values in one result and the upper half's in the other, for every lane
@@ -93,13 +92,16 @@ __device__ __forceinline__ float half_sum(float v) {
 template <typename TM> __device__ __forceinline__ float round_op(float x);
 template <> __device__ __forceinline__ float round_op<float>(float x) { return x; }
 template <> __device__ __forceinline__ float round_op<bf16_t>(float x) { return __uint_as_float(pack_bf16x2(0.f, x) & 0xffff0000u); }
+template <> __device__ __forceinline__ float round_op<f16_t>(float x) { return f16_lo(pack_f16x2(x, 0.f)); }
 // first 16-B chunk of a K/Q "aux" k-slab: {e0, e1, 0, ...}
 template <typename TM> __device__ __forceinline__ u32x4_t aux_chunk(float e0, float e1);
 template <> __device__ __forceinline__ u32x4_t aux_chunk<float>(float e0, float e1) { return u32x4_t{__float_as_uint(e0), __float_as_uint(e1), 0u, 0u}; }
 template <> __device__ __forceinline__ u32x4_t aux_chunk<bf16_t>(float e0, float e1) { return u32x4_t{pack_bf16x2(e0, e1), 0u, 0u, 0u}; }
+template <> __device__ __forceinline__ u32x4_t aux_chunk<f16_t>(float e0, float e1) { return u32x4_t{pack_f16x2(e0, e1), 0u, 0u, 0u}; }
 template <typename TM> __device__ __forceinline__ TM op_from_float(float x);
 template <> __device__ __forceinline__ float op_from_float<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t op_from_float<bf16_t>(float x) { bf16_t r; r.v = (uint16_t)pack_bf16x2(x, 0.f); return r; }
+template <> __device__ __forceinline__ f16_t op_from_float<f16_t>(float x) { f16_t r; r.v = (uint16_t)pack_f16x2(x, 0.f); return r; }   // (-inf passes)
 
 // The attention kernel is VALU-bound on MI355X (v_exp_f32 is quarter rate and every score used to cost a scale-fma,
 // a max, a subtract, an exp, a sum-add and half a convert), while its MFMA pipe idles.  So everything except max / exp /
@@ -113,7 +115,7 @@ template <> __device__ __forceinline__ bf16_t op_from_float<bf16_t>(float x) { b
 //     by the MFMA is exact too);
 //   * V^T carries a row of ones, so the PV MFMA also accumulates the denominator (of the SAME rounded probabilities
 //     that build the numerator): no per-score add, no separate running sum.
-template <typename TM, int HD, bool QPROJ>
+template <typename TM, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
   // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2e: lane (q, hi) holds d = s*2*EPC + hi*EPC .. +EPC
   u32x4_t qf[NS];
-  if constexpr (!QPROJ) {
+  {
     const TM* qp = reinterpret_cast<const TM*>(a.q) + ((size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldq + h * HD);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -174,95 +176,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         qf[s] = u32x4_t{__float_as_uint(__uint_as_float(raw.x) * sc2), __float_as_uint(__uint_as_float(raw.y) * sc2),
                         __float_as_uint(__uint_as_float(raw.z) * sc2), __float_as_uint(__uint_as_float(raw.w) * sc2)};
       } else {
-        auto sc = [&](uint32_t w) __attribute__((always_inline)) {
-          return pack_bf16x2(__uint_as_float(w << 16) * sc2, __uint_as_float(w & 0xffff0000u) * sc2);
-        };
+        auto sc = [&](uint32_t w) __attribute__((always_inline)) { return Op16<TM>::pack(Op16<TM>::lo(w) * sc2, Op16<TM>::hi(w) * sc2); };
         qf[s] = u32x4_t{sc(raw.x), sc(raw.y), sc(raw.z), sc(raw.w)};
       }
       if (q >= a.Lq) qf[s] = u32x4_t{0, 0, 0, 0};
-    }
-  } else {
-    // Fused query projection: Q^T[d][q] = sum_c Wq[h*HD + d][c] * x[q][c] on the MFMA (A = weight rows, B = this wave's
-    // 32 input rows, both straight from global memory / L2 -- the launch of a separate to_q GEMM is gone), then bias,
-    // LayerNorm-by-linearity fix-up and the softmax scale in registers, and a half-wave exchange turns the
-    // accumulator layout (4 consecutive d per lane half) into the B-operand layout (EPC consecutive d).
-    constexpr int DB = (HD + 31) / 32;
-    f32x16_t qa[DB];
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) qa[db][r] = 0.f;
-    const TM* xr = reinterpret_cast<const TM*>(a.xq) + (size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldx + hi * EPC;
-    const TM* wr = reinterpret_cast<const TM*>(a.wq) + (size_t)(h * HD + l31) * a.xdim + hi * EPC;
-    const int nks = a.xdim / (2 * EPC);
-    for (int k0 = 0; k0 < nks; k0 += 4) {
-      u32x4_t xf[4], wf[4][DB];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool in = k0 + u < nks;
-        xf[u] = in ? *reinterpret_cast<const u32x4_t*>(xr + (k0 + u) * 2 * EPC) : u32x4_t{0, 0, 0, 0};
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-          wf[u][db] = (in && db * 32 + l31 < HD) ? *reinterpret_cast<const u32x4_t*>(wr + (size_t)db * 32 * a.xdim + (k0 + u) * 2 * EPC)
-                                                 : u32x4_t{0, 0, 0, 0};
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int db = 0; db < DB; ++db) AMma<TM>::mma(qa[db], wf[u][db], xf[u]);
-    }
-    // this lane's query row statistics (both lane halves hold the same query)
-    float mu = 0.f, rs = 1.f;
-    if (a.ln_stats) {
-      const int n4 = a.ln_dim >> 7;
-      const float4* p = reinterpret_cast<const float4*>(a.ln_stats + (size_t)(b * a.Lq + min(q, a.Lq - 1)) * (a.ln_dim >> 6) * 2);
-      float sm = 0.f, sq = 0.f;
-      for (int i = 0; i < n4; ++i) { const float4 v = p[i]; sm += v.x + v.z; sq += v.y + v.w; }
-      const float inv = 1.0f / (float)a.ln_dim;
-      mu = sm * inv;
-      double var = (double)sq * (double)inv - (double)mu * (double)mu;
-      if (var < 0.0) var = 0.0;
-      rs = 1.0f / sqrtf((float)var + a.ln_eps);
-    }
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int d0 = db * 32 + 8 * gq + 4 * hi;                 // rows of registers 4*gq .. 4*gq+3
-        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), ww = bb;
-        if (d0 < HD) {
-          if (a.bq) bb = *reinterpret_cast<const float4*>(a.bq + h * HD + d0);
-          if (a.ln_stats) ww = *reinterpret_cast<const float4*>(a.ln_wsum + h * HD + d0);
-        }
-        const float bbv[4] = {bb.x, bb.y, bb.z, bb.w}, wwv[4] = {ww.x, ww.y, ww.z, ww.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = rs * (qa[db][4 * gq + i] - mu * wwv[i]) + bbv[i];
-          qa[db][4 * gq + i] = (d0 < HD && q < a.Lq) ? round_op<TM>(v) * sc2 : 0.f;       // (the separate GEMM rounded Q to the operand type)
-        }
-      }
-    if constexpr (SZ == 4) {        // fp32: slab s = 8 d's, lane half hi owns d = 8s + 4hi .. +4 = registers 4*(s%4) .. +3 of block s/4
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const f32x16_t& blk = qa[s / 4];
-        const int r0 = 4 * (s % 4);
-        qf[s] = u32x4_t{__float_as_uint(blk[r0]), __float_as_uint(blk[r0 + 1]), __float_as_uint(blk[r0 + 2]), __float_as_uint(blk[r0 + 3])};
-      }
-    } else {                        // bf16: slab s = 16 d's = registers 8*(s%2) .. +7 of block s/2; exchange 4 of them with lane^32
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const f32x16_t& blk = qa[s / 2];
-        const int r0 = 8 * (s % 2);
-        float lo[4], hi4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // vdst = rows 16ls+0..3 (+4hi), vsrc = rows 16ls+8..11 (+4hi): swap(vdst.upper, vsrc.lower)
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(blk[r0 + i]), __float_as_uint(blk[r0 + 4 + i]), false, false);
-          lo[i] = __uint_as_float(sw[0]);      // lower half: d 0..3        upper half: d 8..11
-          hi4[i] = __uint_as_float(sw[1]);     // lower half: d 4..7        upper half: d 12..15
-        }
-        qf[s] = u32x4_t{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi4[0], hi4[1]), pack_bf16x2(hi4[2], hi4[3])};
-      }
     }
   }
   float m_ref = 0.f;                       // softmax reference of this lane's query (operand-representable)
@@ -384,8 +301,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
           pf = u32x4_t{__float_as_uint(s[k2][4 * sl + 0]), __float_as_uint(s[k2][4 * sl + 1]),
                        __float_as_uint(s[k2][4 * sl + 2]), __float_as_uint(s[k2][4 * sl + 3])};
         } else {
-          pf = u32x4_t{pack_bf16x2(s[k2][8 * sl + 0], s[k2][8 * sl + 1]), pack_bf16x2(s[k2][8 * sl + 2], s[k2][8 * sl + 3]),
-                       pack_bf16x2(s[k2][8 * sl + 4], s[k2][8 * sl + 5]), pack_bf16x2(s[k2][8 * sl + 6], s[k2][8 * sl + 7])};
+          pf = u32x4_t{Op16<TM>::pack(s[k2][8 * sl + 0], s[k2][8 * sl + 1]), Op16<TM>::pack(s[k2][8 * sl + 2], s[k2][8 * sl + 3]),
+                       Op16<TM>::pack(s[k2][8 * sl + 4], s[k2][8 * sl + 5]), Op16<TM>::pack(s[k2][8 * sl + 6], s[k2][8 * sl + 7])};
         }
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
@@ -426,8 +343,7 @@ template <typename TM, int HD> static constexpr size_t attn_lds() {
 template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);
   const size_t lds = attn_lds<TM, HD>();
-  if (a.q) hipLaunchKernelGGL((attn_kernel<TM, HD, false>), grid, dim3(256), lds, s, a);
-  else hipLaunchKernelGGL((attn_kernel<TM, HD, true>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn_kernel<TM, HD>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 
@@ -442,34 +358,33 @@ template <typename TM> static hipError_t launch_tm(const AttnArgs& a, int hd, hi
 }
 
 template <typename TM, int HD> static hipError_t set_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)attn_lds<TM, HD>());
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)attn_lds<TM, HD>());
 }
-hipError_t init_attn_attributes() {
+template <typename TM> static hipError_t set_attr_tm() {
   hipError_t e;
-  if ((e = set_attr<float, 16>()) != hipSuccess) return e;
-  if ((e = set_attr<float, 32>()) != hipSuccess) return e;
-  if ((e = set_attr<float, 48>()) != hipSuccess) return e;
-  if ((e = set_attr<float, 64>()) != hipSuccess) return e;
-  if ((e = set_attr<bf16_t, 16>()) != hipSuccess) return e;
-  if ((e = set_attr<bf16_t, 32>()) != hipSuccess) return e;
-  if ((e = set_attr<bf16_t, 48>()) != hipSuccess) return e;
-  if ((e = set_attr<bf16_t, 64>()) != hipSuccess) return e;
-  return hipSuccess;
+  if ((e = set_attr<TM, 16>()) != hipSuccess) return e;
+  if ((e = set_attr<TM, 32>()) != hipSuccess) return e;
+  if ((e = set_attr<TM, 48>()) != hipSuccess) return e;
+  return set_attr<TM, 64>();
+}
+hipError_t init_attn_attributes() {
+  hipError_t e = set_attr_tm<float>();
+  if (e == hipSuccess) e = set_attr_tm<bf16_t>();
+  if (e == hipSuccess) e = set_attr_tm<f16_t>();
+  return e;
 }
 
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s) {
-  const int al = prec == PREC_BF16 ? 7 : 3;      // rows must start 16-B aligned
-  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldk & al) || (a.ldv & al) || (a.ldo & 3)) return hipErrorInvalidValue;
-  if (a.q) { if (a.ldq & al) return hipErrorInvalidValue; }
-  else {     // fused query projection
-    if (!a.xq || !a.wq || (a.ldx & al) || a.xdim <= 0 || (a.xdim & 15)) return hipErrorInvalidValue;
-    if (a.ln_stats && (!a.ln_wsum || a.ln_dim <= 0 || (a.ln_dim & 127) || a.ln_dim > 512)) return hipErrorInvalidValue;
+  const int al = prec == PREC_F32 ? 3 : 7;       // rows must start 16-B aligned
+  if (!a.q || !a.k || !a.v || !a.out) return hipErrorInvalidValue;
+  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldq & al) || (a.ldk & al) || (a.ldv & al) || (a.ldo & 3)) return hipErrorInvalidValue;
+  switch (prec) {
+    case PREC_BF16: return launch_tm<bf16_t>(a, head_dim, s);
+    case PREC_F16: return launch_tm<f16_t>(a, head_dim, s);
+    case PREC_F32: return launch_tm<float>(a, head_dim, s);
+    default: return hipErrorInvalidValue;
   }
-  return prec == PREC_BF16 ? launch_tm<bf16_t>(a, head_dim, s) : launch_tm<float>(a, head_dim, s);
 }
 
 }  // namespace ns2vc

@@ -12,8 +12,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-// 2-byte storage type for bf16 activations / weights
+// 2-byte storage types of the 16-bit operand precisions (activations / weights as the MFMA reads them)
 struct bf16_t { uint16_t v; };
+struct f16_t { uint16_t v; };
 
 __host__ __device__ inline uint16_t f32_to_bf16_bits(float f) {
   union { float f; uint32_t u; } x;
@@ -29,6 +30,42 @@ __host__ __device__ inline float bf16_bits_to_f32(uint16_t h) {
   return x.f;
 }
 
+// IEEE binary16, round to nearest even; overflow -> inf, subnormals kept (host side: weight packing, test helpers)
+__host__ __device__ inline uint16_t f32_to_f16_bits(float f) {
+  union { float f; uint32_t u; } x;
+  x.f = f;
+  const uint32_t sign = (x.u >> 16) & 0x8000u;
+  uint32_t a = x.u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);             // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            // >= 65520 rounds to inf
+  if (a < 0x38800000u) {                                              // below the smallest normal (2^-14): subnormal / zero
+    if (a < 0x33000000u) return (uint16_t)sign;                       // < 2^-25 -> 0
+    const int e = (int)(a >> 23);                                     // biased fp32 exponent, 102..112
+    const uint32_t m = (a & 0x7fffffu) | 0x800000u;                   // 24-bit significand
+    const int shift = 126 - e;                                        // 14..24: bits dropped
+    uint32_t r = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+  }
+  a += 0xc8000000u;                                                   // rebias exponent 127 -> 15 (subtract 112 << 23)
+  a += 0xfffu + ((a >> 13) & 1u);                                     // round to nearest even on the 13 dropped bits
+  return (uint16_t)(sign | (a >> 13));
+}
+__host__ __device__ inline float f16_bits_to_f32(uint16_t h) {
+  union { float f; uint32_t u; } x;
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  if (e == 0) {
+    if (m == 0) { x.u = sign; return x.f; }
+    x.f = (float)m * 5.9604644775390625e-8f;                          // m * 2^-24
+    x.u |= sign;
+    return x.f;
+  }
+  if (e == 31) { x.u = sign | 0x7f800000u | (m << 13); return x.f; }
+  x.u = sign | ((e + 112u) << 23) | (m << 13);
+  return x.f;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -41,17 +78,51 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// fp16 (IEEE binary16, round to nearest even).  pack_f16x2 is the plain conversion (inf / -inf pass through: the
+// attention mask relies on that); pack_f16x2_sat clamps to the largest finite half first, so an activation outlier
+// beyond 65504 saturates instead of turning a whole row into inf/NaN (bf16 has the fp32 range and needs no clamp).
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  union { f16x2_t h; uint32_t u; } r;
+  r.h = __builtin_convertvector(v, f16x2_t);
+  return r.u;
+}
+__device__ __forceinline__ float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+__device__ __forceinline__ uint32_t pack_f16x2_sat(float lo, float hi) { return pack_f16x2(f16_sat(lo), f16_sat(hi)); }
+__device__ __forceinline__ float f16_lo(uint32_t u) { union { uint32_t u; f16x2_t h; } r; r.u = u; return (float)r.h[0]; }
+__device__ __forceinline__ float f16_hi(uint32_t u) { union { uint32_t u; f16x2_t h; } r; r.u = u; return (float)r.h[1]; }
+
+// one interface over the two 16-bit operand types (TM = bf16_t | f16_t): two floats <-> one packed dword
+template <typename TM> struct Op16;
+template <> struct Op16<bf16_t> {
+  __device__ static __forceinline__ uint32_t pack(float lo, float hi) { return pack_bf16x2(lo, hi); }        // plain (inf passes)
+  __device__ static __forceinline__ uint32_t pack_sat(float lo, float hi) { return pack_bf16x2(lo, hi); }    // (fp32 range: nothing to clamp)
+  __device__ static __forceinline__ float lo(uint32_t u) { return bf16_lo(u); }
+  __device__ static __forceinline__ float hi(uint32_t u) { return bf16_hi(u); }
+};
+template <> struct Op16<f16_t> {
+  __device__ static __forceinline__ uint32_t pack(float lo, float hi) { return pack_f16x2(lo, hi); }
+  __device__ static __forceinline__ uint32_t pack_sat(float lo, float hi) { return pack_f16x2_sat(lo, hi); }
+  __device__ static __forceinline__ float lo(uint32_t u) { return f16_lo(u); }
+  __device__ static __forceinline__ float hi(uint32_t u) { return f16_hi(u); }
+};
 
 // operand-typed scalar / 4-vector stores and loads (TM = float or bf16_t)
 template <typename TM> __device__ __forceinline__ void store_op(TM* p, float v);
 template <> __device__ __forceinline__ void store_op<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_op<bf16_t>(bf16_t* p, float v) { p->v = (uint16_t)pack_bf16x2(v, 0.f); }
+template <> __device__ __forceinline__ void store_op<f16_t>(f16_t* p, float v) { p->v = (uint16_t)pack_f16x2_sat(v, 0.f); }
 template <typename TM> __device__ __forceinline__ void store_op4(TM* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store_op4<float>(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 template <> __device__ __forceinline__ void store_op4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+template <> __device__ __forceinline__ void store_op4<f16_t>(f16_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2_sat(a, b), pack_f16x2_sat(c, d));
 }
 // Result stores of the big producers (GEMM epilogues, norm outputs).  NS2VC_WT_STORES=1 (default) issues them
 // write-through (sc1): the bytes leave during the kernel instead of as an L2 write-back at the kernel boundary
@@ -86,9 +157,11 @@ __device__ __forceinline__ void out_f4(float* p, float a, float b, float c, floa
 template <typename TM> __device__ __forceinline__ void out_op4(TM* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void out_op4<float>(float* p, float a, float b, float c, float d) { out_f4(p, a, b, c, d); }
 template <> __device__ __forceinline__ void out_op4<bf16_t>(bf16_t* p, float a, float b, float c, float d) { out_store8(p, pack_bf16x2(a, b), pack_bf16x2(c, d)); }
+template <> __device__ __forceinline__ void out_op4<f16_t>(f16_t* p, float a, float b, float c, float d) { out_store8(p, pack_f16x2_sat(a, b), pack_f16x2_sat(c, d)); }
 template <typename TM> __device__ __forceinline__ void store_op2(TM* p, float a, float b);
 template <> __device__ __forceinline__ void store_op2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
 template <> __device__ __forceinline__ void store_op2<bf16_t>(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b); }
+template <> __device__ __forceinline__ void store_op2<f16_t>(f16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_f16x2_sat(a, b); }
 #endif
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -119,27 +192,25 @@ enum { PRO_NONE = 0, PRO_BC = 1, PRO_ROW = 2 };
 
 typedef ::ns2vc_gemm_args GemmArgs;   // public POD, include/ns2vc_hip.h
 typedef ::ns2vc_attn_args AttnArgs;
-typedef ::ns2vc_convgn_args ConvGnArgs;
 
-enum Precision { PREC_F32 = 0, PREC_BF16 = 1 };
+enum Precision { PREC_F32 = 0, PREC_BF16 = 1, PREC_F16 = 2 };
+inline size_t operand_bytes(int prec) { return prec == PREC_F32 ? 4 : 2; }
+// host-side rounding of a value to the operand type (weight packing, row sums of the rounded weights)
+inline uint16_t f32_to_op16_bits(float v, int prec) { return prec == PREC_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v); }
+inline float op16_bits_to_f32(uint16_t b, int prec) { return prec == PREC_BF16 ? bf16_bits_to_f32(b) : f16_bits_to_f32(b); }
 // fixed-point scales of the epilogue GroupNorm statistics (order-independent int64 atomics => deterministic)
 constexpr double GN_SUM_SCALE = 268435456.0;   // 2^28
 constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
-hipError_t launch_convgn(const ConvGnArgs& a, int prec, hipStream_t s);
-bool convgn_eligible(const ConvGnArgs& a, int prec);
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
-// fused row-panel chains (chain.hip), bf16 operand type only
-hipError_t launch_chain_ab(const void* a, int M, int D, const void* wstream, const float* bias1, const float* res, float* y, float eps,
-                           const float* bias2, void* out2, int N2, hipStream_t s);
 void set_forced_gemm_tile(int bm, int bn, int stages);
 void set_gemm_trace(unsigned long long* p);
 hipError_t init_attn_attributes();
 
-// misc kernels (misc.hip).  "op" buffers are operand-typed (bf16 when prec == PREC_BF16, else fp32)
+// misc kernels (misc.hip).  "op" buffers are operand-typed (bf16 / fp16 / fp32 by `prec`)
 hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1,
                              int B, int T, int G, double* partial, int nchunk, int rows_per_chunk, hipStream_t s);
 hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,

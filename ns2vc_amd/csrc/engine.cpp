@@ -7,6 +7,7 @@
 // attention.py:130-203) as a flat list of kernel launches on channels-last tensors.
 #include "common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -66,9 +67,7 @@ struct AttnW {
   int dim = 0, kv_off = 0;
   float *ng = nullptr, *nb = nullptr;
   PackedW proj_in, qkv, o1, q2, o2, ff1, ff2, proj_out;
-  // fused row chains (bf16): A = proj_in -> LN1 -> q|k|v ; B = attn1.to_out(+y) -> LN2 -> attn2.to_q
-  void *chain_a = nullptr, *chain_b = nullptr;
-  float *ca_b1 = nullptr, *ca_b2 = nullptr, *cb_b1 = nullptr, *cb_b2 = nullptr;
+  PackedW ffpo;    // ff.net.2 folded into proj_out: [W_po W_2 | W_po], K = 4*dim + dim (see pack_all)
 };
 struct BlockW {
   std::string kind;   // down | mid | up
@@ -116,22 +115,17 @@ struct ns2vc_unet {
   void* arena = nullptr;
   size_t arena_bytes = 0, arena_used = 0;
   std::vector<Op> cond_ops, fwd_ops;
+  size_t cond_split = 0;      // cond_ops[0 .. cond_split) depend on the content only, the rest on the prompt (+ mask) only
   bool debug = false;
-  // bf16: fused row-chain kernels for the transformer linears (csrc/chain.hip).  Correct, but measured SLOWER than
-  // the separate launches on MI355X (5.74-6.09 vs 5.61 ms/step, profiles/chain_ab_r01.txt): one workgroup per CU
-  // serialises 4-5 dependent global round trips.  Off unless NS2VC_USE_CHAINS=1.
-  bool use_chains = false;
-  // LayerNorm by linearity (csrc/gemm.hip): no normalisation pass; NS2VC_LN_LINEAR=0 restores the ln_apply kernels
+  int device = 0;             // HIP device the engine (weights, arena, graph) lives on; every entry point binds to it
+  // LayerNorm by linearity (csrc/gemm.hip): no normalisation pass; NS2VC_LN_LINEAR=0 (or ns2vc_unet_set_option) restores
+  // the ln_apply kernels.  The consumers record max |mean| * rstd over all LayerNorm rows in `ln_health`: the 16-bit
+  // modes round the RAW x before centring, so their error on a row grows with that ratio (ns2vc_unet_ln_ratio).
   bool ln_linear = true;
-  // cross-attention to_q computed inside the attention kernel (csrc/attn.hip, NS2VC_FUSE_TOQ=1).  Correct and tested,
-  // but measured SLOWER on MI355X (attention +0.21 ms, GEMMs -0.16 ms per step): every head's workgroup re-reads the
-  // same input rows through the load path, 8x the bytes of the separate GEMM.  Off by default.
-  bool fuse_toq = false;
-  // GroupNorm(+scale/shift)+SiLU computed inside the 3-tap conv that consumes it (conv3gn_kernel, NS2VC_FUSE_GN=1).
-  // Correct and tested, 37 launches fewer, but measured SLOWER on MI355X (4.91 vs 4.63 ms/step): the panel build (cold
-  // fp32 rows + SiLU) sits serially in front of every workgroup's K loop and is redone by each of the N/128 column
-  // workgroups, while the separate pass does the same work at full-chip parallelism.  Off by default.
-  bool fuse_gn = false;
+  // ff.net.2 folded into proj_out at pack time (one GEMM with a second K segment instead of two launches; the
+  // post-feed-forward stream tensor is never materialised).  NS2VC_FOLD_FF=0 restores the two launches.
+  bool fold_ff = true;
+  unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -287,20 +281,6 @@ void build_expected(ns2vc_unet* h) {
 // ------------------------------------------------------------------------------------
 // weight packing (host, fp32/double) -> device
 // ------------------------------------------------------------------------------------
-// Append the 16 KB weight tiles of a row-major [N][K] matrix (N % 128 == 0, K % 64 == 0) to a chain stream, in the
-// order the chain kernels consume them (128-row chunk major, 64-wide k-tile minor), each tile already in the
-// XOR-swizzled LDS image: byte r*128 + p*16 holds logical 16-B chunk p ^ ((r>>1)&7) of row r.
-static void append_chain_tiles(std::vector<uint16_t>& stream, const float* rows, int N, int K) {
-  for (int nc = 0; nc < N / 128; ++nc)
-    for (int kt = 0; kt < K / 64; ++kt)
-      for (int r = 0; r < 128; ++r)
-        for (int p = 0; p < 8; ++p) {
-          const int lc = p ^ ((r >> 1) & 7);
-          const float* src = rows + (size_t)(nc * 128 + r) * K + kt * 64 + lc * 8;
-          for (int e = 0; e < 8; ++e) stream.push_back(f32_to_bf16_bits(src[e]));
-        }
-}
-
 // sum_k of the operand-rounded weight row (what the MFMA will actually multiply), accumulated in double
 static std::vector<float> rounded_rowsum(const float* rows, int N, int K, int Np, int prec) {
   std::vector<float> ws(Np, 0.f);
@@ -308,7 +288,7 @@ static std::vector<float> rounded_rowsum(const float* rows, int N, int K, int Np
     double acc = 0.0;
     for (int k = 0; k < K; ++k) {
       float v = rows[(size_t)n * K + k];
-      if (prec == PREC_BF16) v = bf16_bits_to_f32(f32_to_bf16_bits(v));
+      if (prec != PREC_F32) v = op16_bits_to_f32(f32_to_op16_bits(v, prec), prec);
       acc += (double)v;
     }
     ws[n] = (float)acc;
@@ -333,14 +313,6 @@ struct Packer {
     return (float*)d;
   }
   float* vec(const std::string& k) { return upload_f32(T(k).data); }
-  void* upload_stream(const std::vector<uint16_t>& v) {
-    void* d = nullptr;
-    if (hipMalloc(&d, std::max<size_t>(v.size(), 1) * 2) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return nullptr; }
-    h->weight_allocs.push_back(d);
-    if (hipMemcpy(d, v.data(), v.size() * 2, hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed (weights)");
-    return d;
-  }
-
   // rows: [N][K] fp32, bias: [N] or empty.  Pads N to a multiple of 128 with zero rows.
   PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias, bool want_wsum = false) {
     PackedW p;
@@ -348,9 +320,9 @@ struct Packer {
     p.N = Np; p.K = K;
     if (want_wsum) p.wsum = upload_f32(rounded_rowsum(rows.data(), N, K, Np, h->prec));
     void* d = nullptr;
-    if (h->prec == PREC_BF16) {
+    if (h->prec != PREC_F32) {
       std::vector<uint16_t> q((size_t)Np * K, 0);
-      for (size_t i = 0; i < (size_t)N * K; ++i) q[i] = f32_to_bf16_bits(rows[i]);
+      for (size_t i = 0; i < (size_t)N * K; ++i) q[i] = f32_to_op16_bits(rows[i], h->prec);
       if (hipMalloc(&d, q.size() * 2) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return p; }
       h->weight_allocs.push_back(d);
       if (hipMemcpy(d, q.data(), q.size() * 2, hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed");
@@ -496,22 +468,6 @@ int pack_all(ns2vc_unet* h) {
         a.q2 = P.pack(rows, d, d, bias, true);
       }
       a.o2 = P.pack(P.T(t + ".attn2.to_out.0.weight").data, d, d, P.T(t + ".attn2.to_out.0.bias").data);
-      if (h->prec == PREC_BF16) {   // weight streams of the fused row chains
-        std::vector<float> qkv_rows, qkv_bias, q2_rows, q2_bias;
-        for (const char* nm : {"to_q", "to_k", "to_v"}) P.ln_fold(P.T(t + ".attn1." + nm + ".weight"), nullptr, P.T(t + ".norm1.weight"), P.T(t + ".norm1.bias"), qkv_rows, qkv_bias);
-        P.ln_fold(P.T(t + ".attn2.to_q.weight"), nullptr, P.T(t + ".norm2.weight"), P.T(t + ".norm2.bias"), q2_rows, q2_bias);
-        const HostTensor& pin = P.T(a.prefix + ".proj_in.weight");
-        const HostTensor& o1w = P.T(t + ".attn1.to_out.0.weight");
-        if (P.err) return 1;
-        std::vector<uint16_t> sa, sb;
-        append_chain_tiles(sa, pin.data.data(), d, d);            // (D, D, 1) conv == [D][D] rows
-        append_chain_tiles(sa, qkv_rows.data(), 3 * d, d);
-        append_chain_tiles(sb, o1w.data.data(), d, d);
-        append_chain_tiles(sb, q2_rows.data(), d, d);
-        a.chain_a = P.upload_stream(sa); a.chain_b = P.upload_stream(sb);
-        a.ca_b1 = P.vec(a.prefix + ".proj_in.bias"); a.ca_b2 = P.upload_f32(qkv_bias);
-        a.cb_b1 = P.vec(t + ".attn1.to_out.0.bias"); a.cb_b2 = P.upload_f32(q2_bias);
-      }
       {  // GEGLU projection: LayerNorm(norm3) folded, rows interleaved in (32 value | 32 gate) groups
         std::vector<float> rows, bias;
         P.ln_fold(P.T(t + ".ff.net.0.proj.weight"), &P.T(t + ".ff.net.0.proj.bias"), P.T(t + ".norm3.weight"), P.T(t + ".norm3.bias"), rows, bias);
@@ -530,6 +486,33 @@ int pack_all(ns2vc_unet* h) {
         a.ff1 = P.pack(rows2, 8 * d, d, bias2, true);
       }
       a.ff2 = P.pack(P.T(t + ".ff.net.2.weight").data, d, 4 * d, P.T(t + ".ff.net.2.bias").data);
+      {  // ff.net.2 folded into proj_out (attention.py:178-203 + transformer_1d.py:287-295):
+         //   proj_out(y + W2 g + b2) + x = [Wpo W2 | Wpo] [g | y] + (Wpo b2 + bpo) + x
+         // one GEMM, K = 4d (GEGLU output) + d (second K segment: the operand copy of y).  Products in double.
+        const HostTensor& w2 = P.T(t + ".ff.net.2.weight");      // [d][4d]
+        const HostTensor& b2 = P.T(t + ".ff.net.2.bias");
+        const HostTensor& wp = P.T(a.prefix + ".proj_out.weight"); // [d][d][1]
+        const HostTensor& bp = P.T(a.prefix + ".proj_out.bias");
+        if (P.err) return 1;
+        const int K1 = 4 * d, K2 = d;
+        std::vector<float> rows((size_t)d * (K1 + K2)), bias(d);
+        std::vector<double> acc(K1);
+        for (int n = 0; n < d; ++n) {
+          std::fill(acc.begin(), acc.end(), 0.0);
+          double bacc = (double)bp.data[n];
+          for (int j = 0; j < d; ++j) {
+            const double wpj = (double)wp.data[(size_t)n * d + j];
+            const float* w2r = &w2.data[(size_t)j * K1];
+            for (int k = 0; k < K1; ++k) acc[k] += wpj * (double)w2r[k];
+            bacc += wpj * (double)b2.data[j];
+          }
+          float* r = &rows[(size_t)n * (K1 + K2)];
+          for (int k = 0; k < K1; ++k) r[k] = (float)acc[k];
+          memcpy(r + K1, &wp.data[(size_t)n * d], (size_t)K2 * sizeof(float));
+          bias[n] = (float)bacc;
+        }
+        a.ffpo = P.pack(rows, d, K1 + K2, bias);
+      }
       {  // cross-attention k|v of this block into the hoisted all-blocks projection
         const HostTensor& wk = P.T(t + ".attn2.to_k.weight");
         const HostTensor& wv = P.T(t + ".attn2.to_v.weight");
@@ -667,31 +650,16 @@ struct Planner {
 
   // ResnetBlock2D (resnet.py:591-641).  out (fp32) [+ out_op operand copy when a conv consumes it next]
   void resnet(const ResnetW& r, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float* h1, void* hn,
-              float* sc, float* out, void* out_op) {
+              float* out, void* out_op) {
     const int cin = c0 + c1;
-    const int pr = prec, Gq = G, ldt = h->temb_all.N;
-    // ---- conv1(act(norm1(x))): GroupNorm fused into the conv when the kernel can take it (csrc/gemm.hip conv3gn_kernel)
+    // ---- conv1(act(norm1(x)))
+    groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
-    ConvGnArgs f1;
-    memset(&f1, 0, sizeof(f1));
-    f1.x0 = a0; f1.ldx0 = lda0; f1.x1 = a1; f1.ldx1 = lda1;
-    f1.st0 = find_stats(a0); f1.st1 = a1 ? find_stats(a1) : nullptr;
-    f1.gamma = r.n1g; f1.beta = r.n1b; f1.groups = Gq; f1.eps = 1e-5f; f1.silu = 1;
-    f1.raw_op = r.shortcut ? xr : nullptr;
-    f1.g = g; f1.g.a0 = nullptr; f1.g.c0 = c0; f1.g.c1 = c1; f1.g.lda0 = 0;
-    const bool fuse1 = h->fuse_gn && convgn_eligible(f1, pr);
-    if (!fuse1) groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
     g.stats = new_stats(h1, Tl, r.cout);
-    if (fuse1) {
-      f1.g.stats = g.stats;
-      const double n = (double)B * Tl * cin;
-      add(r.prefix + ".norm1+conv1", [=](hipStream_t s) { return launch_convgn(f1, pr, s); }, 1, 2.0 * g.M * (double)g.N * g.K,
-          4.0 * n + (double)g.N * g.K * opsz + 4.0 * g.M * g.N + (f1.raw_op ? n * opsz : 0.0));
-    } else {
-      gemm(r.prefix + ".conv1", g);
-    }
+    gemm(r.prefix + ".conv1", g);
     // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut
+    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3;
     if (r.shortcut) {      // out = conv2(hn) + conv_shortcut(x): the 1x1 conv rides along as a second K segment
@@ -699,43 +667,21 @@ struct Planner {
     } else {
       g2.res = a0; g2.ldres = lda0;
     }
-    ConvGnArgs f2;
-    memset(&f2, 0, sizeof(f2));
-    f2.x0 = h1; f2.ldx0 = r.cout;
-    f2.st0 = g.stats;
-    f2.gamma = r.n2g; f2.beta = r.n2b; f2.groups = Gq; f2.eps = 1e-5f; f2.silu = 1;
-    f2.temb = h->temb; f2.ldtemb = ldt; f2.temb_off = r.temb_off;
-    f2.g = g2; f2.g.a0 = nullptr; f2.g.c0 = r.cout; f2.g.c1 = 0;
-    const bool fuse2 = h->fuse_gn && convgn_eligible(f2, pr);
-    if (!fuse2) groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
     g2.stats = new_stats(out, Tl, r.cout);
-    if (fuse2) {
-      f2.g.stats = g2.stats;
-      const double n = (double)B * Tl * r.cout;
-      add(r.prefix + ".norm2+conv2", [=](hipStream_t s) { return launch_convgn(f2, pr, s); }, 1, 2.0 * g2.M * (double)g2.N * g2.K,
-          4.0 * n + (double)g2.N * g2.K * opsz + (double)B * Tl * g2.c2 * opsz + 4.0 * g2.M * g2.N + (g2.out_op ? (double)g2.M * g2.N * opsz : 0.0) +
-              (g2.res ? 4.0 * g2.M * g2.N : 0.0));
-    } else {
-      gemm(r.prefix + ".conv2", g2);
-    }
-    (void)sc;
+    gemm(r.prefix + ".conv2", g2);
   }
 
-  // `proj` (optional): fused query projection -- only its xq/ldx/xdim/wq/bq/ln_* fields are read
   void attention(const std::string& name, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int Lq, int Lk,
-                 const float* bias, int hd, void* out, int ldo, const AttnArgs* proj = nullptr) {
+                 const float* bias, int hd, void* out, int ldo) {
     AttnArgs a;
     memset(&a, 0, sizeof(a));
-    if (proj) a = *proj;
     a.q = q; a.k = k; a.v = v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.B = B; a.H = h->cfg.heads; a.Lq = Lq; a.Lk = Lk; a.bias = bias;
     a.scale = 1.0f / std::sqrt((float)hd);
     a.out = out; a.ldo = ldo;
     const int pr = prec;
-    const double pf = proj ? 2.0 * B * (double)Lq * a.xdim * (a.H * hd) : 0.0;       // fused to_q projection
-    const double pb = proj ? (double)opsz * (B * (double)Lq * a.xdim + (double)a.xdim * a.H * hd) : (double)opsz * B * a.H * hd * Lq;
-    add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd + pf,
-        (double)opsz * B * a.H * hd * (Lq + 2.0 * Lk) + pb);
+    add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd,
+        (double)opsz * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
   }
 
   // Transformer2DModel + BasicTransformerBlock (transformer_1d.py:256-295, attention.py:130-203)
@@ -745,61 +691,45 @@ struct Planner {
     const std::string t = a.prefix + ".transformer_blocks.0";
     groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
     GemmArgs g;
-    AttnArgs qproj;
-    bool fuse_q = false;
     auto layernorm = [&](const std::string& nm) {
       add(nm, [=](hipStream_t s) { return launch_ln_apply_op(y, d, M, d, 1e-5f, yn, pr, s); }, 3, 8.0 * M * d, (4.0 + opsz) * M * d);
     };
-    const bool fused = (pr == PREC_BF16) && a.chain_a && h->use_chains;
-    const double wsz = (double)opsz;
-    if (fused) {
-      // proj_in -> LayerNorm(norm1) -> q|k|v in one launch: y (fp32) and qkv (operand) leave the chip, nothing else
-      const void* wsa = a.chain_a; const float *b1 = a.ca_b1, *b2 = a.ca_b2; void* xn_ = xn;
-      add(a.prefix + ".chainA[proj_in+norm1+qkv]", [=](hipStream_t s) { return launch_chain_ab(xn_, M, d, wsa, b1, nullptr, y, 1e-5f, b2, qkv, 3 * d, s); },
-          1, 2.0 * M * d * (4.0 * d), M * d * wsz + 4.0 * d * d * wsz + 4.0 * M * d + 3.0 * M * d * wsz);
-    } else {
-      // LayerNorm by linearity (h->ln_linear): the producer of every LayerNorm input also writes the raw operand copy
-      // `yn` and per-row statistics; the consumer GEMM reads yn and normalises in its epilogue -- no ln_apply pass
-      float* r1 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs1 : nullptr;
-      g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
-      g.rowstats = r1;
-      gemm(a.prefix + ".proj_in", g);
-      // self attention
-      if (!r1) layernorm(t + ".norm1");
-      g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
-      if (r1) { g.ln_stats = r1; g.ln_wsum = a.qkv.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
-      gemm(t + ".attn1.qkv", g);
-    }
+    // LayerNorm by linearity (h->ln_linear): the producer of every LayerNorm input also writes the raw operand copy
+    // `yn` and per-row statistics; the consumer GEMM reads yn and normalises in its epilogue -- no ln_apply pass
+    const bool lin = h->ln_linear && (d % 128 == 0) && d <= 512;
+    auto consume = [&](GemmArgs& gg, float* rs, const PackedW& w) {
+      if (rs) { gg.ln_stats = rs; gg.ln_wsum = w.wsum; gg.ln_eps = 1e-5f; gg.ln_dim = d; gg.ln_health = h->ln_health; }
+    };
+    float* r1 = lin ? rs1 : nullptr;
+    g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
+    g.rowstats = r1;
+    gemm(a.prefix + ".proj_in", g);
+    // self attention
+    if (!r1) layernorm(t + ".norm1");
+    g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
+    consume(g, r1, a.qkv);
+    gemm(t + ".attn1.qkv", g);
     attention(t + ".attn1.sdpa", qkv, 3 * d, op_off(qkv, d), 3 * d, op_off(qkv, 2 * d), 3 * d, Tl, Tl, nullptr, hd, ao, d);
-    if (fused) {
-      // attn1.to_out + residual -> LayerNorm(norm2) -> attn2.to_q
-      const void* wsb = a.chain_b; const float *b1 = a.cb_b1, *b2 = a.cb_b2;
-      add(t + ".chainB[attn1.to_out+norm2+to_q]", [=](hipStream_t s) { return launch_chain_ab(ao, M, d, wsb, b1, y, y, 1e-5f, b2, qb, d, s); },
-          1, 2.0 * M * d * (2.0 * d), M * d * wsz + 2.0 * d * d * wsz + 8.0 * M * d + M * d * wsz);
-    } else {
-      float* r2 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs2 : nullptr;
-      g = base(ao, d, d, Tl, Tl, a.o1, y, r2 ? yn : nullptr, d);
-      g.res = y; g.ldres = d;
-      g.rowstats = r2;
-      gemm(t + ".attn1.to_out", g);
-      if (!r2) layernorm(t + ".norm2");
-      fuse_q = h->fuse_toq && (d % 16 == 0);
-      if (fuse_q) {          // attn2.to_q runs inside the cross-attention kernel (no launch, Q never touches HBM)
-        memset(&qproj, 0, sizeof(qproj));
-        qproj.xq = yn; qproj.ldx = d; qproj.xdim = d; qproj.wq = a.q2.w; qproj.bq = a.q2.bias;
-        if (r2) { qproj.ln_stats = r2; qproj.ln_wsum = a.q2.wsum; qproj.ln_eps = 1e-5f; qproj.ln_dim = d; }
-      } else {
-        g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
-        if (r2) { g.ln_stats = r2; g.ln_wsum = a.q2.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
-        gemm(t + ".attn2.to_q", g);
-      }
-    }
+    float* r2 = lin ? rs2 : nullptr;
+    g = base(ao, d, d, Tl, Tl, a.o1, y, r2 ? yn : nullptr, d);
+    g.res = y; g.ldres = d;
+    g.rowstats = r2;
+    gemm(t + ".attn1.to_out", g);
+    if (!r2) layernorm(t + ".norm2");
+    g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
+    consume(g, r2, a.q2);
+    gemm(t + ".attn2.to_q", g);
     // cross attention (k|v hoisted into h->kv by set_condition)
     const int nkv = h->kv_all.N;
-    attention(t + (fuse_q ? ".attn2.to_q+sdpa" : ".attn2.sdpa"), fuse_q ? nullptr : qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
-              h->has_mask ? h->maskbias : nullptr, hd, ao, d, fuse_q ? &qproj : nullptr);
-    float* r3 = h->ln_linear && (d % 128 == 0) && d <= 512 ? rs3 : nullptr;
-    g = base(ao, d, d, Tl, Tl, a.o2, y, r3 ? yn : nullptr, d);
+    attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
+              h->has_mask ? h->maskbias : nullptr, hd, ao, d);
+    float* r3 = lin ? rs3 : nullptr;
+    // With the feed-forward output folded into proj_out, proj_out reads the RAW operand copy of y next to the GEGLU
+    // output.  LayerNorm by linearity writes that copy anyway (yn); the explicit-LayerNorm plan overwrites yn with the
+    // normalised rows, so there the raw copy goes to qb (the cross-attention query buffer, free by now).
+    const bool fold = h->fold_ff;
+    void* yraw = r3 ? yn : (fold ? qb : nullptr);
+    g = base(ao, d, d, Tl, Tl, a.o2, y, yraw, d);
     g.res = y; g.ldres = d;
     g.rowstats = r3;
     gemm(t + ".attn2.to_out", g);
@@ -807,15 +737,24 @@ struct Planner {
     if (!r3) layernorm(t + ".norm3");
     g = base(yn, d, d, Tl, Tl, a.ff1, nullptr, ffh, 4 * d);
     g.geglu = 1;
-    if (r3) { g.ln_stats = r3; g.ln_wsum = a.ff1.wsum; g.ln_eps = 1e-5f; g.ln_dim = d; }
+    consume(g, r3, a.ff1);
     gemm(t + ".ff.geglu", g);
-    g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ff2, nullptr, yn, d);     // y_final = y + ff(...) is only consumed by proj_out: operand copy only
-    g.res = y; g.ldres = d;
-    gemm(t + ".ff.out", g);
-    g = base(yn, d, d, Tl, Tl, a.proj_out, out, out_op, d);
-    g.res = x; g.ldres = d;
-    g.stats = new_stats(out, Tl, d);
-    gemm(a.prefix + ".proj_out", g);
+    if (fold) {
+      // out = [Wpo W2 | Wpo] [ffh | yn] + (Wpo b2 + bpo) + x : ff.net.2 and proj_out in one launch
+      g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ffpo, out, out_op, d);
+      g.a2 = yraw; g.lda2 = d; g.c2 = d;
+      g.res = x; g.ldres = d;
+      g.stats = new_stats(out, Tl, d);
+      gemm(a.prefix + ".ff.out+proj_out", g);
+    } else {
+      g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ff2, nullptr, yn, d);     // y_final = y + ff(...) is only consumed by proj_out: operand copy only
+      g.res = y; g.ldres = d;
+      gemm(t + ".ff.out", g);
+      g = base(yn, d, d, Tl, Tl, a.proj_out, out, out_op, d);
+      g.res = x; g.ldres = d;
+      g.stats = new_stats(out, Tl, d);
+      gemm(a.prefix + ".proj_out", g);
+    }
   }
 };
 
@@ -829,7 +768,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
 
   Planner P;
   P.h = h; P.sizing = sizing; P.B = B; P.T = T; P.Lp = Lp; P.G = c.norm_num_groups; P.prec = h->prec;
-  P.opsz = h->prec == PREC_BF16 ? 2 : 4;
+  P.opsz = operand_bytes(h->prec);
   const int prec = h->prec;
   if (!sizing) { h->cond_ops.clear(); h->fwd_ops.clear(); h->taps.clear(); }
 
@@ -865,6 +804,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   h->pooled = P.alloc<float>((size_t)B * cross);
   h->t_dev = P.alloc<float>((size_t)B);
   h->step_dev = P.alloc<int>(64);
+  h->ln_health = P.alloc<unsigned>(64);
   // ---- shared scratch
   P.gn_rows = 32;
   P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
@@ -872,7 +812,6 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   P.rs1 = P.alloc<float>(maxMC / 32); P.rs2 = P.alloc<float>(maxMC / 32); P.rs3 = P.alloc<float>(maxMC / 32);
   float* h1 = P.alloc<float>(maxMC);
   void* hn = P.alloc_op(maxMC);
-  float* scb = P.alloc<float>(maxMC);
   float* y = P.alloc<float>(maxMC);
   void* yn = P.alloc_op(maxMC);
   void* qkv = P.alloc_op(3 * maxMC);
@@ -893,6 +832,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     GemmArgs g = P.base(h->content_op, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, nullptr, c0);
     g.taps = 3;
     P.gemm("cond.conv_in.content", g);
+    if (!sizing) h->cond_split = h->cond_ops.size();
     // all cross-attention k|v projections in one GEMM: prompt [B*Lp][cross] x [n_kv][cross]^T -> operand tensor
     const size_t np = (size_t)B * Lp * cross;
     P.add("cond.prompt.cast", [=](hipStream_t s) { return launch_cast_op(prompt, np, prompt_op, prec, s); });
@@ -962,7 +902,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
         const bool has_attn = !b.attn.empty();
         const bool last = (j + 1 == b.res.size());
         float* rout = has_attn ? ua : new_skip(l);
-        P.resnet(b.res[j], cur, curC, curC, nullptr, 0, 0, Tl, h1, hn, scb, rout, (!has_attn && last && b.sampler) ? samp_in : nullptr);
+        P.resnet(b.res[j], cur, curC, curC, nullptr, 0, 0, Tl, h1, hn, rout, (!has_attn && last && b.sampler) ? samp_in : nullptr);
         P.tap(tag + ".res" + std::to_string(j), rout, B * Tl, b.channels);
         cur = rout; curC = b.channels;
         if (has_attn) {
@@ -983,11 +923,11 @@ int build_plan(ns2vc_unet* h, bool sizing) {
         cur = ds;
       }
     } else if (b.kind == "mid") {
-      P.resnet(b.res[0], cur, curC, curC, nullptr, 0, 0, Tl, h1, hn, scb, ua, nullptr);
+      P.resnet(b.res[0], cur, curC, curC, nullptr, 0, 0, Tl, h1, hn, ua, nullptr);
       P.tap("mid.res0", ua, B * Tl, b.channels);
       P.transformer(b.attn[0], ua, Tl, y, yn, qkv, ao, qb, ffh, ub, nullptr);
       P.tap("mid.attn0", ub, B * Tl, b.channels);
-      P.resnet(b.res[1], ub, b.channels, b.channels, nullptr, 0, 0, Tl, h1, hn, scb, uc, nullptr);
+      P.resnet(b.res[1], ub, b.channels, b.channels, nullptr, 0, 0, Tl, h1, hn, uc, nullptr);
       P.tap("mid.res1", uc, B * Tl, b.channels);
       cur = uc; curC = b.channels;
     } else {
@@ -1000,7 +940,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
         if (curC + sk.C != b.res[j].cin) return fail("internal: concat width %d+%d != %d at %s", curC, sk.C, b.res[j].cin, b.res[j].prefix.c_str());
         float* rout = (cur == ua) ? ub : ua;
         if (rout == cur) rout = uc;
-        P.resnet(b.res[j], cur, curC, curC, sk.p, sk.C, sk.C, Tl, h1, hn, scb, rout, (!has_attn && last && b.sampler) ? samp_in : nullptr);
+        P.resnet(b.res[j], cur, curC, curC, sk.p, sk.C, sk.C, Tl, h1, hn, rout, (!has_attn && last && b.sampler) ? samp_in : nullptr);
         P.tap(tag + ".res" + std::to_string(j), rout, B * Tl, b.channels);
         cur = rout; curC = b.channels;
         if (has_attn) {
@@ -1031,24 +971,44 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     P.tap("out", h->x0, B * T, CP);
   }
   if (sizing) h->arena_bytes = P.off;
+  else if (P.off > h->arena_bytes) {    // a rebuild must never carve past the allocation the sizing pass measured
+    h->cond_ops.clear(); h->fwd_ops.clear(); h->taps.clear();
+    return fail("internal: plan needs %zu bytes but the arena holds %zu (re-run ns2vc_unet_prepare)", P.off, h->arena_bytes);
+  }
   h->arena_used = P.off;
   h->stats_bytes = std::max<size_t>(P.stats_used, 1) * sizeof(long long);
   return 0;
 }
 
-int run_ops(const std::vector<Op>& ops, hipStream_t s) {
-  for (const auto& op : ops) {
-    hipError_t e = op.fn(s);
-    if (e != hipSuccess) return fail("launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
+int run_ops(const std::vector<Op>& ops, hipStream_t s, size_t first = 0, size_t last = (size_t)-1) {
+  for (size_t i = first; i < std::min(last, ops.size()); ++i) {
+    hipError_t e = ops[i].fn(s);
+    if (e != hipSuccess) return fail("launch of '%s' failed: %s", ops[i].name.c_str(), hipGetErrorString(e));
   }
   return 0;
 }
 
+// Every entry point that touches the device binds the calling thread to the engine's device first: weights, arena and
+// the captured graph live there, and launches go to the CURRENT device (a model on cuda:1 called while cuda:0 is
+// current would otherwise launch on the wrong GPU with cross-device pointers).
+int bind_device(ns2vc_unet* h) {
+  int cur = -1;
+  HIPCHK(hipGetDevice(&cur));
+  if (cur != h->device) HIPCHK(hipSetDevice(h->device));
+  return 0;
+}
 int check_ready(ns2vc_unet* h, bool need_plan) {
   if (!h) return fail("null engine handle");
+  if (bind_device(h)) return 1;
   if (!h->finalized) return fail("weights not finalized (call ns2vc_unet_finalize_weights)");
   if (need_plan && !h->arena) return fail("engine not prepared (call ns2vc_unet_prepare)");
   return 0;
+}
+void drop_plan(ns2vc_unet* h) {
+  if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+  if (h->arena) { (void)hipDeviceSynchronize(); (void)hipFree(h->arena); h->arena = nullptr; }
+  h->cond_ops.clear(); h->fwd_ops.clear(); h->taps.clear();
+  h->arena_bytes = h->arena_used = 0;
 }
 
 }  // namespace
@@ -1094,16 +1054,16 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
     if (hd != 16 && hd != 32 && hd != 48 && hd != 64) return fail("head_dim %d unsupported (16/32/48/64)", hd);
     if (c % cfg->norm_num_groups || (c / cfg->norm_num_groups) % 4) return fail("channels %d incompatible with %d groups", c, cfg->norm_num_groups);
   }
+  if (cfg->norm_num_groups < 1 || cfg->norm_num_groups > 8) return fail("norm_num_groups=%d unsupported (1..8)", cfg->norm_num_groups);
   if (cfg->cross_attention_dim % cfg->pool_heads || cfg->cross_attention_dim / cfg->pool_heads > 8) return fail("pool heads unsupported");
   hipError_t e = init_gemm_attributes();
   if (e == hipSuccess) e = init_attn_attributes();
   if (e != hipSuccess) return fail("kernel attribute setup failed: %s (is a gfx950 GPU visible?)", hipGetErrorString(e));
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
-  if (const char* e = getenv("NS2VC_USE_CHAINS")) h->use_chains = atoi(e) != 0;
+  if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail("hipGetDevice failed"); }
   if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_TOQ")) h->fuse_toq = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_GN")) h->fuse_gn = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FOLD_FF")) h->fold_ff = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1111,12 +1071,14 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
 }
 
 int ns2vc_unet_destroy(ns2vc_unet* h) {
+  if (h) (void)bind_device(h);
   delete h;
   return 0;
 }
 
 int ns2vc_unet_load_weight(ns2vc_unet* h, const char* key, const void* data, const int64_t* shape, int ndim) {
   if (!h || !key || !data) return fail("null argument");
+  if (bind_device(h)) return 1;
   std::string k(key);
   const std::vector<int64_t>* want = nullptr;
   for (const auto& e : h->expected) if (e.first == k) { want = &e.second; break; }
@@ -1144,7 +1106,8 @@ int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int bufle
 
 int ns2vc_unet_finalize_weights(ns2vc_unet* h, int precision) {
   if (!h) return fail("null engine handle");
-  if (precision != NS2VC_PREC_F32 && precision != NS2VC_PREC_BF16) return fail("unknown precision %d", precision);
+  if (bind_device(h)) return 1;
+  if (precision != NS2VC_PREC_F32 && precision != NS2VC_PREC_BF16 && precision != NS2VC_PREC_F16) return fail("unknown precision %d", precision);
   char first[256] = {0};
   const int miss = ns2vc_unet_num_missing_weights(h, first, sizeof(first));
   if (miss) return fail("%d weights missing, first: %s", miss, first);
@@ -1153,15 +1116,39 @@ int ns2vc_unet_finalize_weights(ns2vc_unet* h, int precision) {
   h->prec = precision;
   if (pack_all(h)) return 1;
   h->finalized = true;
-  // a plan built for other weights holds stale pointers
-  if (h->arena) { (void)hipFree(h->arena); h->arena = nullptr; }
-  if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+  drop_plan(h);       // a plan built for other weights holds stale pointers
   return 0;
 }
 
 int ns2vc_unet_set_debug(ns2vc_unet* h, int enable) {
   if (!h) return fail("null engine handle");
-  h->debug = enable != 0;
+  if (bind_device(h)) return 1;
+  if (h->debug != (enable != 0)) {
+    h->debug = enable != 0;
+    drop_plan(h);     // the tap copies change the arena size: a later rebuild must not carve a stale allocation
+  }
+  return 0;
+}
+
+int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
+  if (!h || !name) return fail("null argument");
+  if (bind_device(h)) return 1;
+  bool* opt = nullptr;
+  if (!strcmp(name, "ln_linear")) opt = &h->ln_linear;
+  else if (!strcmp(name, "fold_ff")) opt = &h->fold_ff;
+  else return fail("unknown option '%s' (ln_linear, fold_ff)", name);
+  if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
+  return 0;
+}
+
+int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio) {
+  if (check_ready(h, true)) return 1;
+  if (!out_ratio) return fail("null argument");
+  unsigned bits = 0;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(&bits, h->ln_health, sizeof(bits), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemset(h->ln_health, 0, sizeof(bits)));
+  memcpy(out_ratio, &bits, sizeof(float));
   return 0;
 }
 
@@ -1170,8 +1157,7 @@ int ns2vc_unet_prepare(ns2vc_unet* h, int B, int T, int Lp) {
   if (B <= 0 || T <= 0 || Lp <= 0) return fail("B, T, Lp must be positive");
   const int min_t = 1 << (h->cfg.n_levels - 1);
   if (T < min_t) return fail("T=%d too short for %d levels", T, h->cfg.n_levels);
-  if (h->arena) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(h->arena); h->arena = nullptr; }
-  if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
+  drop_plan(h);
   h->B = B; h->T = T; h->Lp = Lp;
   h->has_mask = false;
   if (build_plan(h, true)) return 1;
@@ -1187,25 +1173,45 @@ int ns2vc_unet_workspace_bytes(ns2vc_unet* h, size_t* out) {
   return 0;
 }
 
-int ns2vc_unet_set_condition(ns2vc_unet* h, const float* content_bct, const float* prompt_blc, const uint8_t* mask_bl, void* stream) {
+int ns2vc_unet_set_content(ns2vc_unet* h, const float* content_bct, void* stream) {
   if (check_ready(h, true)) return 1;
-  if (!content_bct || !prompt_blc) return fail("null condition tensor");
+  if (!content_bct) return fail("null condition tensor");
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
+  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, nullptr, h->content_op, h->prec, c.content_channels, c.content_channels, s));
+  return run_ops(h->cond_ops, s, 0, h->cond_split);
+}
+
+int ns2vc_unet_set_mask(ns2vc_unet* h, const uint8_t* mask_bl, void* stream) {
+  if (check_ready(h, true)) return 1;
+  hipStream_t s = (hipStream_t)stream;
   const bool want_mask = mask_bl != nullptr;
   if (want_mask != h->has_mask) {
-    // the cross-attention launches bake in whether a bias is read: rebuild the (cheap) plan
+    // the cross-attention launches bake in whether a bias is read: rebuild the (cheap) plan; workspace offsets do not
+    // depend on it, so everything already hoisted stays valid
     h->has_mask = want_mask;
     if (h->step_graph) { (void)hipGraphExecDestroy(h->step_graph); h->step_graph = nullptr; }
     if (build_plan(h, false)) return 1;
   }
-  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, nullptr, h->content_op, h->prec, c.content_channels, c.content_channels, s));
-  HIPCHK(hipMemcpyAsync(h->prompt, prompt_blc, (size_t)h->B * h->Lp * c.cross_attention_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (want_mask) {
     HIPCHK(hipMemcpyAsync(h->mask_dev, mask_bl, (size_t)h->B * h->Lp, hipMemcpyDeviceToDevice, s));
     HIPCHK(launch_mask_bias(h->mask_dev, h->B * h->Lp, h->maskbias, s));
   }
-  return run_ops(h->cond_ops, s);
+  return 0;
+}
+
+int ns2vc_unet_set_prompt(ns2vc_unet* h, const float* prompt_blc, const uint8_t* mask_bl, void* stream) {
+  if (!prompt_blc) return fail("null condition tensor");
+  if (ns2vc_unet_set_mask(h, mask_bl, stream)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(h->prompt, prompt_blc, (size_t)h->B * h->Lp * h->cfg.cross_attention_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return run_ops(h->cond_ops, s, h->cond_split);
+}
+
+int ns2vc_unet_set_condition(ns2vc_unet* h, const float* content_bct, const float* prompt_blc, const uint8_t* mask_bl, void* stream) {
+  if (!content_bct || !prompt_blc) return fail("null condition tensor");
+  if (ns2vc_unet_set_prompt(h, prompt_blc, mask_bl, stream)) return 1;      // (first: it may rebuild the plan)
+  return ns2vc_unet_set_content(h, content_bct, stream);
 }
 
 int ns2vc_unet_forward(ns2vc_unet* h, const float* x_bct, const float* t_b, float* out_bct, void* stream) {
@@ -1363,9 +1369,9 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
     inited = true;
   }
   void* d = nullptr;
-  if (precision == NS2VC_PREC_BF16) {
+  if (precision != NS2VC_PREC_F32) {
     std::vector<uint16_t> q((size_t)N * K);
-    for (size_t i = 0; i < q.size(); ++i) q[i] = f32_to_bf16_bits(rows_host[i]);
+    for (size_t i = 0; i < q.size(); ++i) q[i] = f32_to_op16_bits(rows_host[i], precision);
     HIPCHK(hipMalloc(&d, q.size() * 2));
     HIPCHK(hipMemcpy(d, q.data(), q.size() * 2, hipMemcpyHostToDevice));
   } else {
@@ -1377,7 +1383,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
 }
 int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev) {
   if (!rows_host || !out_dev || N <= 0 || K <= 0) return fail("bad argument");
-  const std::vector<float> ws = rounded_rowsum(rows_host, N, K, N, precision == NS2VC_PREC_BF16 ? PREC_BF16 : PREC_F32);
+  const std::vector<float> ws = rounded_rowsum(rows_host, N, K, N, precision);
   void* d = nullptr;
   HIPCHK(hipMalloc(&d, ws.size() * sizeof(float)));
   HIPCHK(hipMemcpy(d, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1392,35 +1398,10 @@ int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (e != hipSuccess) return fail("launch_gemm: %s", hipGetErrorString(e));
   return 0;
 }
-int ns2vc_k_convgn(const ns2vc_convgn_args* a, int precision, void* stream) {
-  if (!a) return fail("null args");
-  hipError_t e = launch_convgn(*a, precision, (hipStream_t)stream);
-  if (e != hipSuccess) return fail("launch_convgn: %s", hipGetErrorString(e));
-  return 0;
-}
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_attention(*a, head_dim, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("launch_attention: %s", hipGetErrorString(e));
-  return 0;
-}
-int ns2vc_pack_chain_stream(const float* const* mats_host, const int* Ns, const int* Ks, int count, void** out_dev) {
-  if (!mats_host || !Ns || !Ks || !out_dev || count <= 0) return fail("bad argument");
-  std::vector<uint16_t> st;
-  for (int i = 0; i < count; ++i) {
-    if (Ns[i] % 128 || Ks[i] % 64) return fail("chain matrix %d: N %% 128 and K %% 64 must be 0", i);
-    append_chain_tiles(st, mats_host[i], Ns[i], Ks[i]);
-  }
-  void* d = nullptr;
-  HIPCHK(hipMalloc(&d, st.size() * 2));
-  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
-  *out_dev = d;
-  return 0;
-}
-int ns2vc_k_chain_ab(const void* a_op, int M, int D, const void* wstream, const float* bias1, const float* res, float* y, float eps,
-                     const float* bias2, void* out2_op, int N2, void* stream) {
-  hipError_t e = launch_chain_ab(a_op, M, D, wstream, bias1, res, y, eps, bias2, out2_op, N2, (hipStream_t)stream);
-  if (e != hipSuccess) return fail("chain_ab launch: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
@@ -1447,9 +1428,9 @@ int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, vo
 int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev) {
   if (!host || !out_dev) return fail("null argument");
   void* d = nullptr;
-  if (precision == NS2VC_PREC_BF16) {
+  if (precision != NS2VC_PREC_F32) {
     std::vector<uint16_t> q(n);
-    for (size_t i = 0; i < n; ++i) q[i] = f32_to_bf16_bits(host[i]);
+    for (size_t i = 0; i < n; ++i) q[i] = f32_to_op16_bits(host[i], precision);
     HIPCHK(hipMalloc(&d, std::max<size_t>(n, 1) * 2));
     HIPCHK(hipMemcpy(d, q.data(), n * 2, hipMemcpyHostToDevice));
   } else {
@@ -1459,13 +1440,20 @@ int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev)
   *out_dev = d;
   return 0;
 }
+int ns2vc_round_to_operand(const float* host_in, size_t n, int precision, float* host_out) {
+  if (!host_in || !host_out) return fail("null argument");
+  if (precision != NS2VC_PREC_F32 && precision != NS2VC_PREC_BF16 && precision != NS2VC_PREC_F16) return fail("unknown precision %d", precision);
+  for (size_t i = 0; i < n; ++i)
+    host_out[i] = precision == NS2VC_PREC_F32 ? host_in[i] : op16_bits_to_f32(f32_to_op16_bits(host_in[i], precision), precision);
+  return 0;
+}
 int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host) {
   if (!dev || !host) return fail("null argument");
   HIPCHK(hipDeviceSynchronize());
-  if (precision == NS2VC_PREC_BF16) {
+  if (precision != NS2VC_PREC_F32) {
     std::vector<uint16_t> q(n);
     HIPCHK(hipMemcpy(q.data(), dev, n * 2, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) host[i] = bf16_bits_to_f32(q[i]);
+    for (size_t i = 0; i < n; ++i) host[i] = op16_bits_to_f32(q[i], precision);
   } else {
     HIPCHK(hipMemcpy(host, dev, n * 4, hipMemcpyDeviceToHost));
   }

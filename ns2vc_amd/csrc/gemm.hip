@@ -25,9 +25,10 @@
 //     one raw s_barrier per K tile; the DMA is issued through inline asm so the
 //     compiler does not drain it in front of every ds_read.
 // Kernels: gemm4_kernel (default; 512 threads, two wave groups on opposite halves of every
-// K tile, see its header), gemm2_kernel (256 threads = 2x2 waves), gemm3_kernel
-// (register-staged experiment).  Wave tiles are built from 32x32 MFMA tiles:
-//   bf16: v_mfma_f32_32x32x16_bf16 (one per 32-B k-slab)
+// K tile, see its header) and gemm2_kernel (256 threads = 2x2 waves; narrow GEGLU and the
+// 64-column fallback).  Wave tiles are built from 32x32 MFMA tiles:
+//   fp16: v_mfma_f32_32x32x16_f16  (one per 32-B k-slab; the default 16-bit mode: 8.3e-4 end to end)
+//   bf16: v_mfma_f32_32x32x16_bf16 (one per 32-B k-slab; same rate and bytes, 6.5e-3 end to end)
 //   f32 : v_mfma_f32_32x32x2_f32   (four per 32-B k-slab; exact fp32 parity mode)
 // Epilogue: bias, GEGLU (value * gelu_erf(gate)), LayerNorm fix-up, fp32 residual add,
 // fp32 store (residual stream) and/or operand-typed store (feeds the next GEMM /
@@ -68,7 +69,7 @@ __device__ __forceinline__ void ln_row_load(const GemmArgs& g, int m, bool valid
   for (int i = 0; i < 4; ++i) r.v[i] = (valid && i < n4) ? p[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 // consumer, part 2 (epilogue): mean / rstd of the row
-__device__ __forceinline__ void ln_row_finish(const GemmArgs& g, const LnRaw& r, float& mean_f, float& rstd_f) {
+__device__ __forceinline__ void ln_row_finish(const GemmArgs& g, const LnRaw& r, float& mean_f, float& rstd_f, int n0) {
   float s = 0.f, q = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { s += r.v[i].x + r.v[i].z; q += r.v[i].y + r.v[i].w; }
@@ -78,6 +79,16 @@ __device__ __forceinline__ void ln_row_finish(const GemmArgs& g, const LnRaw& r,
   if (var < 0.0) var = 0.0;
   mean_f = mean;
   rstd_f = 1.0f / sqrtf((float)var + g.ln_eps);
+  // health of the linearity trick: the 16-bit modes round the raw row BEFORE centring, so the error on a row grows with
+  // |mean| / std.  The first column workgroup of every row panel reports the largest ratio it sees (a plain read first:
+  // the atomic is issued only by a wave that raises the maximum, i.e. a handful of times per forward).
+  if (g.ln_health && n0 == 0) {
+    float ratio = fabsf(mean) * rstd_f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
+    if ((threadIdx.x & 63) == 0 && ratio > __uint_as_float(__hip_atomic_load(g.ln_health, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+      atomicMax(g.ln_health, __float_as_uint(ratio));
+  }
 }
 // sum over the 16 lanes (one DPP row) that hold one 64-column slice of a result row; no LDS traffic, all 16 get the total
 __device__ __forceinline__ float sum16_dpp(float x) {
@@ -128,7 +139,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
   // of the kernel so the latency hid under the K loop), fetched per row by shuffle
   constexpr bool lnc = LNC;           // compile-time: GEMMs that are not LayerNorm consumers carry none of this
   float lmean = 0.f, lrstd = 1.f;
-  if constexpr (lnc) ln_row_finish(g, lnraw, lmean, lrstd);
+  if constexpr (lnc) ln_row_finish(g, lnraw, lmean, lrstd, n0);
   if (g.geglu) {
     if constexpr (NT == 2) {
       constexpr int LPR = 8, RPI = 8, NIT = WM / RPI;          // 32 output columns per row = 8 lanes x 4
@@ -419,165 +430,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
 }
 
 // ---------------------------------------------------------------------------
-// Register-staged variant.  Measured on MI355X (tools/gemm_trace.py): one global_load_lds costs a wave ~100-170
-// issue cycles per KB, and with the small tiles this workload allows (64x128: 6 DMA pieces per 8 MFMAs) the
-// K loop of gemm2_kernel is DMA-ISSUE-bound (~1600 cycles per K tile for 256 cycles of MFMA).  A plain
-// global_load_dwordx4 + ds_write_b128 moves the same KB for ~20 issue cycles, so here the operands go
-// HBM/L2 -> VGPR -> LDS: two LDS stages, two register sets (tiles kt+1 and kt+2 in flight while tile kt is
-// multiplied), swizzle applied on the LDS write address (global reads stay perfectly coalesced: 8 lanes = one
-// 128-B row), one __syncthreads per K tile.  hipcc counts vmcnt for ordinary loads itself.
-// ---------------------------------------------------------------------------
-template <typename TM, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm3_kernel(const GemmArgs g) {
-  constexpr int EPC = MmaT<TM>::EPC;
-  constexpr int BKE = 8 * EPC;
-  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
-  constexpr int LA = BM / 32, LB = BN / 32;
-  constexpr int STAGE = (BM + BN) * TROW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  unsigned long long* tr = NS2VC_TRACE_PTR();
-  NS2VC_STAMP(0);
-
-  const int nb_n = g.N / BN;
-  const int nb_m = (g.M + BM - 1) / BM;
-  const int nwg = nb_n * nb_m;
-  int tm, tn;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tm = swz / nb_n;
-    tn = swz - tm * nb_n;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  const int prow = tid >> 3, pchunk = tid & 7;
-  const int Ctot = g.c0 + g.c1;
-  const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
-  const int toff = g.taps >> 1;
-  const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
-  const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
-  int rt0[LA], rt1[LA], rt2[LA];
-#pragma unroll
-  for (int j = 0; j < LA; ++j) {
-    const int m = m0 + j * 32 + prow;
-    const bool mok = m < g.M;
-    const int b = mok ? m / g.Tout : 0;
-    const int t = m - b * g.Tout;
-    auto src_row = [&](int tp) __attribute__((always_inline)) {
-      const int u = t * smul + tp - toff;
-      const bool ok = mok && (tp < g.taps) && (u >= 0) && (u < ulim);
-      return ok ? b * g.Tin + min(u >> ushr, g.Tin - 1) : -1;
-    };
-    rt0[j] = src_row(0); rt1[j] = src_row(1); rt2[j] = src_row(2);
-  }
-  const TM* wrow[LB];
-#pragma unroll
-  for (int j = 0; j < LB; ++j) wrow[j] = reinterpret_cast<const TM*>(g.w) + ((size_t)(n0 + j * 32 + prow) * g.K + pchunk * EPC);
-  const unsigned long long zero = reinterpret_cast<unsigned long long>(g_zero_page);
-  // LDS byte offset of this thread's piece inside a tile pass (row prow of the pass, swizzled chunk position)
-  int woff[LA > LB ? LA : LB];
-#pragma unroll
-  for (int j = 0; j < (LA > LB ? LA : LB); ++j) {
-    const int row = j * 32 + prow;
-    woff[j] = row * TROW + ((pchunk ^ ((row >> 1) & 7)) << 4);
-  }
-  const int K1 = g.taps * Ctot;
-
-  auto load_tile = [&](int kt, u32x4_t (&ra)[LA], u32x4_t (&rb)[LB]) __attribute__((always_inline)) {
-    const int k0 = kt * BKE;
-    const bool seg2 = k0 >= K1;
-    const int k1 = seg2 ? 0 : k0;
-    const int tapq = k1 / Ctot;
-    const int tap = seg2 ? toff : tapq;
-    const int cc = k1 - tapq * Ctot;
-    const bool first = cc < g.c0;
-    const unsigned long long src = reinterpret_cast<unsigned long long>(seg2 ? g.a2 : (first ? g.a0 : g.a1));
-    const int ld = seg2 ? g.lda2 : (first ? g.lda0 : g.lda1);
-    const int csrc = (seg2 ? k0 - K1 : (first ? cc : cc - g.c0)) + pchunk * EPC;
-#pragma unroll
-    for (int j = 0; j < LA; ++j) {
-      const int r = tap == 0 ? rt0[j] : (tap == 1 ? rt1[j] : rt2[j]);
-      const unsigned eoff = (unsigned)max(r, 0) * (unsigned)ld + (unsigned)csrc;
-      const unsigned long long pa = src + (unsigned long long)eoff * sizeof(TM);
-      ra[j] = *reinterpret_cast<const u32x4_t*>(r >= 0 ? pa : zero);
-    }
-#pragma unroll
-    for (int j = 0; j < LB; ++j) rb[j] = *reinterpret_cast<const u32x4_t*>(wrow[j] + k0);
-  };
-  auto store_tile = [&](int stage, const u32x4_t (&ra)[LA], const u32x4_t (&rb)[LB]) __attribute__((always_inline)) {
-    char* As = smem + stage * STAGE;
-    char* Bs = As + BM * TROW;
-#pragma unroll
-    for (int j = 0; j < LA; ++j) *reinterpret_cast<u32x4_t*>(As + woff[j]) = ra[j];
-#pragma unroll
-    for (int j = 0; j < LB; ++j) *reinterpret_cast<u32x4_t*>(Bs + woff[j]) = rb[j];
-  };
-
-  f32x16_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int sw = (l31 >> 1) & 7;
-  auto compute = [&](int stage) __attribute__((always_inline)) {
-    const char* As = smem + stage * STAGE;
-    const char* Bs = As + BM * TROW;
-    const char* ap = As + (wm * WM + l31) * TROW;
-    const char* bp = Bs + (wn * WN + l31) * TROW;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int coff = ((2 * ks + hi) ^ sw) * 16;
-      u32x4_t af[MT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
-    }
-  };
-
-  const int nk = g.K / BKE;
-  u32x4_t a0[LA], b0[LB], a1[LA], b1[LB];      // two register sets: tiles kt+1 and kt+2 in flight
-  NS2VC_STAMP(1);
-  load_tile(0, a0, b0);
-  if (nk > 1) load_tile(1, a1, b1);
-  NS2VC_STAMP(2);
-  store_tile(0, a0, b0);
-  __syncthreads();
-  NS2VC_STAMP(3);
-  // steady state, unrolled by two so the register sets are named statically
-  int kt = 0;
-  for (; kt + 2 <= nk; kt += 2) {
-    if (kt + 2 < nk) load_tile(kt + 2, a0, b0);
-    compute(0);
-    if (kt + 1 < nk) store_tile(1, a1, b1);
-    __syncthreads();
-    if (kt + 3 < nk) load_tile(kt + 3, a1, b1);
-    compute(1);
-    if (kt + 2 < nk) store_tile(0, a0, b0);
-    __syncthreads();
-  }
-  if (kt < nk) compute(0);                     // odd tail: tile nk-1 sits in stage 0
-  NS2VC_STAMP(4);
-  LnRaw lnraw;                                 // (this experimental variant is not a LayerNorm consumer)
-  gemm_epilogue<TM, BM, BN, false>(g, acc, smem, m0, n0, tid, tr, lnraw);
-}
-
-// ---------------------------------------------------------------------------
-// epilogue of the 8-wave K-split kernels (gemm4_kernel, conv3gn_kernel): per 32-row slab, both K halves stage their
+// epilogue of the 8-wave K-split kernel (gemm4_kernel): per 32-row slab, both K halves stage their
 // partial tile in LDS (re-using the operand ring), then each of the eight waves adds the pair for 16 rows and moves
 // whole rows out (16-B fp32 / 8-B bf16 stores, coalesced); bias, GEGLU, LayerNorm fix-up, residual, statistics.
 // ---------------------------------------------------------------------------
@@ -621,7 +474,7 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
   float lmean = 0.f, lrstd = 1.f;
   float4 ws = make_float4(0.f, 0.f, 0.f, 0.f), wsv = ws, wsg = ws;
   if constexpr (lnc) {
-    ln_row_finish(g, lnraw, lmean, lrstd);
+    ln_row_finish(g, lnraw, lmean, lrstd, n0);
     if (g.geglu) { wsv = *reinterpret_cast<const float4*>(g.ln_wsum + pcol); wsg = *reinterpret_cast<const float4*>(g.ln_wsum + pcol + 32); }
     else ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
   }
@@ -925,285 +778,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------
-// GroupNorm(+time scale/shift)(+SiLU) fused into the 3-tap conv that consumes it (resnet.py:591-641).
-//
-// A normalisation pass costs a launch (~4.5 us of fixed latency on this chip) plus a read of the fp32 stream and a
-// write + three L2 reads of the operand tensor.  Here the workgroup that owns 64 output rows loads those rows and one
-// halo row each side straight from the fp32 stream, finalises mean / rstd from the producers' epilogue statistics,
-// applies affine (+ time scale/shift) + SiLU in registers and writes the result ONCE into an LDS panel laid out as
-// the K tiles the MFMA fragments want (same XOR swizzle as the DMA image).  The three taps are the same panel read at
-// row offsets 0/1/2; rows that fall off the sequence ends are masked per fragment lane.  Only the weights (and the
-// optional fused 1x1 shortcut operand) still stream through the LDS ring, 16 KB per K step instead of 24.
-// Structure otherwise as gemm4_kernel (512 threads, K split across the two wave groups, shared epilogue).
-// ---------------------------------------------------------------------------
-template <typename TM, int CT64>      // CT64 = input channels / 64 (2, 4, 6, 8): fixes the thread -> (row, channel quad) map at compile time
-__global__ __launch_bounds__(512) void conv3gn_kernel(const ConvGnArgs a) {
-  const GemmArgs& g = a.g;
-  constexpr int EPC = MmaT<TM>::EPC;
-  constexpr int BKE = 8 * EPC;
-  constexpr int BM = 64, BN = 128, STAGES = 3;
-  constexpr int WM = BM / 2, WN = BN / 2, MT = 1, NT = 2;
-  constexpr int LB = BN / 64;
-  constexpr int STAGE = (BM + BN) * TROW;                 // [fused-shortcut A tile 8 KB][W tile 16 KB]
-  constexpr int PROWS = BM + 2;                           // panel rows: output rows -1 .. BM
-  constexpr int PTILE = PROWS * TROW;                     // bytes of one K tile of the panel
-  constexpr unsigned SZB = sizeof(TM);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  __shared__ float s_mean[2][8], s_rstd[2][8];
-  char* const panel = smem + STAGES * STAGE;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave >> 2, wq = wave & 3;
-  const int wm = wq >> 1, wn = wq & 1;
-  const unsigned lds0 = (unsigned)(size_t)smem;
-  unsigned long long* tr = NS2VC_TRACE_PTR();
-  NS2VC_STAMP(0);
-
-  const int nb_n = g.N / BN;
-  const int nb_m = (g.M + BM - 1) / BM;
-  const int nwg = nb_n * nb_m;
-  int tm, tn;
-  {
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    tm = swz / nb_n;
-    tn = swz - tm * nb_n;
-  }
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int T = g.Tout;
-  const int Ctot = g.c0 + g.c1;
-  const int nct = Ctot / BKE;                             // K tiles per tap
-  const int nk = g.K / BKE;                               // 3 * nct (+ fused 1x1 segment)
-  const int K1 = 3 * Ctot;
-
-  // ---- weight (and shortcut operand) stream: buffer-descriptor DMA as in gemm4_kernel
-  const int prow = tid >> 3, pchunk = tid & 7;
-  const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;
-  unsigned vw[LB];
-#pragma unroll
-  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * 64 + prow) * (unsigned)g.K) * SZB + acolb;
-  const unsigned va2 = (m0 + prow < g.M) ? (unsigned)(m0 + prow) * (unsigned)g.lda2 * SZB + acolb : DMA_OOB;
-  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
-  const i32x4_t rA2 = make_rsrc(g.c2 ? g.a2 : g.w, g.c2 ? (unsigned long long)g.M * g.lda2 * SZB : 16ull);
-  int is_k = 0;
-  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
-    const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
-    if (is_k >= K1) blds16(rA2, va2, (unsigned)(is_k - K1) * SZB, sbase);
-    const unsigned bbase = sbase + BM * TROW;
-    const unsigned soffW = (unsigned)is_k * SZB;
-#pragma unroll
-    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * 8192);
-    is_k += BKE;
-  };
-  NS2VC_STAMP(1);
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_tile(s);                            // the first weight tiles fly while the panel is built
-  NS2VC_STAMP(2);
-
-  // ---- GroupNorm statistics of the (at most two) batch items this panel touches: wave w finalises group w
-  const int mfirst = max(m0 - 1, 0);
-  const int bA = mfirst / T;
-  const int mSplit = (bA + 1) * T;                        // first global row of batch item bA + 1
-  const int G = a.groups, Cg = Ctot / G;
-  {
-    const int nb = Cg >> 4, nblk0 = g.c0 >> 4, nblk1 = g.c1 >> 4;
-    const int nB = g.M / T;
-    for (int which = 0; which < 2; ++which) {
-      const int b = min(bA + which, nB - 1);
-      double ds = 0.0, dq = 0.0;
-      if (wave < G && lane < nb) {
-        const int blk = wave * nb + lane;
-        const long long* p = blk < nblk0 ? a.st0 + ((size_t)b * nblk0 + blk) * 2 : a.st1 + ((size_t)b * nblk1 + (blk - nblk0)) * 2;
-        ds = (double)p[0] * (1.0 / GN_SUM_SCALE);
-        dq = (double)p[1] * (1.0 / GN_SQ_SCALE);
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o); dq += __shfl_xor(dq, o); }
-      if (wave < G && lane == 0) {
-        const float inv_nf = 1.0f / ((float)T * (float)Cg);
-        const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
-        const double mean = ds * inv_n;
-        double var = dq * inv_n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float ve = (float)var + a.eps;
-        float r = rsqrtf(ve);
-        r = r * (1.5f - 0.5f * ve * r * r);
-        s_mean[which][wave] = (float)mean;
-        s_rstd[which][wave] = r;
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- build the panel: thread = (channel quad, row lane); rows p = 0 .. 65 are global rows m0 - 1 + p
-  {
-    constexpr int nq = CT64 * 16;                         // channel quads per row
-    constexpr int rl = 512 / nq;                          // row lanes: 16, 8, 5, 4
-    constexpr int NR = (PROWS + rl - 1) / rl;             // rows per thread: 5, 9, 14, 17 -- ALL loaded before any is used,
-    const int quad = tid % nq, rlane = tid / nq;          // so the panel costs one (cold) memory round trip, not NR/4
-    const bool active = rlane < rl;
-    const int c = quad * 4;
-    const float* src; int ld, cs;
-    if (c < g.c0) { src = a.x0; ld = a.ldx0; cs = c; } else { src = a.x1; ld = a.ldx1; cs = c - g.c0; }
-    float4 v[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int p = rlane + k * rl;
-      const int mg = m0 - 1 + p;
-      v[k] = (active && p < PROWS && mg >= 0 && mg < g.M) ? *reinterpret_cast<const float4*>(src + (size_t)mg * ld + cs)
-                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float sc[2][4], sh[2][4];
-    {
-      const int gi = c / Cg;
-      const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c);
-      const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
-      const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
-      const int nB = g.M / T;
-#pragma unroll
-      for (int which = 0; which < 2; ++which) {
-        const int b = min(bA + which, nB - 1);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float s1 = s_rstd[which][gi] * gam[e];
-          float s2 = bet[e] - s_mean[which][gi] * s1;
-          if (a.temb) {
-            const float ts = 1.0f + a.temb[(size_t)b * a.ldtemb + a.temb_off + c + e];
-            const float tf = a.temb[(size_t)b * a.ldtemb + a.temb_off + Ctot + c + e];
-            s1 *= ts;
-            s2 = s2 * ts + tf;
-          }
-          sc[which][e] = s1; sh[which][e] = s2;
-        }
-      }
-    }
-    // LDS position of this quad inside a panel row: K tile, 16-B chunk, offset inside the chunk
-    const int ct = (c * (int)SZB) / TROW;
-    const int cbyte = (c * (int)SZB) % TROW;
-    const int chunk = cbyte >> 4, sub = cbyte & 15;
-    TM* const rawp = reinterpret_cast<TM*>(a.raw_op);
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int p = rlane + k * rl;
-      if (!active || p >= PROWS) continue;
-      const int mg = m0 - 1 + p;
-      const bool ok = mg >= 0 && mg < g.M;
-      const int w = mg >= mSplit ? 1 : 0;
-      float y0 = v[k].x * sc[w][0] + sh[w][0], y1 = v[k].y * sc[w][1] + sh[w][1];
-      float y2 = v[k].z * sc[w][2] + sh[w][2], y3 = v[k].w * sc[w][3] + sh[w][3];
-      if (a.silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-      if (!ok) { y0 = y1 = y2 = y3 = 0.f; }
-      store_op4<TM>(reinterpret_cast<TM*>(panel + ct * PTILE + p * TROW + ((chunk ^ ((p >> 1) & 7)) << 4) + sub), y0, y1, y2, y3);
-      if (rawp && tn == 0 && ok && p >= 1 && p <= BM) store_op4<TM>(rawp + (size_t)mg * Ctot + c, v[k].x, v[k].y, v[k].z, v[k].w);
-    }
-  }
-
-  f32x16_t acc[MT][NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-
-  // per-lane validity of the three taps for this lane's output row (sequence ends: zero padding)
-  const int l31 = lane & 31, hi = lane >> 5;
-  bool tapok[3];
-  {
-    const int m = m0 + wm * WM + l31;
-    const int t = m % T;
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp) tapok[tp] = m < g.M && (t + tp - 1) >= 0 && (t + tp - 1) < T;
-  }
-  LnRaw lnraw;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) lnraw.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();                                         // panel complete
-  NS2VC_STAMP(3);
-
-  int stage = 0, tap = 0, ctile = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt has landed when only the pieces of tile kt+1 are still in flight (2 weight pieces, +1 in the 1x1 segment)
-    if (kt + 1 < nk) {
-      if ((kt + 1) * BKE >= K1) wait_vmcnt<LB + 1>(); else wait_vmcnt<LB>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    auto refill = [&]() __attribute__((always_inline)) {
-      if (kt + STAGES - 1 < nk) {
-        int st2 = stage + STAGES - 1;
-        if (st2 >= STAGES) st2 -= STAGES;
-        issue_tile(st2);
-      }
-    };
-    if (kg == 0) refill();
-    {
-      const char* Ws = smem + stage * STAGE + BM * TROW;
-      const char* bp = Ws + (wn * WN + l31) * TROW;
-      const bool seg2 = kt * BKE >= K1;                    // wave-uniform
-      const int R = wm * WM + l31 + tap;                   // panel row of this lane's A fragment
-      const char* ap = seg2 ? smem + stage * STAGE + (wm * WM + l31) * TROW : panel + ctile * PTILE + R * TROW;
-      const int swa = seg2 ? (l31 >> 1) & 7 : (R >> 1) & 7;
-      const int swb = (l31 >> 1) & 7;
-      const bool aok = seg2 || (tap == 0 ? tapok[0] : (tap == 1 ? tapok[1] : tapok[2]));
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int ch = 2 * (2 * kg + kk) + hi;
-        u32x4_t af = *reinterpret_cast<const u32x4_t*>(ap + ((ch ^ swa) << 4));
-        if (!aok) af = u32x4_t{0, 0, 0, 0};
-        u32x4_t bf[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + ((ch ^ swb) << 4));
-#pragma unroll
-        for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[0][j], af, bf[j]);
-      }
-    }
-    if (kg != 0) refill();
-    if (++stage == STAGES) stage = 0;
-    if (++ctile == nct) { ctile = 0; ++tap; }
-  }
-  gemm4_epilogue<TM, BM, false>(g, acc, smem, m0, n0, tid, tr, lnraw);
-}
-
-static size_t convgn_lds_bytes(int ctot, int prec) {
-  const size_t ring = (size_t)3 * (64 + 128) * TROW;
-  const size_t panel = (size_t)(ctot / (prec == PREC_BF16 ? 64 : 32)) * 66 * TROW;
-  return ring + panel;                                     // the epilogue's 69.6 KB staging fits in the 72 KB ring
-}
-constexpr size_t CONVGN_LDS_MAX = 160 * 1024 - 512;       // (the kernel also has 128 B of static LDS)
-bool convgn_eligible(const ConvGnArgs& a, int prec) {
-  const GemmArgs& g = a.g;
-  const int ctot = g.c0 + g.c1;
-  if (ctot <= 0 || convgn_lds_bytes(ctot, prec) > CONVGN_LDS_MAX) return false;      // bf16: up to 512 channels, fp32: up to 320
-  return g.taps == 3 && g.tmode == TMODE_SAME && g.Tin == g.Tout && g.Tout >= 66 && (g.N % 128) == 0 && ctot <= 512 && (ctot % 128) == 0 &&
-         (g.c0 % 16) == 0 && a.groups == 8 && ((ctot / 8) % 16) == 0 && a.st0 && (!g.c1 || a.st1) && !g.geglu && !g.ln_stats && (g.M % g.Tout) == 0;
-}
-hipError_t launch_convgn(const ConvGnArgs& a, int prec, hipStream_t s) {
-  const GemmArgs& g = a.g;
-  if (!convgn_eligible(a, prec) || !a.x0 || !a.gamma || !a.beta) return hipErrorInvalidValue;
-  const int bke = prec == PREC_BF16 ? 64 : 32;
-  if (g.K != 3 * (g.c0 + g.c1) + g.c2 || (g.c2 % bke) || (g.c2 && (!g.a2 || (g.lda2 % (bke / 8))))) return hipErrorInvalidValue;
-  if ((a.ldx0 & 3) || (g.c1 && (a.ldx1 & 3)) || (!g.out_f32 && !g.out_op)) return hipErrorInvalidValue;
-  if (g.stats && (g.Tout < 64 || (g.N & 15))) return hipErrorInvalidValue;
-  if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;
-  const size_t lds = convgn_lds_bytes(g.c0 + g.c1, prec);
-  const int nb = (g.N / 128) * ((g.M + 63) / 64);
-  const int ct64 = (g.c0 + g.c1) / 64;
-#define NS2VC_CGN(TM_, CT_) case CT_: hipLaunchKernelGGL((conv3gn_kernel<TM_, CT_>), dim3(nb), dim3(512), lds, s, a); break
-  if (prec == PREC_BF16) {
-    switch (ct64) { NS2VC_CGN(bf16_t, 2); NS2VC_CGN(bf16_t, 4); NS2VC_CGN(bf16_t, 6); NS2VC_CGN(bf16_t, 8); default: return hipErrorInvalidValue; }
-  } else {
-    switch (ct64) { NS2VC_CGN(float, 2); NS2VC_CGN(float, 4); default: return hipErrorInvalidValue; }
-  }
-#undef NS2VC_CGN
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
 // LDS = max(STAGES-deep operand ring, the epilogue's per-wave transpose tiles)
@@ -1224,13 +798,6 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
 }
 
 void set_gemm_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &p, sizeof(p)); }
-template <typename TM, int BM, int BN>
-static hipError_t launch_cfg3(const GemmArgs& g, hipStream_t s) {
-  const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
-  const size_t lds = gemm_lds_bytes(BM, BN, 2);
-  hipLaunchKernelGGL((gemm3_kernel<TM, BM, BN>), dim3(nb), dim3(256), lds, s, g);
-  return hipGetLastError();
-}
 
 static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
   const size_t ring = (size_t)stages * (bm + bn) * TROW;
@@ -1248,9 +815,11 @@ static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
 void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
+// Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
+// The compiled set is exactly what this function can return plus the tiles the kernel tests force:
+//   gemm4: {128, 64} x 128, ring {2, 3};   gemm2: 64x128 ring {2, 3}, 128x128 ring 2, 64x64 ring {2, 3, 4}.
 template <typename TM>
 static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
-  auto blocks = [&](int bm, int bn) { return (long)(g.N / bn) * ((g.M + bm - 1) / bm); };
   const int bke = 128 / (int)sizeof(TM);
   const int nk = g.K / bke;
   int bm, bn, st;
@@ -1259,11 +828,9 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
     bm = g_force_bm; bn = g_force_bn; st = g_force_st ? g_force_st : 3;
     if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return hipErrorInvalidValue;
   } else {
-    (void)blocks;
     // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01d_bufferdma.txt).
-    // The 8-wave K-split kernel with buffer-descriptor DMA (stages 12..14 = ring 2..4) wins everywhere except the
-    // narrowest GEGLU; 128-row tiles pay off once K is long (>= 12 tiles) or N is wide, and only while the grid still
-    // covers the chip (M >= ~7000 rows).
+    // The 8-wave K-split kernel wins everywhere except the narrowest GEGLU; 128-row tiles pay off once K is long
+    // (>= 12 tiles) or N is wide, and only while the grid still covers the chip (M >= ~7000 rows).
     const bool big_m = g.M >= 7000;
     if (g.geglu) {
       if (!n128) return hipErrorInvalidValue;
@@ -1281,26 +848,16 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
   }
-  if (st >= 12 && st <= 14) {   // 8-wave K-split kernel, ring depth st - 10
+  if (st == 12 || st == 13) {   // 8-wave K-split kernel, ring depth st - 10
     if (bn != 128) return hipErrorInvalidValue;
 #define NS2VC_CASE4(BM_, ST_) if (bm == BM_ && st == 10 + ST_) return launch_cfg4<TM, BM_, 128, ST_>(g, s)
-    NS2VC_CASE4(128, 2); NS2VC_CASE4(128, 3); NS2VC_CASE4(128, 4);
-    NS2VC_CASE4(64, 2); NS2VC_CASE4(64, 3); NS2VC_CASE4(64, 4);
+    NS2VC_CASE4(128, 2); NS2VC_CASE4(128, 3); NS2VC_CASE4(64, 2); NS2VC_CASE4(64, 3);
 #undef NS2VC_CASE4
     return hipErrorInvalidValue;
   }
-  if (st == 1 && g.ln_stats) return hipErrorInvalidValue;
-  if (st == 1) {     // register-staged kernel (ring depth is fixed: 2 LDS stages + 2 register sets)
-    if (bm == 128 && bn == 128) return launch_cfg3<TM, 128, 128>(g, s);
-    if (bm == 64 && bn == 128) return launch_cfg3<TM, 64, 128>(g, s);
-    if (bm == 128 && bn == 64) return launch_cfg3<TM, 128, 64>(g, s);
-    if (bm == 64 && bn == 64) return launch_cfg3<TM, 64, 64>(g, s);
-    return hipErrorInvalidValue;
-  }
 #define NS2VC_CASE(BM_, BN_, ST_) if (bm == BM_ && bn == BN_ && st == ST_) return launch_cfg<TM, BM_, BN_, ST_>(g, s)
-  NS2VC_CASE(128, 128, 2); NS2VC_CASE(128, 128, 3);
-  NS2VC_CASE(64, 128, 2); NS2VC_CASE(64, 128, 3); NS2VC_CASE(64, 128, 4);
-  NS2VC_CASE(128, 64, 2); NS2VC_CASE(128, 64, 3); NS2VC_CASE(128, 64, 4);
+  NS2VC_CASE(128, 128, 2);
+  NS2VC_CASE(64, 128, 2); NS2VC_CASE(64, 128, 3);
   NS2VC_CASE(64, 64, 2); NS2VC_CASE(64, 64, 3); NS2VC_CASE(64, 64, 4);
 #undef NS2VC_CASE
   return hipErrorInvalidValue;
@@ -1308,7 +865,7 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
 
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.N % 64 != 0 || g.M <= 0) return hipErrorInvalidValue;
-  const int bke = prec == PREC_BF16 ? 64 : 32;
+  const int bke = prec == PREC_F32 ? 32 : 64;
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return hipErrorInvalidValue;
   if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return hipErrorInvalidValue;
   if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
@@ -1319,14 +876,18 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.rowstats && (g.N & 127)) return hipErrorInvalidValue;
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
   {   // the DMA addresses rows by 32-bit byte offsets from each tensor's base: every operand must stay below 4 GB
-    const unsigned long long sz = prec == PREC_BF16 ? 2 : 4, lim = 0xFFF00000ull;
+    const unsigned long long sz = operand_bytes(prec), lim = 0xFFF00000ull;
     const unsigned long long rows = (unsigned long long)g.B * g.Tin;
     if (rows * g.lda0 * sz > lim || (g.c1 && rows * g.lda1 * sz > lim) || (g.c2 && rows * g.lda2 * sz > lim) ||
         (unsigned long long)g.N * g.K * sz > lim)
       return hipErrorInvalidValue;
   }
-  if (prec == PREC_BF16) return launch_typed<bf16_t>(g, s);
-  return launch_typed<float>(g, s);
+  switch (prec) {
+    case PREC_BF16: return launch_typed<bf16_t>(g, s);
+    case PREC_F16: return launch_typed<f16_t>(g, s);
+    case PREC_F32: return launch_typed<float>(g, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
@@ -1339,40 +900,24 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
     if (e == hipSuccess) e = set_lds(gemm2_kernel<TM, BM, BN, ST, true>, gemm_lds_bytes(BM, BN, ST));           \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
-
-#define NS2VC_SET_BOTH(BM, BN, ST) NS2VC_SET(float, BM, BN, ST); NS2VC_SET(bf16_t, BM, BN, ST)
-#define NS2VC_SET3(TM, BM, BN)                                                                                  \
-  do {                                                                                                          \
-    hipError_t e = set_lds(gemm3_kernel<TM, BM, BN>, gemm_lds_bytes(BM, BN, 2));                                \
-    if (e != hipSuccess) return e;                                                                              \
-  } while (0)
 #define NS2VC_SET4(TM, BM, ST)                                                                                  \
   do {                                                                                                          \
     hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false>, gemm4_lds_bytes(BM, 128, ST));                 \
     if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true>, gemm4_lds_bytes(BM, 128, ST));        \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
-hipError_t init_gemm_attributes() {
-  {
-    hipError_t e = set_lds(conv3gn_kernel<bf16_t, 2>, CONVGN_LDS_MAX);
-    if (e == hipSuccess) e = set_lds(conv3gn_kernel<bf16_t, 4>, CONVGN_LDS_MAX);
-    if (e == hipSuccess) e = set_lds(conv3gn_kernel<bf16_t, 6>, CONVGN_LDS_MAX);
-    if (e == hipSuccess) e = set_lds(conv3gn_kernel<bf16_t, 8>, CONVGN_LDS_MAX);
-    if (e == hipSuccess) e = set_lds(conv3gn_kernel<float, 2>, CONVGN_LDS_MAX);
-    if (e == hipSuccess) e = set_lds(conv3gn_kernel<float, 4>, CONVGN_LDS_MAX);
-    if (e != hipSuccess) return e;
-  }
-  NS2VC_SET4(float, 128, 2); NS2VC_SET4(float, 128, 3); NS2VC_SET4(float, 128, 4);
-  NS2VC_SET4(float, 64, 2); NS2VC_SET4(float, 64, 3); NS2VC_SET4(float, 64, 4);
-  NS2VC_SET4(bf16_t, 128, 2); NS2VC_SET4(bf16_t, 128, 3); NS2VC_SET4(bf16_t, 128, 4);
-  NS2VC_SET4(bf16_t, 64, 2); NS2VC_SET4(bf16_t, 64, 3); NS2VC_SET4(bf16_t, 64, 4);
-  NS2VC_SET3(float, 128, 128); NS2VC_SET3(float, 64, 128); NS2VC_SET3(float, 128, 64); NS2VC_SET3(float, 64, 64);
-  NS2VC_SET3(bf16_t, 128, 128); NS2VC_SET3(bf16_t, 64, 128); NS2VC_SET3(bf16_t, 128, 64); NS2VC_SET3(bf16_t, 64, 64);
-  NS2VC_SET_BOTH(128, 128, 2); NS2VC_SET_BOTH(128, 128, 3);
-  NS2VC_SET_BOTH(64, 128, 2); NS2VC_SET_BOTH(64, 128, 3); NS2VC_SET_BOTH(64, 128, 4);
-  NS2VC_SET_BOTH(128, 64, 2); NS2VC_SET_BOTH(128, 64, 3); NS2VC_SET_BOTH(128, 64, 4);
-  NS2VC_SET_BOTH(64, 64, 2); NS2VC_SET_BOTH(64, 64, 3); NS2VC_SET_BOTH(64, 64, 4);
+template <typename TM> static hipError_t init_typed() {
+  NS2VC_SET4(TM, 128, 2); NS2VC_SET4(TM, 128, 3); NS2VC_SET4(TM, 64, 2); NS2VC_SET4(TM, 64, 3);
+  NS2VC_SET(TM, 128, 128, 2);
+  NS2VC_SET(TM, 64, 128, 2); NS2VC_SET(TM, 64, 128, 3);
+  NS2VC_SET(TM, 64, 64, 2); NS2VC_SET(TM, 64, 64, 3); NS2VC_SET(TM, 64, 64, 4);
   return hipSuccess;
+}
+hipError_t init_gemm_attributes() {
+  hipError_t e = init_typed<float>();
+  if (e == hipSuccess) e = init_typed<bf16_t>();
+  if (e == hipSuccess) e = init_typed<f16_t>();
+  return e;
 }
 
 }  // namespace ns2vc

@@ -525,6 +525,15 @@ hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1,
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, partial, rows_per_chunk);
   return hipGetLastError();
 }
+// precision dispatch of a templated kernel launch: TMX is bound to the operand storage type
+#define NS2VC_BY_PREC(prec, ...)                                              \
+  switch (prec) {                                                             \
+    case PREC_BF16: { using TMX = bf16_t; __VA_ARGS__; break; }               \
+    case PREC_F16: { using TMX = f16_t; __VA_ARGS__; break; }                 \
+    case PREC_F32: { using TMX = float; __VA_ARGS__; break; }                 \
+    default: return hipErrorInvalidValue;                                     \
+  }
+
 hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
                            const double* partial, int nchunk, const long long* st0, const long long* st1, const float* gamma,
                            const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, void* raw_op,
@@ -539,12 +548,8 @@ hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, i
   while (rows > 4 * rl && (long)((T + rows - 1) / rows) * B < 1500) rows >>= 1;
   if (rows < 4 * rl) rows = 4 * rl;
   dim3 grid((T + rows - 1) / rows, B);
-  if (prec == PREC_BF16)
-    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, st0, st1,
-                       gamma, beta, temb, ldtemb, temb_off, silu, (bf16_t*)out_op, (bf16_t*)raw_op, rows);
-  else
-    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk, st0, st1,
-                       gamma, beta, temb, ldtemb, temb_off, silu, (float*)out_op, (float*)raw_op, rows);
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(gn_apply_kernel<TMX>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk,
+                                         st0, st1, gamma, beta, temb, ldtemb, temb_off, silu, (TMX*)out_op, (TMX*)raw_op, rows));
   return hipGetLastError();
 }
 template <typename TM> static hipError_t launch_ln_t(const float* x, int ldx, int M, int C, float eps, TM* out, hipStream_t s) {
@@ -560,14 +565,14 @@ template <typename TM> static hipError_t launch_ln_t(const float* x, int ldx, in
 }
 hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s) {
   if (C % 128 || C > 512) return hipErrorInvalidValue;
-  return prec == PREC_BF16 ? launch_ln_t<bf16_t>(x, ldx, M, C, eps, (bf16_t*)out_op, s) : launch_ln_t<float>(x, ldx, M, C, eps, (float*)out_op, s);
+  NS2VC_BY_PREC(prec, return launch_ln_t<TMX>(x, ldx, M, C, eps, (TMX*)out_op, s));
+  return hipSuccess;
 }
 hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s) {
   if (n & 3) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  if (prec == PREC_BF16) hipLaunchKernelGGL(cast_op_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, n4, (bf16_t*)out_op);
-  else hipLaunchKernelGGL(cast_op_kernel<float>, dim3(blocks), dim3(256), 0, s, x, n4, (float*)out_op);
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(cast_op_kernel<TMX>, dim3(blocks), dim3(256), 0, s, x, n4, (TMX*)out_op));
   return hipGetLastError();
 }
 hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float* gamma, const float* beta, float* out, int L,
@@ -595,16 +600,13 @@ hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_p
                              int prec, int B, int tdim, int edim, hipStream_t s) {
   const size_t lds = (size_t)(tdim + edim + 256) * sizeof(float);
   if ((edim & 63) || (tdim & 3) || (edim & 15)) return hipErrorInvalidValue;
-  if (prec == PREC_BF16)
-    hipLaunchKernelGGL(time_embed_kernel<bf16_t>, dim3(B, edim / 64), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (bf16_t*)emb_act_op, tdim, edim);
-  else
-    hipLaunchKernelGGL(time_embed_kernel<float>, dim3(B, edim / 64), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride, w1t, b1, w2t, b2, aug, emb, (float*)emb_act_op, tdim, edim);
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(time_embed_kernel<TMX>, dim3(B, edim / 64), dim3(256), lds, s, t_ptr, t_stride, step_ptr, coef_stride,
+                                         w1t, b1, w2t, b2, aug, emb, (TMX*)emb_act_op, tdim, edim));
   return hipGetLastError();
 }
 hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s) {
   dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
-  if (prec == PREC_BF16) hipLaunchKernelGGL(nct_to_btc_kernel<bf16_t>, grid, dim3(256), 0, s, src, C, T, dst_f32, (bf16_t*)dst_op, ldd, cpad);
-  else hipLaunchKernelGGL(nct_to_btc_kernel<float>, grid, dim3(256), 0, s, src, C, T, dst_f32, (float*)dst_op, ldd, cpad);
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(nct_to_btc_kernel<TMX>, grid, dim3(256), 0, s, src, C, T, dst_f32, (TMX*)dst_op, ldd, cpad));
   return hipGetLastError();
 }
 hipError_t launch_btc_to_nct(const float* src, int lds_, int C, int T, int B, float* dst, hipStream_t s) {
@@ -620,10 +622,8 @@ hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoe
   if (n & 3) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-  if (prec == PREC_BF16)
-    hipLaunchKernelGGL(solver_update_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, (bf16_t*)xe_op, xbar, d1, mprev, n4);
-  else
-    hipLaunchKernelGGL(solver_update_kernel<float>, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, (float*)xe_op, xbar, d1, mprev, n4);
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(solver_update_kernel<TMX>, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, (TMX*)xe_op,
+                                         xbar, d1, mprev, n4));
   return hipGetLastError();
 }
 hipError_t launch_step_advance(int* step_ptr, hipStream_t s) {

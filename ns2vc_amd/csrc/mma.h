@@ -1,10 +1,10 @@
-// MFMA / LDS-DMA helpers shared by the GEMM and the fused row-chain kernels (gfx950).
+// MFMA / LDS-DMA helpers of the GEMM kernels (gfx950).
 #pragma once
 #include "common.h"
 
 namespace ns2vc {
 
-static __device__ uint4 g_zero_page[8];     // 128 B of zeros: source of padded / out-of-range rows (one copy per TU)
+
 
 template <typename T> struct MmaT;
 template <> struct MmaT<float> {
@@ -23,6 +23,16 @@ template <> struct MmaT<bf16_t> {
     U ua, ub;
     ua.u = a; ub.u = b;
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.v, ub.v, acc, 0, 0, 0);
+  }
+};
+
+template <> struct MmaT<f16_t> {
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ void mma(f32x16_t& acc, const u32x4_t& a, const u32x4_t& b) {
+    union U { u32x4_t u; f16x8_t v; };
+    U ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua.v, ub.v, acc, 0, 0, 0);
   }
 };
 

@@ -12,11 +12,14 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import Ns2vcError, PREC_BF16, PREC_F32, check
+from ._lib import Ns2vcError, PREC_BF16, PREC_F16, PREC_F32, check
 from .schedule import NCOEF, SolverTable, build_table
 from .spec import UNetConfig, param_spec
 
-PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}
+# operand precision of the MFMAs (include/ns2vc_hip.h): fp16 is the default 16-bit mode -- same speed and bytes as bf16,
+# 8e-4 end-to-end error (inside the 1e-3 parity gate) instead of 6.5e-3
+PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
+DEFAULT_PRECISION = "fp16"
 
 
 class DevBuf:
@@ -150,7 +153,7 @@ def device_count() -> int:
 class Engine:
     """One denoiser instance: weights + workspace for a (B, T, Lp) shape."""
 
-    def __init__(self, cfg: UNetConfig = UNetConfig(), precision: str = "bf16"):
+    def __init__(self, cfg: UNetConfig = UNetConfig(), precision: str = DEFAULT_PRECISION):
         cfg.validate()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(PRECISIONS)}")
@@ -174,6 +177,7 @@ class Engine:
         self.shape: Optional[Tuple[int, int, int]] = None
         self.table: Optional[SolverTable] = None
         self._weights_ready = False
+        self._debug = False
 
     # -- weights ----------------------------------------------------------------
     def load_state_dict(self, state: Dict[str, object], strict: bool = True) -> None:
@@ -213,7 +217,23 @@ class Engine:
 
     # -- workspace ----------------------------------------------------------------
     def set_debug(self, enable: bool) -> None:
+        """Keep a copy of every block output (``taps()``).  Changing it drops the plan: call ``prepare`` afterwards."""
         check(self.lib.ns2vc_unet_set_debug(self.h, int(enable)), "set_debug")
+        if bool(enable) != self._debug:
+            self._debug = bool(enable)
+            self.shape = None
+
+    def set_option(self, name: str, value: bool) -> None:
+        """Plan options ("ln_linear", "fold_ff"; include/ns2vc_hip.h).  Changing one drops the plan: ``prepare`` again."""
+        check(self.lib.ns2vc_unet_set_option(self.h, name.encode(), int(value)), f"set_option({name})")
+        self.shape = None
+
+    def ln_ratio(self) -> float:
+        """max |mean| / std over all LayerNorm input rows since the last call (synchronises).  The 16-bit modes' error on a
+        LayerNorm row grows with it under the default "ln_linear" plan; see ``Denoiser`` for the automatic guard."""
+        r = C.c_float()
+        check(self.lib.ns2vc_unet_ln_ratio(self.h, C.byref(r)), "ln_ratio")
+        return float(r.value)
 
     def prepare(self, B: int, T: int, Lp: int) -> None:
         check(self.lib.ns2vc_unet_prepare(self.h, B, T, Lp), "ns2vc_unet_prepare")
@@ -233,6 +253,18 @@ class Engine:
     def set_condition(self, content, prompt, mask=None, stream=None) -> None:
         """content (B,256,T) fp32, prompt (B,Lp,256) fp32, mask (B,Lp) uint8/bool or None — all on the GPU."""
         check(self.lib.ns2vc_unet_set_condition(self.h, _ptr(content), _ptr(prompt), _ptr(mask), _stream_ptr(stream)), "set_condition")
+
+    def set_content(self, content, stream=None) -> None:
+        """only the content half of set_condition (the content part of conv_in)"""
+        check(self.lib.ns2vc_unet_set_content(self.h, _ptr(content), _stream_ptr(stream)), "set_content")
+
+    def set_prompt(self, prompt, mask=None, stream=None) -> None:
+        """only the prompt half of set_condition (cross-attention K/V, add_embedding, mask bias)"""
+        check(self.lib.ns2vc_unet_set_prompt(self.h, _ptr(prompt), _ptr(mask), _stream_ptr(stream)), "set_prompt")
+
+    def set_mask(self, mask=None, stream=None) -> None:
+        """only the keep-mask -> additive-bias conversion (None = no mask)"""
+        check(self.lib.ns2vc_unet_set_mask(self.h, _ptr(mask), _stream_ptr(stream)), "set_mask")
 
     def forward(self, x, t, out, stream=None) -> None:
         """x (B,100,T), t (B,) fp32, out (B,100,T): one denoiser evaluation."""

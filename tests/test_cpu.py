@@ -214,6 +214,50 @@ def test_table_argument_errors():
     assert S.build_table("dpmsolver++", 1, order=1).coef.shape == (1, S.NCOEF)
 
 
+# ---- round-2 goldens (tests/golden/make_golden_v2.py): oracle and the PyTorch conditioning module vs the reference ----
+def test_oracle_reproduces_golden_v2_forwards():
+    """The oracle at the BASELINE lengths (10 s full output; 30 s windows + sums) against the reference's outputs."""
+    import torch
+    from ns2vc_amd.spec import UNetConfig
+    from ns2vc_amd.weights import hash_normal, procedural_state_dict
+    from oracle import unet_ref
+    from util import g7_summary
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+    cfg = UNetConfig()
+    P = {k: torch.from_numpy(v) for k, v in procedural_state_dict(cfg, 0).items()}
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    for tag, T in (("g6", 938), ("g7", 2813)):
+        x = torch.from_numpy(hash_normal(f"{tag}.x", (1, cfg.latent_channels, T)))
+        content = torch.from_numpy(hash_normal(f"{tag}.content", (1, cfg.content_channels, T)))
+        prompt = torch.from_numpy(hash_normal(f"{tag}.prompt", (1, 469, cfg.cross_attention_dim)))
+        mask = torch.arange(469)[None, :] < torch.from_numpy(g[f"{tag}.prompt_len"])[:, None]
+        y = unet_ref.denoiser(P, cfg, x, content, prompt, mask, torch.from_numpy(g[f"{tag}.t"])).numpy()
+        if tag == "g6":
+            assert rel_l2(y, g["g6.y"]) < 2e-6
+        else:
+            got = g7_summary(y)
+            for k in ("head", "mid", "tail", "chan_sum", "chan_sq", "frame_sum", "frame_sq"):
+                assert rel_l2(got[k], g[f"g7.{k}"]) < 2e-6, k
+
+
+def test_text_time_embedding_matches_reference_golden():
+    """unet1d.embeddings.TextTimeEmbedding (imported by the reference's model.py:6 for Pre_model.ref_enc, model.py:340:
+    TextTimeEmbedding(100, 100, 1)) against outputs of the reference's own class on the same procedural parameters."""
+    import torch
+    from unet1d.embeddings import TextTimeEmbedding
+    from ns2vc_amd.weights import hash_normal
+    from util import tte_state
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+    for tag in ("g8.ref_enc", "g8.h64"):
+        dim, odim, heads, L = (int(v) for v in g[f"{tag}.shape"])
+        m = TextTimeEmbedding(dim, odim, heads).eval()
+        m.load_state_dict(tte_state(tag, dim, odim), strict=True)       # reference parameter names load strict
+        with torch.no_grad():
+            y = m(torch.from_numpy(hash_normal(tag + ".x", (2, L, dim)))).numpy()
+        assert y.shape == g[f"{tag}.y"].shape
+        assert rel_l2(y, g[f"{tag}.y"]) < 1e-5, tag
+
+
 # ---- C ABI ------------------------------------------------------------------------------
 def test_cabi_library_exports_every_declared_symbol():
     from ns2vc_amd import _lib
@@ -224,7 +268,31 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ns2vc_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.ns2vc_abi_version() == 1
+    assert lib.ns2vc_abi_version() == _lib.ABI_VERSION == 2
+
+
+def test_host_operand_rounding_matches_ieee():
+    """The weight-packing conversions (csrc/common.h f32_to_f16_bits / f32_to_bf16_bits) against numpy's IEEE binary16
+    and the bit-level bf16 reference: random values over the whole exponent range, subnormals, ties, overflow, inf/nan."""
+    import ctypes as C
+    from ns2vc_amd import _lib
+    from util import bf16_round, f16_round
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(200000) * np.exp2(rng.integers(-30, 18, 200000))).astype(np.float32)
+    edge = np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e9, -1e9, np.inf, -np.inf, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8, 2.99e-8, 1e-9,
+                     1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 1.0 + 2.0 ** -8, 1.0 + 3 * 2.0 ** -8, 2.0 ** -14, 2.0 ** -24 * 1.5], dtype=np.float32)
+    x = np.concatenate([x, edge, -edge])
+    for prec, ref in ((2, f16_round), (1, bf16_round), (0, lambda a: a)):
+        out = np.empty_like(x)
+        assert lib.ns2vc_round_to_operand(x.ctypes.data_as(C.c_void_p), x.size, prec, out.ctypes.data_as(C.c_void_p)) == 0
+        want = ref(x)
+        assert np.array_equal(out.view(np.uint32), want.view(np.uint32)), (prec, x[out.view(np.uint32) != want.view(np.uint32)][:8])
+    nan = np.array([np.nan], dtype=np.float32)
+    out = np.empty_like(nan)
+    for prec in (1, 2):
+        lib.ns2vc_round_to_operand(nan.ctypes.data_as(C.c_void_p), 1, prec, out.ctypes.data_as(C.c_void_p))
+        assert np.isnan(out[0])
 
 
 def test_no_cpu_fallback_engine_fails_loudly_without_gpu():
@@ -264,6 +332,11 @@ full = torch.arange(n * 2 * 3, dtype=torch.float32).reshape(n, 2, 3)
 lo, hi = shard_range(n, rank, world)
 out = gather_latents(full[lo:hi] * 1.0, n)
 assert torch.equal(out, full), (rank, out)
+one = full[:1]                          # fewer items than ranks: rank 1's shard is EMPTY but it still joins the collective
+lo, hi = shard_range(1, rank, world)
+assert (hi - lo) == (1 if rank == 0 else 0)
+out = gather_latents(one[lo:hi] * 1.0, 1)
+assert torch.equal(out, one), (rank, out)
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

@@ -53,10 +53,59 @@ def test_dropin_module_forward_matches_reference_golden(state, diag):
     assert abs(float((out2 - out.sample).mean()) - 1.0) < 1e-3
 
 
+def test_dropin_module_reference_call_pattern(state, diag):
+    """The reference's solver loop as model.py:403-415 drives the module: a fresh cat([x, content]) and a fresh mask tensor
+    on every step, the SAME prompt storage (a permuted view), float32 fractional timesteps from the samplers and int64
+    ones from training / DDIM (model.py:580,714), fp16 inputs under autocast.  The prompt-side hoisting must run once per
+    prompt, results must equal a cold module's, and the default 16-bit precision must stay inside the parity bar."""
+    import torch
+    from unet1d import UNet1DConditionModel
+    gold = np.load(GOLD)
+    kw = dict(in_channels=356, out_channels=100, block_out_channels=(128, 256, 384, 512), norm_num_groups=8, cross_attention_dim=256,
+              attention_head_dim=8, addition_embed_type="text", resnet_time_scale_shift="scale_shift")
+    m = UNet1DConditionModel(engine_precision="fp16", **kw)
+    m.load_state_dict(state, strict=True)
+    m = m.cuda().eval()
+    x, content, prompt = _inputs("g3b", 2, 37, 21)
+    prompt_tbc = prompt.permute(1, 0, 2).contiguous()          # the reference keeps (Lp, B, C) and permutes per call (model.py:407)
+    lens = torch.tensor([21, 13]).cuda()
+    outs = []
+    with torch.no_grad():
+        for step in range(4):
+            mask = torch.arange(21, device="cuda")[None, :] < lens[:, None]          # rebuilt per call (model.py:412)
+            sample = torch.cat([x + 0.01 * step, content], dim=1)                    # rebuilt per call (model.py:409)
+            outs.append(m(sample, torch.tensor([499.50003, 499.50003]).cuda(), prompt_tbc.permute(1, 0, 2), encoder_attention_mask=mask).sample)
+    assert m.prompt_hoists == 1, m.prompt_hoists
+    e = rel_l2(outs[0].cpu().numpy(), gold["g3b.y"])
+    diag(f"drop-in nn.Module, reference call pattern (fp16 engine): step 0 vs golden {e:.3e}; prompt hoisted {m.prompt_hoists}x in 4 calls")
+    assert e < 1e-3
+    with torch.no_grad():                                      # cached result == a cold module on the step-3 input
+        cold = UNet1DConditionModel(engine_precision="fp16", **kw)
+        cold.load_state_dict(state, strict=True)
+        cold = cold.cuda().eval()
+        mask = torch.arange(21, device="cuda")[None, :] < lens[:, None]
+        y_cold = cold(torch.cat([x + 0.03, content], dim=1), torch.tensor([499.50003, 499.50003]).cuda(), prompt, encoder_attention_mask=mask).sample
+        assert torch.equal(y_cold, outs[3])
+        # a modified prompt (in place: version bump) and a different mask are both picked up
+        prompt_tbc.mul_(1.0)
+        y5 = m(torch.cat([x, content], dim=1), torch.tensor([499.50003, 499.50003]).cuda(), prompt_tbc.permute(1, 0, 2), encoder_attention_mask=mask).sample
+        assert m.prompt_hoists == 2 and torch.equal(y5, outs[0])
+        mask2 = torch.ones_like(mask)
+        y6 = m(torch.cat([x, content], dim=1), torch.tensor([499.50003, 499.50003]).cuda(), prompt_tbc.permute(1, 0, 2), encoder_attention_mask=mask2).sample
+        assert m.prompt_hoists == 2 and not torch.equal(y6, y5)
+        # int64 timesteps (training / DDIM) and half-precision inputs
+        yi = m(torch.cat([x, content], dim=1), torch.tensor([3, 3], dtype=torch.int64).cuda(), prompt, encoder_attention_mask=mask).sample
+        yf = m(torch.cat([x, content], dim=1), torch.tensor([3.0, 3.0]).cuda(), prompt, encoder_attention_mask=mask).sample
+        assert torch.equal(yi, yf)
+        yh = m(torch.cat([x, content], dim=1).half(), 3, prompt.half(), encoder_attention_mask=mask).sample
+        assert yh.dtype == torch.float16 and rel_l2(yh.float().cpu().numpy(), yf.cpu().numpy()) < 5e-3
+
+
 def test_pipeline_sampler_matches_reference_golden(state, diag):
     import torch
     from ns2vc_amd.pipeline import Denoiser
     gold = np.load(GOLD)
+    assert Denoiser.__init__.__defaults__[1] == "fp16"      # the default precision is the 16-bit mode that meets the parity bar
     d = Denoiser(state, precision="fp32")
     for tag, solver, steps, B in (("unipc6_b2", "unipc", 6, 2), ("dpm6_b3", "dpmsolver++", 6, 3)):
         xT, content, prompt = _inputs(f"g5.{tag}", B, 188, 469)
@@ -67,6 +116,43 @@ def test_pipeline_sampler_matches_reference_golden(state, diag):
         assert e < 1e-3
     y1 = d.denoise(xT, torch.full((3,), 666.0).cuda(), content, prompt, mask)
     assert y1.shape == xT.shape and bool(torch.isfinite(y1).all())
+    d16 = Denoiser(state)                                     # default precision (fp16), LayerNorm guard on
+    y = d16.sample(content, prompt, mask, noise=xT, solver="dpmsolver++", steps=6)
+    e = rel_l2(y.cpu().numpy(), gold["g5.dpm6_b3.y"])
+    diag(f"pipeline.Denoiser.sample dpm6_b3, default precision {d16.engine.precision}: {e:.3e}; LayerNorm |mean|/std max {d16.ln_ratio_seen:.2f}")
+    assert e < 1e-3 and d16.ln_ratio_seen is not None and d16.ln_ratio_seen < 8.0
+
+
+def test_pipeline_layernorm_guard_switches_plan(state, diag):
+    """the 16-bit LayerNorm-by-linearity plan loses accuracy on rows with |mean| >> std.  A checkpoint whose
+    proj_in biases put a large common offset on every token triggers the Denoiser's first-call guard: the plan switches
+    to explicit LayerNorm passes, which removes the LayerNorm consumers' share of the error.  (What remains is inherent to
+    ANY 16-bit operand: proj_out reads y itself, offset included -- the reference under fp16 autocast has it too; the
+    kernel-level comparison of the two LayerNorm plans is tests/test_kernels_gpu.py::test_layernorm_plans_vs_row_offset.)"""
+    import torch
+    import warnings
+    from ns2vc_amd.pipeline import Denoiser
+    from oracle import unet_ref
+    from ns2vc_amd.spec import UNetConfig
+    bad = {k: v.clone() for k, v in state.items()}
+    for k in bad:
+        if k.endswith(".proj_in.bias"):
+            bad[k] = bad[k] + 24.0                      # every token of every transformer block: mean 24, std ~1
+    B, T, Lp = 1, 64, 16
+    x, content, prompt = _inputs("lnguard", B, T, Lp)
+    t = torch.full((B,), 500.0).cuda()
+    ref = unet_ref.denoiser({k: v for k, v in bad.items()}, UNetConfig(), x.cpu(), content.cpu(), prompt.cpu(), None, t.cpu()).numpy()
+    errs = {}
+    for guard in (None, 8.0):
+        d = Denoiser(bad, precision="fp16", ln_guard=guard)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            y = d.denoise(x, t, content, prompt, None)
+        errs[guard] = rel_l2(y.cpu().numpy(), ref)
+        if guard is not None:
+            assert d.ln_ratio_seen > 8.0 and any("ln_linear" in str(i.message) for i in w)
+    diag(f"LayerNorm guard, offset-24 checkpoint (fp16): unguarded {errs[None]:.3e}, guarded (explicit LayerNorm) {errs[8.0]:.3e}")
+    assert errs[8.0] < 0.9 * errs[None]
 
 
 def test_overlapped_pipeline_matches_sequential(diag):
@@ -77,7 +163,7 @@ def test_overlapped_pipeline_matches_sequential(diag):
     from ns2vc_amd.pipeline import Denoiser, OverlappedPipeline
     from ns2vc_amd.weights import procedural_state_dict
     dev = torch.device("cuda", 0)
-    den = Denoiser(procedural_state_dict(seed=0), precision="bf16")
+    den = Denoiser(procedural_state_dict(seed=0))
     B, T, Lp = 2, 188, 64
     Wpre = torch.randn(256, 256, device=dev) / 16.0
     Wpost = torch.randn(100, 100, device=dev) / 10.0

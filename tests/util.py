@@ -17,6 +17,12 @@ def bf16_round(a: np.ndarray) -> np.ndarray:
     return u.astype(np.uint32).view(np.float32).reshape(a.shape)
 
 
+def f16_round(a: np.ndarray) -> np.ndarray:
+    """round-to-nearest-even to IEEE binary16 (overflow -> inf), returned as float32"""
+    with np.errstate(over="ignore"):
+        return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
 def silu(x):
     return x / (1.0 + np.exp(-x))
 
@@ -45,3 +51,28 @@ def gather_rows(a: np.ndarray, B: int, Tin: int, Tout: int, taps: int, tmode: in
             if ok:
                 out[:, t, tap, :] = a[:, tt, :]
     return out
+
+
+# ---- shared with tests/golden/make_golden_v2.py (the generator and the tests must build identical data) ----
+def g7_summary(y: np.ndarray) -> dict:
+    """what is stored of a (1, 100, 2813) output instead of its 1.1 MB"""
+    T = y.shape[-1]
+    mid = (T // 2) // 64 * 64
+    return {"head": y[:, :, :256].copy(), "mid": y[:, :, mid:mid + 256].copy(), "tail": y[:, :, T - 256:].copy(), "mid_start": np.array([mid]),
+            "chan_sum": y.astype(np.float64).sum(-1), "chan_sq": (y.astype(np.float64) ** 2).sum(-1),
+            "frame_sum": y.astype(np.float64).sum(1), "frame_sq": (y.astype(np.float64) ** 2).sum(1)}
+
+
+def tte_state(prefix: str, dim: int, out_dim: int) -> dict:
+    """procedural parameters of a TextTimeEmbedding(dim, out_dim, heads), reference parameter names (torch tensors)"""
+    import torch
+    from ns2vc_amd.weights import hash_normal
+    s = dim ** -0.5
+    sd = {"norm1.weight": 1.0 + 0.1 * hash_normal(prefix + "n1w", (dim,)), "norm1.bias": 0.1 * hash_normal(prefix + "n1b", (dim,)),
+          "pool.positional_embedding": s * hash_normal(prefix + "pos", (1, dim)),
+          "proj.weight": s * hash_normal(prefix + "pw", (out_dim, dim)), "proj.bias": 0.1 * hash_normal(prefix + "pb", (out_dim,)),
+          "norm2.weight": 1.0 + 0.1 * hash_normal(prefix + "n2w", (out_dim,)), "norm2.bias": 0.1 * hash_normal(prefix + "n2b", (out_dim,))}
+    for p in ("k_proj", "q_proj", "v_proj"):
+        sd[f"pool.{p}.weight"] = s * hash_normal(prefix + p + "w", (dim, dim))
+        sd[f"pool.{p}.bias"] = 0.1 * hash_normal(prefix + p + "b", (dim,))
+    return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items()}

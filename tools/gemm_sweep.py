@@ -20,11 +20,11 @@ from ns2vc_amd import _lib                     # noqa: E402
 from ns2vc_amd._lib import GemmArgs, check     # noqa: E402
 from ns2vc_amd.engine import DevBuf, Event, Stream  # noqa: E402
 
-# stages == 1 selects the register-staged kernel (gemm3_kernel); 2..4 = global_load_lds ring depth (gemm2_kernel)
-# (BM, BN, stages | flags << 8); stages 1 = register-staged kernel; flags: 1 = K rotation, 2 = loads only, 4 = no steady-state loads
-CONFIGS = [(128, 128, 12), (128, 128, 13), (128, 128, 14), (64, 128, 12), (64, 128, 13), (64, 128, 14), (128, 128, 2), (64, 128, 2), (64, 128, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
+# (BM, BN, stages | flags << 8); stages 2..4 = LDS-DMA ring depth of the 4-wave kernel (gemm2_kernel), 12 / 13 = the 8-wave
+# K-split kernel (gemm4_kernel) with ring 2 / 3; flags (gemm2 only): 1 = K rotation, 2 = loads only, 4 = no steady-state loads
+CONFIGS = [(128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13), (128, 128, 2), (64, 128, 2), (64, 128, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
 ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 1024), (64, 128, 3 | 512), (64, 64, 2 | 256), (64, 64, 2 | 512), (64, 64, 2 | 1024),
-          (128, 128, 2 | 256), (128, 128, 2 | 512), (128, 128, 2 | 1024), (128, 128, 3 | 512)]
+          (128, 128, 2 | 256), (128, 128, 2 | 512), (128, 128, 2 | 1024)]
 
 
 def shapes(B=32, T=938):
@@ -47,15 +47,15 @@ def shapes(B=32, T=938):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--prec", default="bf16")
+    ap.add_argument("--prec", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--ablate", action="store_true", help="time the ABLATE list (K rotation / loads-only / compute-only variants)")
     a = ap.parse_args()
     global CONFIGS
     if a.ablate:
         CONFIGS = ABLATE
-    prec = 1 if a.prec == "bf16" else 0
-    esz = 2 if prec else 4
+    prec = {"fp32": 0, "bf16": 1, "fp16": 2}[a.prec]
+    esz = 4 if prec == 0 else 2
     lib = _lib.load()
     st = Stream()
     rng = np.random.default_rng(0)

@@ -10,9 +10,16 @@ Boundary kept:
 
 The forward itself is NOT PyTorch: it hands device pointers to libns2vc_hip.so.
 There is no CPU path and no autograd path — both raise.  The fast path for sampling
-is ``ns2vc_amd.pipeline.Denoiser`` (captured loop, condition hoisted once); this
-class re-derives the step-invariant condition work on every call because the
-reference API concatenates x and content into one ``sample`` tensor per call.
+is ``ns2vc_amd.pipeline.Denoiser`` (captured loop, condition hoisted once).  Here the
+reference API concatenates x and content into a NEW ``sample`` tensor on every solver
+step (``model.py:409``), so the content half of conv_in is redone per call, but the
+prompt-side hoisting (all 32 cross-attention K/V projections, ``add_embedding``: 92 %
+of the step-invariant FLOPs) is cached for as long as the caller keeps passing the same
+prompt storage unmodified (``(data_ptr, _version, shape, stride)``; the keyed tensor is
+kept alive, so its address cannot be recycled by the allocator while it is the key);
+the tiny mask -> bias conversion is refreshed on every call.
+Engine precision: ``engine_precision=`` / env ``NS2VC_PRECISION`` (fp32 | fp16 | bf16;
+default fp32, the reference's arithmetic).
 """
 from __future__ import annotations
 
@@ -91,10 +98,24 @@ class UNet1DConditionModel(nn.Module):
         self._engine = None
         self._engine_key = None
         self._engine_shape = None
+        self._plist = None              # flat parameter list (the key walk is per call: keep it a list comprehension)
+        self._prompt_key = None         # ((data_ptr, _version, shape) of prompt and mask) the engine's prompt half was built from
+        self._prompt_hold = None        # ... and the tensors themselves: while they live their storage cannot be re-used
+        self.prompt_hoists = 0          # how often the prompt half of the condition was (re)computed: tests / diagnostics
 
     # ---------------------------------------------------------------------------------
     def _weights_key(self):
-        return (self.engine_precision,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._plist is None or len(self._plist) != len(self._parameters_flat()):
+            self._plist = self._parameters_flat()
+        return (self.engine_precision, tuple([(p.data_ptr(), p._version) for p in self._plist]))
+
+    def _parameters_flat(self):
+        return list(self.parameters())
+
+    def _apply(self, fn, *a, **kw):      # .to() / .cuda() / .half() may replace parameter storage
+        self._plist = None
+        self._prompt_key = self._prompt_hold = None
+        return super()._apply(fn, *a, **kw)
 
     def _get_engine(self):
         from ns2vc_amd.engine import Engine
@@ -105,6 +126,7 @@ class UNet1DConditionModel(nn.Module):
             self._engine.load_state_dict({k: v for k, v in self.state_dict().items()})
             self._engine_key = key
             self._engine_shape = None
+            self._prompt_key = self._prompt_hold = None
         return self._engine
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], encoder_hidden_states: torch.Tensor,
@@ -132,22 +154,34 @@ class UNet1DConditionModel(nn.Module):
         ts = timestep
         if not torch.is_tensor(ts):
             ts = torch.tensor([float(ts)], dtype=torch.float32, device=dev)
-        ts = ts.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        ts = ts.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()     # int64 (training / DDIM, model.py:580,714) or float
         x = sample[:, :cfg.latent_channels].to(torch.float32).contiguous()
         content = sample[:, cfg.latent_channels:].to(torch.float32).contiguous()
         prompt = encoder_hidden_states.to(torch.float32).contiguous()
         mask = None
         if encoder_attention_mask is not None:
             mask = encoder_attention_mask.to(device=dev).reshape(B, Lp).to(torch.uint8).contiguous()
-        eng = self._get_engine()
-        if self._engine_shape != (B, T, Lp):
-            torch.cuda.synchronize(dev)
-            eng.prepare(B, T, Lp)
-            self._engine_shape = (B, T, Lp)
-        out = torch.empty((B, cfg.out_channels, T), dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev)
-        eng.set_condition(content, prompt, mask, stream=stream)
-        eng.forward(x, ts, out, stream=stream)
+        with torch.cuda.device(dev):     # engine creation / weights / workspace / launches all bind to the tensors' device
+            eng = self._get_engine()
+            if self._engine_shape != (B, T, Lp):
+                torch.cuda.synchronize(dev)
+                eng.prepare(B, T, Lp)
+                self._engine_shape = (B, T, Lp)
+                self._prompt_key = self._prompt_hold = None
+            out = torch.empty((B, cfg.out_channels, T), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev)
+
+            ehs = encoder_hidden_states
+            pkey = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), tuple(ehs.stride()), ehs.dtype, stream.cuda_stream)
+            if pkey != self._prompt_key:
+                eng.set_prompt(prompt, mask, stream=stream)
+                self._prompt_key = pkey
+                self._prompt_hold = ehs          # alive => its address cannot be handed to another tensor while it is the key
+                self.prompt_hoists += 1
+            else:                                # the reference rebuilds the (tiny) mask per call (model.py:412): always refresh it
+                eng.set_mask(mask, stream=stream)
+            eng.set_content(content, stream=stream)
+            eng.forward(x, ts, out, stream=stream)
         out = out.to(sample.dtype)
         if not return_dict:
             return (out,)
