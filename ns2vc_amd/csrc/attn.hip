@@ -117,6 +117,7 @@ template <> __device__ __forceinline__ f16_t op_from_float<f16_t>(float x) { f16
 //     that build the numerator): no per-score add, no separate running sum.
 template <typename TM, int HD>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
+  op_mode_init<TM>();
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
   constexpr int NS = HD * SZ / 32;        // 32-B d-slabs per key row (QK^T k-steps), + 1 aux slab

@@ -78,9 +78,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-// fp16 (IEEE binary16, round to nearest even).  pack_f16x2 is the plain conversion (inf / -inf pass through: the
-// attention mask relies on that); pack_f16x2_sat clamps to the largest finite half first, so an activation outlier
-// beyond 65504 saturates instead of turning a whole row into inf/NaN (bf16 has the fp32 range and needs no clamp).
+// fp16 (IEEE binary16, round to nearest even; v_cvt_pk_f16_f32 on gfx950).  Overflow: every kernel that produces fp16
+// operands starts with op_mode_init<f16_t>(), which sets MODE.FP16_OVFL -- finite values beyond +-65504 then convert to
+// +-65504 instead of +-inf (an activation outlier saturates instead of turning whole rows into inf/NaN downstream), while
+// +-inf inputs stay inf (the attention mask's -inf for tail keys relies on that).  Checked on MI355X by
+// tools/fp16_ovfl_probe.hip; costs nothing per element (an explicit v_med3 clamp cost 1.7 % of the step).
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
@@ -89,31 +91,30 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
   r.h = __builtin_convertvector(v, f16x2_t);
   return r.u;
 }
-__device__ __forceinline__ float f16_sat(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
-__device__ __forceinline__ uint32_t pack_f16x2_sat(float lo, float hi) { return pack_f16x2(f16_sat(lo), f16_sat(hi)); }
 __device__ __forceinline__ float f16_lo(uint32_t u) { union { uint32_t u; f16x2_t h; } r; r.u = u; return (float)r.h[0]; }
 __device__ __forceinline__ float f16_hi(uint32_t u) { union { uint32_t u; f16x2_t h; } r; r.u = u; return (float)r.h[1]; }
 
 // one interface over the two 16-bit operand types (TM = bf16_t | f16_t): two floats <-> one packed dword
 template <typename TM> struct Op16;
 template <> struct Op16<bf16_t> {
-  __device__ static __forceinline__ uint32_t pack(float lo, float hi) { return pack_bf16x2(lo, hi); }        // plain (inf passes)
-  __device__ static __forceinline__ uint32_t pack_sat(float lo, float hi) { return pack_bf16x2(lo, hi); }    // (fp32 range: nothing to clamp)
+  __device__ static __forceinline__ uint32_t pack(float lo, float hi) { return pack_bf16x2(lo, hi); }
   __device__ static __forceinline__ float lo(uint32_t u) { return bf16_lo(u); }
   __device__ static __forceinline__ float hi(uint32_t u) { return bf16_hi(u); }
 };
 template <> struct Op16<f16_t> {
   __device__ static __forceinline__ uint32_t pack(float lo, float hi) { return pack_f16x2(lo, hi); }
-  __device__ static __forceinline__ uint32_t pack_sat(float lo, float hi) { return pack_f16x2_sat(lo, hi); }
   __device__ static __forceinline__ float lo(uint32_t u) { return f16_lo(u); }
   __device__ static __forceinline__ float hi(uint32_t u) { return f16_hi(u); }
 };
+// per-kernel setup of the operand type: fp16 -> MODE.FP16_OVFL = 1 (hwreg(HW_REG_MODE, offset 23, size 1)), see above
+template <typename TM> __device__ __forceinline__ void op_mode_init() {}
+template <> __device__ __forceinline__ void op_mode_init<f16_t>() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
 
 // operand-typed scalar / 4-vector stores and loads (TM = float or bf16_t)
 template <typename TM> __device__ __forceinline__ void store_op(TM* p, float v);
 template <> __device__ __forceinline__ void store_op<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_op<bf16_t>(bf16_t* p, float v) { p->v = (uint16_t)pack_bf16x2(v, 0.f); }
-template <> __device__ __forceinline__ void store_op<f16_t>(f16_t* p, float v) { p->v = (uint16_t)pack_f16x2_sat(v, 0.f); }
+template <> __device__ __forceinline__ void store_op<f16_t>(f16_t* p, float v) { p->v = (uint16_t)pack_f16x2(v, 0.f); }
 template <typename TM> __device__ __forceinline__ void store_op4(TM* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store_op4<float>(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -122,7 +123,7 @@ template <> __device__ __forceinline__ void store_op4<bf16_t>(bf16_t* p, float a
   *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
 template <> __device__ __forceinline__ void store_op4<f16_t>(f16_t* p, float a, float b, float c, float d) {
-  *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2_sat(a, b), pack_f16x2_sat(c, d));
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack_f16x2(a, b), pack_f16x2(c, d));
 }
 // Result stores of the big producers (GEMM epilogues, norm outputs).  NS2VC_WT_STORES=1 (default) issues them
 // write-through (sc1): the bytes leave during the kernel instead of as an L2 write-back at the kernel boundary
@@ -157,11 +158,11 @@ __device__ __forceinline__ void out_f4(float* p, float a, float b, float c, floa
 template <typename TM> __device__ __forceinline__ void out_op4(TM* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void out_op4<float>(float* p, float a, float b, float c, float d) { out_f4(p, a, b, c, d); }
 template <> __device__ __forceinline__ void out_op4<bf16_t>(bf16_t* p, float a, float b, float c, float d) { out_store8(p, pack_bf16x2(a, b), pack_bf16x2(c, d)); }
-template <> __device__ __forceinline__ void out_op4<f16_t>(f16_t* p, float a, float b, float c, float d) { out_store8(p, pack_f16x2_sat(a, b), pack_f16x2_sat(c, d)); }
+template <> __device__ __forceinline__ void out_op4<f16_t>(f16_t* p, float a, float b, float c, float d) { out_store8(p, pack_f16x2(a, b), pack_f16x2(c, d)); }
 template <typename TM> __device__ __forceinline__ void store_op2(TM* p, float a, float b);
 template <> __device__ __forceinline__ void store_op2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
 template <> __device__ __forceinline__ void store_op2<bf16_t>(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf16x2(a, b); }
-template <> __device__ __forceinline__ void store_op2<f16_t>(f16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_f16x2_sat(a, b); }
+template <> __device__ __forceinline__ void store_op2<f16_t>(f16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_f16x2(a, b); }
 #endif
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

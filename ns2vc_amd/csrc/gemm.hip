@@ -245,6 +245,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16_t (&acc)
 
 template <typename TM, int BM, int BN, int STAGES, bool LNC>
 __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int flags) {
+  op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
@@ -592,6 +593,7 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 // ---------------------------------------------------------------------------
 template <typename TM, int BM, int BN, int STAGES, bool LNC>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
+  op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;

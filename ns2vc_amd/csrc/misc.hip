@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ temb, int ldtemb, int temb_off, int silu,
                                                        TM* __restrict__ out, TM* __restrict__ raw, int rows) {
+  op_mode_init<TM>();
   __shared__ float s_mean[8], s_rstd[8];
   const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
   const int C = c0 + c1, nq = C >> 2, Cg = C / G;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 template <typename TM, int NP>      // NP = float2 pairs per lane = C / 128
 __global__ __launch_bounds__(256) void ln_apply_op_kernel(const float* __restrict__ x, int ldx, int M, int C, float eps,
                                                           TM* __restrict__ out) {
+  op_mode_init<TM>();
   constexpr int R = 4;                          // rows per wave: 4 independent load streams / reduction chains
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(256) void ln_apply_op_kernel(const float* __restric
 
 template <typename TM>
 __global__ __launch_bounds__(256) void cast_op_kernel(const float* __restrict__ x, size_t n4, TM* __restrict__ out) {
+  op_mode_init<TM>();
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     store_op4<TM>(out + 4 * i, v.x, v.y, v.z, v.w);
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
                                                          const float* __restrict__ w2t, const float* __restrict__ b2,
                                                          const float* __restrict__ aug, float* __restrict__ emb,
                                                          TM* __restrict__ emb_act, int tdim, int edim) {
+  op_mode_init<TM>();
   // grid (B, edim/64): every block recomputes the (cheap) hidden layer and produces 64 outputs of the second
   // Linear with 4 k-slices per output, so the 1 MB second weight matrix is spread over 8x more CUs.
   extern __shared__ float s_te[];           // tdim sinusoid + edim hidden + 256 partials
@@ -437,6 +441,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
 template <typename TM>
 __global__ __launch_bounds__(256) void nct_to_btc_kernel(const float* __restrict__ src, int C, int T, float* __restrict__ dst,
                                                          TM* __restrict__ dst_op, int ldd, int cpad) {
+  op_mode_init<TM>();
   __shared__ float tile[32][33];
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -485,6 +490,7 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
                                                             const float* __restrict__ x0, float* __restrict__ xe, TM* __restrict__ xe_op,
                                                             float* __restrict__ xbar, float* __restrict__ d1,
                                                             float* __restrict__ mprev, size_t n4) {
+  op_mode_init<TM>();
   const float* c = coef + (size_t)(*step_ptr) * ncoef;
   const float alpha = c[1], sigma = c[2], g0 = c[3], g1 = c[4], A = c[5], Bc = c[6], d1c = c[7], pc = c[8];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {

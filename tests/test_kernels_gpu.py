@@ -439,6 +439,37 @@ def test_gemm_fused_shortcut_segment(prec, diag):
         lib.ns2vc_dev_free(d_w)
 
 
+def test_fp16_operand_stores_saturate(diag):
+    """fp16 operand stores clamp finite overflow to +-65504 (MODE.FP16_OVFL, set at kernel entry) instead of producing inf:
+    a GEMM whose results reach ~2e5 writes an operand copy equal to the fp32 result clipped to +-65504 and then rounded."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(31)
+    B, T, K, N = 2, 70, 128, 128
+    M = B * T
+    a = rnd(1000.0 * rng.standard_normal((B, T, K)), 2)
+    W = rnd(10.0 * rng.standard_normal((N, K)), 2)
+    d_a, d_w = OpBuf(a, 2), _pack(W, 2)
+    d_o = DevBuf(M * N * 4)
+    d_op = OpBuf(np.zeros((M, N), dtype=np.float32), 2)
+    g = GemmArgs()
+    g.a0 = d_a.ptr; g.lda0 = K; g.c0 = K
+    g.B, g.Tin, g.Tout, g.M = B, T, T, M
+    g.taps, g.tmode = 1, 0
+    g.w = d_w.value; g.K = K; g.N = N
+    g.out_f32 = d_o.ptr; g.ldo_f32 = N
+    g.out_op = d_op.ptr; g.ldo_op = N
+    check(lib.ns2vc_k_gemm(C.byref(g), 2, None), "k_gemm")
+    sync()
+    out, op = d_o.to_numpy((M, N)), d_op.read()
+    n_over = int((np.abs(out) > 65504).sum())
+    diag(f"fp16 saturating stores: {n_over} of {out.size} results beyond 65504, max |result| {np.abs(out).max():.3e}, max |operand copy| {np.abs(op).max():.1f}")
+    assert n_over > 100 and np.isfinite(op).all()
+    assert np.array_equal(op, f16_round(np.clip(out, -65504.0, 65504.0)))
+    lib.ns2vc_dev_free(d_w)
+
+
 def test_gemm_heuristic_large(diag):
     """A level-0 sized problem (M = 4*938) goes through the tile heuristic."""
     rng = np.random.default_rng(7)
