@@ -79,7 +79,9 @@ int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int bufle
 /* Plan options, by name; call before ns2vc_unet_prepare (an existing plan / workspace is dropped):
  *   "ln_linear" 1|0  LayerNorm by linearity (default 1) vs explicit normalisation passes
  *   "fold_ff"   1|0  ff.net.2 folded into proj_out at pack time (default 1) vs two launches
- * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF set the defaults at ns2vc_unet_create. */
+ *   "fuse_ffn"  1|0  GEGLU feed-forward + proj_out in ONE launch where eligible (16-bit precisions, dim <= 256; needs
+ *                    ln_linear and fold_ff; default 1) vs the GEGLU GEMM + the folded GEMM
+ * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF / NS2VC_FUSE_FFN set the defaults at ns2vc_unet_create. */
 int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value);
 /* LayerNorm-by-linearity health: the largest |mean| / std over every LayerNorm input row seen since the last call
  * (or since prepare).  The 16-bit modes round the raw row before centring, so their error on a row grows ~linearly
@@ -186,6 +188,28 @@ typedef struct ns2vc_attn_args {
   float scale;
   void* out; int32_t ldo;         /* operand-typed */
 } ns2vc_attn_args;
+
+/* Fused feed-forward + proj_out of one transformer block (attention.py:178-203 GEGLU feed-forward, transformer_1d.py:287-295),
+ * 16-bit precisions, dim 128 | 256, T >= 64:
+ *   out = [Wpo W2 | Wpo] [GEGLU(LayerNorm(y) W1^T + b1) | y] + (Wpo b2 + bpo) + res
+ * `yn` = the RAW rows y in the operand type with their LayerNorm-by-linearity statistics `ln_stats` (as a producer GEMM's
+ * `rowstats` leaves them); `wstream` from ns2vc_pack_ffn; `consts` [8*dim][2] = (sum_k of the rounded packed W1 row, folded
+ * bias) in packed row order (per 32 hidden units: 32 value rows, then their 32 gate rows); `bias2` [dim]. */
+typedef struct ns2vc_ffn_args {
+  const void* yn; int32_t ldy;
+  const float* ln_stats; float ln_eps;
+  const void* wstream; const float* consts; const float* bias2;
+  const float* res; int32_t ldres;          /* fp32 block residual x */
+  float* out_f32; int32_t ldo_f32;          /* fp32 result, or NULL */
+  void* out_op; int32_t ldo_op;             /* operand-typed copy, or NULL */
+  long long* stats;                         /* optional GroupNorm statistics of the result, as in ns2vc_gemm_args */
+  int32_t B, T, M, dim;                     /* M = B*T rows */
+  unsigned* ln_health;                      /* optional, as in ns2vc_gemm_args */
+} ns2vc_ffn_args;
+/* w1_packed [8*dim][dim]: LayerNorm-folded ff.net.0 rows in the packed (32 value | 32 gate) order; w2f [dim][5*dim] =
+ * [Wpo W2 | Wpo]; both fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
+int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, int precision, void** out_stream_dev);
+int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream);
 
 /* operand-typed conversions for tests: fp32 host [n] -> device operand buffer and back */
 int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev);

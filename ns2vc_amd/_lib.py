@@ -49,6 +49,20 @@ class GemmArgs(C.Structure):
     ]
 
 
+class FfnArgs(C.Structure):
+    _fields_ = [
+        ("yn", C.c_void_p), ("ldy", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
+        ("wstream", C.c_void_p), ("consts", C.c_void_p), ("bias2", C.c_void_p),
+        ("res", C.c_void_p), ("ldres", C.c_int32),
+        ("out_f32", C.c_void_p), ("ldo_f32", C.c_int32),
+        ("out_op", C.c_void_p), ("ldo_op", C.c_int32),
+        ("stats", C.c_void_p),
+        ("B", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("dim", C.c_int32),
+        ("ln_health", C.c_void_p),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
@@ -110,6 +124,8 @@ PROTOTYPES = {
     "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
+    "ns2vc_pack_ffn": (_I, [_P, _P, _I, _I, _PP]),
+    "ns2vc_k_ffn": (_I, [C.POINTER(FfnArgs), _I, _P]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),

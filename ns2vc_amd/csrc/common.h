@@ -210,6 +210,10 @@ hipError_t init_gemm_attributes();
 void set_forced_gemm_tile(int bm, int bn, int stages);
 void set_gemm_trace(unsigned long long* p);
 hipError_t init_attn_attributes();
+// fused feed-forward + proj_out (ffn.hip), 16-bit operand types only
+hipError_t launch_ffn(const ::ns2vc_ffn_args& a, int prec, hipStream_t s);
+bool ffn_eligible(int dim, int T, int prec);
+hipError_t init_ffn_attributes();
 
 // misc kernels (misc.hip).  "op" buffers are operand-typed (bf16 / fp16 / fp32 by `prec`)
 hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1,

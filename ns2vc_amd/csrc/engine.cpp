@@ -21,6 +21,10 @@
 
 using namespace ns2vc;
 
+namespace ns2vc {
+hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
+}
+
 namespace {
 
 thread_local std::string g_err;
@@ -68,6 +72,8 @@ struct AttnW {
   float *ng = nullptr, *nb = nullptr;
   PackedW proj_in, qkv, o1, q2, o2, ff1, ff2, proj_out;
   PackedW ffpo;    // ff.net.2 folded into proj_out: [W_po W_2 | W_po], K = 4*dim + dim (see pack_all)
+  void* ffn_stream = nullptr;     // fused feed-forward + proj_out (ffn.hip): weight tile stream ...
+  float* ffn_consts = nullptr;    // ... and (rowsum, bias) per packed ff.net.0 row; 16-bit precisions, dim <= 256 only
 };
 struct BlockW {
   std::string kind;   // down | mid | up
@@ -125,6 +131,9 @@ struct ns2vc_unet {
   // ff.net.2 folded into proj_out at pack time (one GEMM with a second K segment instead of two launches; the
   // post-feed-forward stream tensor is never materialised).  NS2VC_FOLD_FF=0 restores the two launches.
   bool fold_ff = true;
+  // GEGLU feed-forward + ff.net.2 + proj_out in ONE launch per transformer block (csrc/ffn.hip) where eligible
+  // (16-bit precisions, dim 128 / 256, LayerNorm by linearity and the fold on).  NS2VC_FUSE_FFN=0 restores the two GEMMs.
+  bool fuse_ffn = true;
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -468,6 +477,7 @@ int pack_all(ns2vc_unet* h) {
         a.q2 = P.pack(rows, d, d, bias, true);
       }
       a.o2 = P.pack(P.T(t + ".attn2.to_out.0.weight").data, d, d, P.T(t + ".attn2.to_out.0.bias").data);
+      std::vector<float> ff1_rows, ff1_bias;     // packed ff.net.0 (kept for the fused feed-forward stream below)
       {  // GEGLU projection: LayerNorm(norm3) folded, rows interleaved in (32 value | 32 gate) groups
         std::vector<float> rows, bias;
         P.ln_fold(P.T(t + ".ff.net.0.proj.weight"), &P.T(t + ".ff.net.0.proj.bias"), P.T(t + ".norm3.weight"), P.T(t + ".norm3.bias"), rows, bias);
@@ -484,6 +494,7 @@ int pack_all(ns2vc_unet* h) {
             bias2[g_dst] = bias[g_src];
           }
         a.ff1 = P.pack(rows2, 8 * d, d, bias2, true);
+        ff1_rows.swap(rows2); ff1_bias.swap(bias2);
       }
       a.ff2 = P.pack(P.T(t + ".ff.net.2.weight").data, d, 4 * d, P.T(t + ".ff.net.2.bias").data);
       {  // ff.net.2 folded into proj_out (attention.py:178-203 + transformer_1d.py:287-295):
@@ -512,6 +523,21 @@ int pack_all(ns2vc_unet* h) {
           bias[n] = (float)bacc;
         }
         a.ffpo = P.pack(rows, d, K1 + K2, bias);
+        if (h->prec != PREC_F32 && (d == 128 || d == 256)) {   // fused feed-forward + proj_out (csrc/ffn.hip)
+          std::vector<unsigned short> st;
+          if (pack_ffn_stream(ff1_rows.data(), rows.data(), d, h->prec, st) != hipSuccess) return fail("ffn stream packing failed");
+          void* dev = nullptr;
+          if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
+          h->weight_allocs.push_back(dev);
+          if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
+          a.ffn_stream = dev;
+          const std::vector<float> ws = rounded_rowsum(ff1_rows.data(), 8 * d, d, 8 * d, h->prec);
+          std::vector<float> cs((size_t)8 * d * 2);
+          for (int r = 0; r < 8 * d; ++r) { cs[2 * r] = ws[r]; cs[2 * r + 1] = ff1_bias[r]; }
+          a.ffn_consts = P.upload_f32(cs);
+        } else {
+          a.ffn_stream = nullptr; a.ffn_consts = nullptr;
+        }
       }
       {  // cross-attention k|v of this block into the hoisted all-blocks projection
         const HostTensor& wk = P.T(t + ".attn2.to_k.weight");
@@ -734,6 +760,21 @@ struct Planner {
     g.rowstats = r3;
     gemm(t + ".attn2.to_out", g);
     // feed-forward (GEGLU)
+    if (fold && r3 && h->fuse_ffn && a.ffn_stream && ffn_eligible(d, Tl, pr)) {
+      // LayerNorm(norm3) -> GEGLU -> ff.net.2 -> + y -> proj_out -> + x in ONE launch: the hidden tensor never exists
+      ns2vc_ffn_args f;
+      memset(&f, 0, sizeof(f));
+      f.yn = yn; f.ldy = d; f.ln_stats = r3; f.ln_eps = 1e-5f;
+      f.wstream = a.ffn_stream; f.consts = a.ffn_consts; f.bias2 = a.ffpo.bias;
+      f.res = x; f.ldres = d;
+      f.out_f32 = out; f.ldo_f32 = d; f.out_op = out_op; f.ldo_op = d;
+      f.stats = new_stats(out, Tl, d);
+      f.B = B; f.T = Tl; f.M = M; f.dim = d; f.ln_health = h->ln_health;
+      const double fl = 2.0 * M * (double)d * (13.0 * d);
+      add(a.prefix + ".ffn[geglu+ff.out+proj_out]", [=](hipStream_t s) { return launch_ffn(f, pr, s); }, 1, fl,
+          (double)M * d * (opsz + 8.0 + (out_op ? opsz : 0.0)) + 13.0 * d * d * opsz);
+      return;
+    }
     if (!r3) layernorm(t + ".norm3");
     g = base(yn, d, d, Tl, Tl, a.ff1, nullptr, ffh, 4 * d);
     g.geglu = 1;
@@ -1058,12 +1099,14 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (cfg->cross_attention_dim % cfg->pool_heads || cfg->cross_attention_dim / cfg->pool_heads > 8) return fail("pool heads unsupported");
   hipError_t e = init_gemm_attributes();
   if (e == hipSuccess) e = init_attn_attributes();
+  if (e == hipSuccess) e = init_ffn_attributes();
   if (e != hipSuccess) return fail("kernel attribute setup failed: %s (is a gfx950 GPU visible?)", hipGetErrorString(e));
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail("hipGetDevice failed"); }
   if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FOLD_FF")) h->fold_ff = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1136,7 +1179,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   bool* opt = nullptr;
   if (!strcmp(name, "ln_linear")) opt = &h->ln_linear;
   else if (!strcmp(name, "fold_ff")) opt = &h->fold_ff;
-  else return fail("unknown option '%s' (ln_linear, fold_ff)", name);
+  else if (!strcmp(name, "fuse_ffn")) opt = &h->fuse_ffn;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1365,6 +1409,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
   if (!inited) {
     hipError_t e = init_gemm_attributes();
     if (e == hipSuccess) e = init_attn_attributes();
+    if (e == hipSuccess) e = init_ffn_attributes();
     if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
     inited = true;
   }
@@ -1396,6 +1441,28 @@ int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_gemm(*a, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("launch_gemm: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, int precision, void** out_stream_dev) {
+  if (!w1_packed_host || !w2f_host || !out_stream_dev) return fail("null argument");
+  static bool inited = false;
+  if (!inited) {
+    hipError_t e = init_ffn_attributes();
+    if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
+    inited = true;
+  }
+  std::vector<unsigned short> st;
+  if (pack_ffn_stream(w1_packed_host, w2f_host, dim, precision, st) != hipSuccess) return fail("ffn: dim must be 128 or 256 and the precision 16-bit");
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, st.size() * 2));
+  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  *out_stream_dev = d;
+  return 0;
+}
+int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream) {
+  if (!a) return fail("null args");
+  hipError_t e = launch_ffn(*a, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_ffn: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream) {

@@ -1,0 +1,347 @@
+// Fused feed-forward + proj_out of a transformer block of the NS2VC denoiser, CDNA4 (gfx950), 16-bit operand types.
+//
+// Replaces, in ONE launch, the tail of BasicTransformerBlock / Transformer2DModel
+// (reference unet1d/attention.py:178-203, 206-301 GEGLU with erf GELU; unet1d/transformer_1d.py:287-295):
+//
+//     n   = LayerNorm(y)                                   (norm3, gamma/beta folded into W1 / b1 at pack time)
+//     h   = (n W1v^T + b1v) * gelu(n W1g^T + b1g)          (ff.net.0: GEGLU, hidden = 4 dim)
+//     out = Wpo (y + W2 h + b2) + bpo + x                  (ff.net.2, + residual, proj_out (1x1 conv), + block residual)
+//         = [Wpo W2 | Wpo] [h | y] + (Wpo b2 + bpo) + x    (folded at pack time: engine.cpp pack_all)
+//
+// As separate launches the GEGLU GEMM (K = dim: one or two K tiles, N = 8 dim) was the slowest GEMM of the step at every
+// level (30-44 us: prologue, two cold K tiles and an erf epilogue per workgroup, 15 workgroups per CU, and a 30 MB
+// hidden tensor written and read back), followed by a K = 5 dim GEMM.  Here one workgroup owns 64 tokens for the WHOLE
+// chain: the raw rows y stay in LDS as the K panel of ff.net.0 AND of the Wpo segment, the hidden tensor never leaves
+// registers, and the only stream from L2 is the weights -- one flat sequence of 16 KB tiles ([128 rows][64 k], already
+// in the bank-conflict-free XOR-swizzled LDS image, in exactly the order the kernel consumes them), so the loader is a
+// lane-linear LDS-DMA with every address in SGPRs.
+//
+// Everything is computed TRANSPOSED (the attention kernel's trick): S^T = W1 y^T, so after the 32x32 MFMA a lane holds
+// 16 hidden units of ONE token (column = lane & 31): value and gate of a unit sit in the same lane and register, the
+// LayerNorm fix-up is per lane (mean / rstd of the lane's token), GEGLU is pure register arithmetic, and the packed
+// result IS the B operand of the second MFMA chain  O^T += W2' h^T  (W2' columns are stored with unit bits 2 and 3
+// swapped so that the 8 units a lane half holds are contiguous in k).  512 threads = 8 waves = 2 token halves x 4
+// hidden-unit groups: every wave accumulates O^T[all dim channels][its 32 tokens] over ITS hidden units; the four
+// partials meet in the LDS-staged epilogue (bias, fp32 residual, fp32 + operand stores, GroupNorm statistics).
+#include "common.h"
+#include "mma.h"
+#include <vector>
+
+namespace ns2vc {
+
+typedef ::ns2vc_ffn_args FfnArgs;
+
+// tile stream geometry (host packer below and kernel must agree)
+constexpr int FFN_TILE = 128 * 128;        // bytes: [128 rows][128 B of K]
+constexpr int FFN_PAIR = 2 * FFN_TILE;     // the kernel consumes tiles two at a time
+constexpr int FFN_RING = 3;                // pairs resident in LDS
+
+template <int D> struct FfnGeom {
+  static constexpr int KT = D / 64;        // K tiles of ff.net.0 (= tiles of the token panel)
+  static constexpr int NB = D / 32;        // 32-channel output blocks (accumulator tiles per wave)
+  static constexpr int NSS = D / 32;       // super-steps of 128 hidden units (4 D hidden in all)
+  static constexpr int NB128 = D / 128;    // 128-row blocks of W2' / Wpo
+  static constexpr int PO_STEPS = NB128 * KT / 2;
+  static constexpr int PAIRS = NSS * (KT + NB128) + PO_STEPS;
+  static constexpr int PANEL = KT * 64 * 128;               // bytes: 64 tokens x D, as KT swizzled [64][128 B] tiles
+  static constexpr int CONSTS = 8 * D * 8;                  // bytes: (rowsum, bias) per packed W1 row
+  static constexpr int LDS = FFN_RING * FFN_PAIR + PANEL + CONSTS;
+  static constexpr int EP = 36;                             // epilogue staging pitch (floats)
+  static_assert(2 * 4 * 32 * EP * 4 + 8 * 2 * NB * 4 * 8 <= FFN_RING * FFN_PAIR, "epilogue staging fits in the ring");
+};
+
+template <typename TM, int D>
+__global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
+  op_mode_init<TM>();
+  using G = FfnGeom<D>;
+  constexpr int KT = G::KT, NB = G::NB, NSS = G::NSS, NB128 = G::NB128, NP = G::PAIRS, EP = G::EP;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const panel = smem + FFN_RING * FFN_PAIR;
+  const float* const consts = reinterpret_cast<const float*>(panel + G::PANEL);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = wave & 1, hw = wave >> 1;          // token half, hidden-unit group
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int sw = (l31 >> 1) & 7;                    // read-side XOR swizzle of every fragment row this lane touches
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int m0 = blockIdx.x * 64;
+  const int mtok = m0 + 32 * tw + l31;              // this lane's token (both lane halves)
+
+  // ---- DMA: token panel (source-side swizzle, rows past M read as zeros), constants, then the weight stream
+  {
+    const int prow = 8 * wave + (lane >> 3), pchunk = lane & 7;           // one 1-KB piece per wave = 8 rows x 128 B
+    const int m = m0 + prow;
+    const unsigned voff = m < a.M ? (unsigned)m * (unsigned)a.ldy * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
+    const i32x4_t rY = make_rsrc(a.yn, (unsigned long long)a.M * a.ldy * 2ull);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) blds16(rY, voff, (unsigned)(kt * 128), lds0 + FFN_RING * FFN_PAIR + kt * 8192 + wave * 1024);
+    const i32x4_t rC = make_rsrc(a.consts, (unsigned long long)G::CONSTS);
+#pragma unroll
+    for (int j = 0; j < G::CONSTS / 8192; ++j)
+      blds16(rC, (unsigned)(lane * 16), (unsigned)((j * 8 + wave) * 1024), lds0 + FFN_RING * FFN_PAIR + G::PANEL + (j * 8 + wave) * 1024);
+  }
+  const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * FFN_PAIR);
+  const unsigned lane16 = (unsigned)(lane * 16);
+  auto issue_pair = [&](int p) __attribute__((always_inline)) {           // 32 pieces of 1 KB: four per wave, all addresses scalar
+    const int slot = p % FFN_RING;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      blds16(rW, lane16, (unsigned)(p * FFN_PAIR + (j * 8 + wave) * 1024), lds0 + slot * FFN_PAIR + (j * 8 + wave) * 1024);
+  };
+  issue_pair(0);
+  if (NP > 1) issue_pair(1);
+
+  // ---- LayerNorm statistics of this lane's token (ordinary loads: the compiler waits for them -- and, not seeing the
+  // DMA above, for everything issued so far: that is the prologue's wait for the first tiles anyway)
+  float mean, rstd;
+  {
+    const float4* sp = reinterpret_cast<const float4*>(a.ln_stats + (size_t)min(mtok, a.M - 1) * (D / 64) * 2);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) { const float4 v = sp[i]; s += v.x + v.z; q += v.y + v.w; }
+    const float inv = 1.0f / (float)D;
+    mean = s * inv;
+    double var = (double)q * (double)inv - (double)mean * (double)mean;
+    if (var < 0.0) var = 0.0;
+    rstd = 1.0f / sqrtf((float)var + a.ln_eps);
+    if (a.ln_health && hw == 0) {          // same health report as the LayerNorm-consumer GEMMs (gemm.hip ln_row_finish)
+      float ratio = mtok < a.M ? fabsf(mean) * rstd : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
+      if (lane == 0 && ratio > __uint_as_float(__hip_atomic_load(a.ln_health, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        atomicMax(a.ln_health, __float_as_uint(ratio));
+    }
+  }
+
+  f32x16_t accO[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accO[i][r] = 0.f;
+
+  int p = 0;                                        // next pair to consume
+  auto step_begin = [&]() __attribute__((always_inline)) -> const char* {
+    // pair p has landed when only the four pieces of pair p+1 may still be in flight
+    if (p + 1 < NP) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragment reads of the slot about to be refilled are done
+    __builtin_amdgcn_s_barrier();
+    if (p + 2 < NP) issue_pair(p + 2);                         // into the slot of pair p-1, free for everyone after the barrier
+    return ring + (p % FFN_RING) * FFN_PAIR;
+  };
+  const char* const bpanel = panel + (32 * tw + l31) * 128;    // this lane's token row inside a panel tile (+ kt * 8192)
+
+#pragma unroll 1
+  for (int ss = 0; ss < NSS; ++ss) {
+    // ---- ff.net.0 (transposed): value / gate pre-activations of this wave's 32 hidden units for its 32 tokens
+    f32x16_t av, ag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const char* T = step_begin();
+      ++p;
+      const char* wrow = T + (hw >> 1) * FFN_TILE + (64 * (hw & 1) + l31) * 128;      // value row; gate row = + 32 rows
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ((2 * ks + hi) ^ sw) * 16;
+        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(bpanel + kt * 8192 + c);
+        const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(wrow + c);
+        const u32x4_t wg = *reinterpret_cast<const u32x4_t*>(wrow + 32 * 128 + c);
+        MmaT<TM>::mma(av, wv, b);
+        MmaT<TM>::mma(ag, wg, b);
+      }
+    }
+    // ---- LayerNorm fix-up + bias + GEGLU in registers; register r <-> unit (r&3) + 8 (r>>2) + 4 hi of this wave's 32
+    u32x4_t hf[2];
+    {
+      const float* cv = consts + (size_t)(256 * ss + 64 * hw) * 2;           // (rowsum, bias) of the value rows; gate rows = + 32
+      float h[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v0 = *reinterpret_cast<const float4*>(cv + (8 * j + 4 * hi) * 2);
+        const float4 v1 = *reinterpret_cast<const float4*>(cv + (8 * j + 4 * hi) * 2 + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(cv + (32 + 8 * j + 4 * hi) * 2);
+        const float4 g1 = *reinterpret_cast<const float4*>(cv + (32 + 8 * j + 4 * hi) * 2 + 4);
+        const float wsv[4] = {v0.x, v0.z, v1.x, v1.z}, bv[4] = {v0.y, v0.w, v1.y, v1.w};
+        const float wsg[4] = {g0.x, g0.z, g1.x, g1.z}, bg[4] = {g0.y, g0.w, g1.y, g1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float pv = rstd * (av[4 * j + i] - mean * wsv[i]) + bv[i];
+          const float pg = rstd * (ag[4 * j + i] - mean * wsg[i]) + bg[i];
+          h[4 * j + i] = pv * gelu_erf_f(pg);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        hf[s] = u32x4_t{Op16<TM>::pack(h[8 * s + 0], h[8 * s + 1]), Op16<TM>::pack(h[8 * s + 2], h[8 * s + 3]),
+                        Op16<TM>::pack(h[8 * s + 4], h[8 * s + 5]), Op16<TM>::pack(h[8 * s + 6], h[8 * s + 7])};
+    }
+    // ---- O^T[n][token] += W2'[n][this wave's 32 units] h^T : 32 units = half of a 64-unit tile
+#pragma unroll
+    for (int nb = 0; nb < NB128; ++nb) {
+      const char* T = step_begin();
+      ++p;
+      const char* wrow = T + (hw >> 1) * FFN_TILE + l31 * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const u32x4_t w = *reinterpret_cast<const u32x4_t*>(wrow + i * 32 * 128 + ((4 * (hw & 1) + 2 * s + hi) ^ sw) * 16);
+          MmaT<TM>::mma(accO[4 * nb + i], w, hf[s]);
+        }
+    }
+  }
+  // ---- the Wpo segment: O^T += Wpo y^T; wave hw takes k-slab hw of every 64-wide K tile
+#pragma unroll
+  for (int j = 0; j < G::PO_STEPS; ++j) {
+    const char* T = step_begin();
+    ++p;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int q = 2 * j + t, nb = q / KT, kt = q % KT;                     // (compile-time after unrolling)
+      const int c = ((2 * hw + hi) ^ sw) * 16;
+      const u32x4_t b = *reinterpret_cast<const u32x4_t*>(bpanel + kt * 8192 + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(T + t * FFN_TILE + (32 * i + l31) * 128 + c);
+        MmaT<TM>::mma(accO[4 * nb + i], w, b);
+      }
+    }
+  }
+
+  // ---- epilogue: the four hidden-group partials of a token half meet in LDS (re-using the ring); 512 lanes = 2 halves x
+  // 32 tokens x 8 channel quads take one float4 each per 32-channel block: bias, residual, stores, GroupNorm statistics
+  __syncthreads();
+  float* const E = reinterpret_cast<float*>(ring);
+  double* const S = reinterpret_cast<double*>(ring + 2 * 4 * 32 * EP * 4);     // [wave][2 NB blocks][2 items][2 moments]
+  const int L = tid, eth = L >> 8, etok = (L >> 3) & 31, equad = L & 7;
+  const int em = m0 + 32 * eth + etok;
+  const bool eok = em < a.M;
+  const int b0 = min(m0, a.M - 1) / a.T;                 // first batch item of this 64-token block (T >= 64: at most two)
+  const int mB = (b0 + 1) * a.T;
+  float4 rr[NB];                                          // residual rows + bias: every load in flight before the first store
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    rr[nb] = eok ? *reinterpret_cast<const float4*>(a.res + (size_t)em * a.ldres + 32 * nb + 4 * equad) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bb = *reinterpret_cast<const float4*>(a.bias2 + 32 * nb + 4 * equad);
+    rr[nb].x += bb.x; rr[nb].y += bb.y; rr[nb].z += bb.z; rr[nb].w += bb.w;
+  }
+  float* const Ew = E + ((tw * 4 + hw) * 32 + l31) * EP + 4 * hi;
+  const float* const Er = E + (eth * 4 * 32 + etok) * EP + 4 * equad;
+  TM* const oo = reinterpret_cast<TM*>(a.out_op);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (nb) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<float4*>(Ew + 8 * j) = make_float4(accO[nb][4 * j], accO[nb][4 * j + 1], accO[nb][4 * j + 2], accO[nb][4 * j + 3]);
+    __syncthreads();
+    float4 v = *reinterpret_cast<const float4*>(Er);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float4 u = *reinterpret_cast<const float4*>(Er + k * 32 * EP);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int n = 32 * nb + 4 * equad;
+    float ps = 0.f, pq = 0.f;
+    if (eok) {
+      v.x += rr[nb].x; v.y += rr[nb].y; v.z += rr[nb].z; v.w += rr[nb].w;
+      if (a.out_f32) out_f4(a.out_f32 + (size_t)em * a.ldo_f32 + n, v.x, v.y, v.z, v.w);
+      if (oo) out_op4<TM>(oo + (size_t)em * a.ldo_op + n, v.x, v.y, v.z, v.w);
+      ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (a.stats) {
+      // fixed shuffle tree inside the wave (8 tokens x 8 quads): the 4 quads of a 16-channel block, then the 8 tokens
+      double d0 = (eok && em < mB) ? ps : 0.0, d1 = (eok && em < mB) ? pq : 0.0;
+      double d2 = (eok && em >= mB) ? ps : 0.0, d3 = (eok && em >= mB) ? pq : 0.0;
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
+      if ((lane & 59) == 0) {                          // lanes 0 and 4: first token lane of channel quads 0-3 / 4-7
+        double* sp = S + ((wave * 2 * NB) + 2 * nb + (lane >> 2)) * 4;
+        sp[0] = d0; sp[1] = d1; sp[2] = d2; sp[3] = d3;
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    if (tid < 2 * NB * 4) {                            // one thread per (16-channel block, item slot, moment): waves summed in fixed order
+      const int blk = tid >> 2, which = tid & 3;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) acc += S[((w * 2 * NB) + blk) * 4 + which];
+      const int item = which >> 1, moment = which & 1;
+      if (item == 0 || (mB < a.M && mB < m0 + 64)) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(a.stats) + ((size_t)(b0 + item) * (D / 16) + blk) * 2 + moment;
+        atomicAdd(st, (unsigned long long)llrint(acc * (moment ? GN_SQ_SCALE : GN_SUM_SCALE)));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side: tile-stream packer and launcher
+// ---------------------------------------------------------------------------
+// one 16 KB tile [128 rows][64 k] of a row-major fp32 matrix, rounded to the operand type, in the swizzled LDS image:
+// byte r*128 + pos*16 holds logical chunk pos ^ ((r>>1)&7) of row r; `perm` (optional) maps a stored k to the source column
+static void append_tile(std::vector<unsigned short>& out, const float* mat, size_t ld, int row0, int col0, int prec, const int* perm) {
+  for (int r = 0; r < 128; ++r)
+    for (int pos = 0; pos < 8; ++pos) {
+      const int lc = pos ^ ((r >> 1) & 7);
+      for (int e = 0; e < 8; ++e) {
+        const int k = lc * 8 + e;
+        const int col = col0 + (perm ? perm[k] : k);
+        out.push_back(f32_to_op16_bits(mat[(size_t)(row0 + r) * ld + col], prec));
+      }
+    }
+}
+
+hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec, std::vector<unsigned short>& out) {
+  if ((dim != 128 && dim != 256) || (prec != PREC_BF16 && prec != PREC_F16)) return hipErrorInvalidValue;
+  const int KT = dim / 64, NSS = dim / 32, NB128 = dim / 128;
+  int perm[64];                          // stored k -> unit offset inside a 64-unit tile: bits 2 and 3 swapped per 16 units
+  for (int k = 0; k < 64; ++k) perm[k] = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1);
+  out.clear();
+  out.reserve((size_t)(NSS * (KT + NB128) + NB128 * KT / 2) * FFN_PAIR / 2);
+  for (int ss = 0; ss < NSS; ++ss) {
+    for (int kt = 0; kt < KT; ++kt)
+      for (int half = 0; half < 2; ++half) append_tile(out, w1p, dim, 256 * ss + 128 * half, 64 * kt, prec, nullptr);
+    for (int nb = 0; nb < NB128; ++nb)
+      for (int kt2 = 0; kt2 < 2; ++kt2) append_tile(out, w2f, 5 * (size_t)dim, 128 * nb, 128 * ss + 64 * kt2, prec, perm);
+  }
+  for (int nb = 0; nb < NB128; ++nb)
+    for (int kt = 0; kt < KT; ++kt) append_tile(out, w2f, 5 * (size_t)dim, 128 * nb, 4 * dim + 64 * kt, prec, nullptr);
+  return hipSuccess;
+}
+
+bool ffn_eligible(int dim, int T, int prec) { return (dim == 128 || dim == 256) && T >= 64 && (prec == PREC_BF16 || prec == PREC_F16); }
+
+template <typename TM, int D> static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
+  const size_t lds = FfnGeom<D>::LDS;
+  hipLaunchKernelGGL((ffn_kernel<TM, D>), dim3((a.M + 63) / 64), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_ffn(const FfnArgs& a, int prec, hipStream_t s) {
+  if (!ffn_eligible(a.dim, a.T, prec) || a.M <= 0 || a.M != a.B * a.T) return hipErrorInvalidValue;
+  if (!a.yn || !a.ln_stats || !a.wstream || !a.consts || !a.bias2 || !a.res || (!a.out_f32 && !a.out_op)) return hipErrorInvalidValue;
+  if ((a.ldy & 7) || (a.ldres & 3) || (a.out_f32 && (a.ldo_f32 & 3)) || (a.out_op && (a.ldo_op & 3))) return hipErrorInvalidValue;
+  if ((unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
+  if (prec == PREC_BF16) return a.dim == 128 ? launch_ffn_t<bf16_t, 128>(a, s) : launch_ffn_t<bf16_t, 256>(a, s);
+  return a.dim == 128 ? launch_ffn_t<f16_t, 128>(a, s) : launch_ffn_t<f16_t, 256>(a, s);
+}
+
+hipError_t init_ffn_attributes() {
+  hipError_t e;
+#define NS2VC_FFN_ATTR(TM, D_)                                                                                          \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<TM, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)FfnGeom<D_>::LDS)) != hipSuccess) return e
+  NS2VC_FFN_ATTR(bf16_t, 128); NS2VC_FFN_ATTR(bf16_t, 256); NS2VC_FFN_ATTR(f16_t, 128); NS2VC_FFN_ATTR(f16_t, 256);
+#undef NS2VC_FFN_ATTR
+  return hipSuccess;
+}
+
+}  // namespace ns2vc

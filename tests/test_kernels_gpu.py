@@ -506,6 +506,84 @@ def test_gemm_bench_shapes(case, prec, diag):
     assert np.array_equal(out_op, rnd(out, prec)), name
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("dim,B,T", [(128, 3, 150), (256, 2, 97), (128, 1, 64), (256, 5, 200)], ids=str)
+def test_ffn_fused(dim, B, T, prec, diag):
+    """The fused feed-forward + proj_out kernel (csrc/ffn.hip) against numpy fp64 of
+        out = Wpo (y + W2 (GEGLU(LayerNorm(y) W1^T + b1)) + b2) + bpo + x
+    with the engine's pack-time folds (LayerNorm gamma/beta into W1/b1, [Wpo W2 | Wpo], value|gate row interleave), the
+    kernel's own rounding points modelled (operands and the hidden tensor are rounded to the operand type), rows with a
+    common offset (LayerNorm by linearity), a row count that is no multiple of 64 and 64-token blocks that straddle batch
+    items (GroupNorm statistics of the result per item)."""
+    from scipy.special import erf
+    from ns2vc_amd._lib import FfnArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(dim * 1000 + B * 10 + T)
+    d, M = dim, B * T
+    y = (rng.standard_normal((M, d)) + 1.5 * rng.standard_normal((M, 1))).astype(np.float32)
+    x = rng.standard_normal((M, d)).astype(np.float32)
+    gamma, beta = (1.0 + 0.2 * rng.standard_normal(d)), 0.2 * rng.standard_normal(d)
+    W1, b1 = rng.standard_normal((8 * d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(8 * d)
+    W2, b2 = rng.standard_normal((d, 4 * d)) / np.sqrt(4 * d), 0.3 * rng.standard_normal(d)
+    Wpo, bpo = rng.standard_normal((d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(d)
+    # ---- pack-time folds (engine.cpp pack_all), fp64
+    W1f, b1f = W1 * gamma[None, :], b1 + W1 @ beta
+    order = np.concatenate([np.concatenate([np.arange(32 * g, 32 * g + 32), 4 * d + np.arange(32 * g, 32 * g + 32)]) for g in range(4 * d // 32)])
+    W1p, b1p = W1f[order].astype(np.float32), b1f[order].astype(np.float32)
+    w2f = np.concatenate([Wpo @ W2, Wpo], axis=1).astype(np.float32)
+    bias2 = (Wpo @ b2 + bpo).astype(np.float32)
+    W1r, w2r, yr = rnd(W1p, prec).astype(np.float64), rnd(w2f, prec).astype(np.float64), rnd(y, prec).astype(np.float64)
+    consts = np.stack([W1r.sum(1), b1p.astype(np.float64)], axis=1).astype(np.float32)
+    # ---- reference with the kernel's rounding points
+    y64 = y.astype(np.float64)
+    mean, var = y64.mean(1, keepdims=True), y64.var(1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + 1e-5)
+    pre = rstd * (yr @ W1r.T - mean * consts[:, 0].astype(np.float64)[None, :]) + b1p.astype(np.float64)[None, :]
+    pg = pre.reshape(M, 4 * d // 32, 2, 32)
+    h = (pg[:, :, 0] * 0.5 * pg[:, :, 1] * (1.0 + erf(pg[:, :, 1] / np.sqrt(2.0)))).reshape(M, 4 * d)
+    hr = rnd(h.astype(np.float32), prec).astype(np.float64)
+    ref = hr @ w2r[:, :4 * d].T + yr @ w2r[:, 4 * d:].T + bias2 + x
+    # ---- device
+    ys = y64.reshape(M, d // 64, 64)
+    stats = np.stack([ys.sum(2), (ys ** 2).sum(2)], axis=-1).astype(np.float32)
+    stream = C.c_void_p()
+    check(lib.ns2vc_pack_ffn(np.ascontiguousarray(W1p).ctypes.data, np.ascontiguousarray(w2f).ctypes.data, d, prec, C.byref(stream)), "pack_ffn")
+    d_y, d_st, d_c, d_b2, d_x = OpBuf(y, prec), _dev(stats), _dev(consts), _dev(bias2), _dev(x)
+    d_o = DevBuf(M * d * 4)
+    d_o.upload(np.full((M, d), np.nan, dtype=np.float32))
+    d_op = OpBuf(np.full((M, d), np.nan, dtype=np.float32), prec)
+    d_gs = DevBuf.from_numpy(np.zeros((B, d // 16, 2), dtype=np.int64))
+    d_health = DevBuf.from_numpy(np.zeros(16, dtype=np.uint32))
+    f = FfnArgs()
+    f.yn = d_y.ptr; f.ldy = d; f.ln_stats = d_st.ptr; f.ln_eps = 1e-5
+    f.wstream = stream.value; f.consts = d_c.ptr; f.bias2 = d_b2.ptr
+    f.res = d_x.ptr; f.ldres = d
+    f.out_f32 = d_o.ptr; f.ldo_f32 = d; f.out_op = d_op.ptr; f.ldo_op = d
+    f.stats = d_gs.ptr
+    f.B, f.T, f.M, f.dim = B, T, M, d
+    f.ln_health = d_health.ptr
+    check(lib.ns2vc_k_ffn(C.byref(f), prec, None), "k_ffn")
+    sync()
+    out, op = d_o.to_numpy((M, d)), d_op.read()
+    e = rel_l2(out, ref)
+    gs = d_gs.to_numpy((B, d // 16, 2), dtype=np.int64).astype(np.float64)
+    blk = out.astype(np.float64).reshape(B, T, d // 16, 16)
+    e_s = np.abs(gs[..., 0] / 2 ** 28 - blk.sum(axis=(1, 3))).max() / np.abs(blk.sum(axis=(1, 3))).max()
+    e_q = np.abs(gs[..., 1] / 2 ** 16 - (blk ** 2).sum(axis=(1, 3))).max() / (blk ** 2).sum(axis=(1, 3)).max()
+    ratio = float(d_health.to_numpy((16,), dtype=np.uint32)[:1].view(np.float32)[0])
+    diag(f"ffn fused dim={d} B={B} T={T} prec={prec}: rel_l2 {e:.3e} nan={int(np.isnan(out).sum())}  stats sum {e_s:.2e} sumsq {e_q:.2e}  |mean|/std {ratio:.2f}")
+    if not e < 2e-4:
+        err = np.abs(out - ref)
+        bad = np.argwhere(~(err <= 1e-2 + 1e-2 * np.abs(ref)))
+        diag(f"  FAIL: {len(bad)} bad of {out.size}; rows {sorted(set(bad[:, 0].tolist()))[:16]} cols {sorted(set(bad[:, 1].tolist()))[:16]}")
+    assert np.isfinite(out).all() and e < 2e-4
+    assert np.array_equal(op, rnd(out, prec))
+    assert e_s < 1e-5 and e_q < 1e-5
+    assert 0.5 < ratio < 12.0
+    lib.ns2vc_dev_free(stream)
+
+
 def ref_attention(q, k, v, bias, H, prec):
     B, Lq, D = q.shape
     Lk = k.shape[1]
