@@ -23,6 +23,7 @@ using namespace ns2vc;
 
 namespace ns2vc {
 hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
+void set_ffn_trace(unsigned long long* p);
 }
 
 namespace {
@@ -1435,7 +1436,11 @@ int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, flo
   *out_dev = (float*)d;
   return 0;
 }
-int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) { set_gemm_trace((unsigned long long*)dev_u64_blocks_x8); return 0; }
+int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) {
+  set_gemm_trace((unsigned long long*)dev_u64_blocks_x8);
+  set_ffn_trace((unsigned long long*)dev_u64_blocks_x8);
+  return 0;
+}
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages) { set_forced_gemm_tile(bm, bn, stages); return 0; }
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");

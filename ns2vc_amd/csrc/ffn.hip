@@ -31,12 +31,45 @@ namespace ns2vc {
 
 typedef ::ns2vc_ffn_args FfnArgs;
 
+// optional per-workgroup phase timing (cycles, wave 0): [block][8] = entry, prologue end, sum ff.net.0 steps, sum GEGLU,
+// sum W2' steps, Wpo steps, epilogue, exit.  Compiled in only with -DNS2VC_GEMM_TRACE=1 (`make TRACE=1`), set through
+// ns2vc_debug_set_gemm_trace; read by tools/ffn_trace.py
+__device__ unsigned long long* g_ffn_trace = nullptr;
+#ifndef NS2VC_GEMM_TRACE
+#define NS2VC_GEMM_TRACE 0
+#endif
+// fragment reads vs MFMAs of a step: 1 = wait for ALL reads, then the MFMAs back to back (scheduling fence); 2 = leave the
+// counted waits to the compiler but pin "reads first" with a scheduling barrier; 0 = compiler's choice
+#ifndef NS2VC_FFN_FENCE
+#define NS2VC_FFN_FENCE 1
+#endif
+#ifndef NS2VC_FFN_WARM
+#define NS2VC_FFN_WARM 1
+#endif
+#if NS2VC_FFN_FENCE == 1
+#define FFN_FRAG_FENCE() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif NS2VC_FFN_FENCE == 2
+#define FFN_FRAG_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define FFN_FRAG_FENCE() do {} while (0)
+#endif
+#if NS2VC_GEMM_TRACE
+#define FFN_NOW() __builtin_readcyclecounter()
+#define FFN_TR(i, v) do { if (tr && tid == 0) tr[i] = (v); } while (0)
+#else
+#define FFN_NOW() 0ull
+#define FFN_TR(i, v) do { (void)tr; } while (0)
+#endif
+void set_ffn_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_trace), &p, sizeof(p)); }
+
 // tile stream geometry (host packer below and kernel must agree)
 constexpr int FFN_TILE = 128 * 128;        // bytes: [128 rows][128 B of K]
 constexpr int FFN_PAIR = 2 * FFN_TILE;     // the kernel consumes tiles two at a time
-constexpr int FFN_RING = 3;                // pairs resident in LDS
 
 template <int D> struct FfnGeom {
+  // pairs resident in LDS.  The stream is LATENCY-bound (one workgroup per CU, ~2 us per piece under load: bytes in flight
+  // per CU set the rate), so the ring is as deep as the 160 KB allow: 4 pairs at dim 128 (3 in flight), 3 at dim 256
+  static constexpr int RING = D <= 128 ? 4 : 3;
   static constexpr int KT = D / 64;        // K tiles of ff.net.0 (= tiles of the token panel)
   static constexpr int NB = D / 32;        // 32-channel output blocks (accumulator tiles per wave)
   static constexpr int NSS = D / 32;       // super-steps of 128 hidden units (4 D hidden in all)
@@ -45,19 +78,21 @@ template <int D> struct FfnGeom {
   static constexpr int PAIRS = NSS * (KT + NB128) + PO_STEPS;
   static constexpr int PANEL = KT * 64 * 128;               // bytes: 64 tokens x D, as KT swizzled [64][128 B] tiles
   static constexpr int CONSTS = 8 * D * 8;                  // bytes: (rowsum, bias) per packed W1 row
-  static constexpr int LDS = FFN_RING * FFN_PAIR + PANEL + CONSTS;
+  static constexpr int LDS = RING * FFN_PAIR + PANEL + CONSTS;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
   static constexpr int EP = 36;                             // epilogue staging pitch (floats)
-  static_assert(2 * 4 * 32 * EP * 4 + 8 * 2 * NB * 4 * 8 <= FFN_RING * FFN_PAIR, "epilogue staging fits in the ring");
+  static_assert(2 * 2 * 4 * 32 * EP * 4 <= RING * FFN_PAIR, "epilogue staging (two 32-channel blocks) fits in the ring");
+  static_assert(NB * 512 * 8 <= PANEL, "per-lane statistics partials fit in the panel");
 };
 
 template <typename TM, int D>
 __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   op_mode_init<TM>();
   using G = FfnGeom<D>;
-  constexpr int KT = G::KT, NB = G::NB, NSS = G::NSS, NB128 = G::NB128, NP = G::PAIRS, EP = G::EP;
+  constexpr int KT = G::KT, NB = G::NB, NSS = G::NSS, NB128 = G::NB128, NP = G::PAIRS, EP = G::EP, RING = G::RING;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
-  char* const panel = smem + FFN_RING * FFN_PAIR;
+  char* const panel = smem + RING * FFN_PAIR;
   const float* const consts = reinterpret_cast<const float*>(panel + G::PANEL);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -68,7 +103,27 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   const unsigned lds0 = (unsigned)(size_t)smem;
   const int m0 = blockIdx.x * 64;
   const int mtok = m0 + 32 * tw + l31;              // this lane's token (both lane halves)
+  unsigned long long* const tr = (NS2VC_GEMM_TRACE && g_ffn_trace) ? g_ffn_trace + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long t_ff1 = 0, t_gg = 0, t_ff2 = 0, t_mark = 0;
+  FFN_TR(0, FFN_NOW());
 
+  const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * FFN_PAIR);
+  const unsigned lane16 = (unsigned)(lane * 16);
+#if NS2VC_FFN_WARM
+  // ---- L2 warm-up.  In the captured step this layer's weights are cold (every layer's weights are read once per step and
+  // 132 MB of them pass through the 4 MB L2s in between), every workgroup consumes the SAME tiles at the same pace, and a
+  // cold pair takes ~2-4 us to arrive: with two pairs in flight the stream crawled at one HBM latency per pair (52 pairs =
+  // 52 us at dim 256, whatever the kernel did in between).  So before anything else the workgroups of an XCD pull
+  // DISJOINT slices of the stream through that XCD's L2 (block b runs on XCD b % 8 -- observed placement, only speed depends
+  // on it): LDS-DMA into the last ring slot (unused until the first refill, which is issued later and therefore lands later).
+  {
+    const unsigned nx = (gridDim.x + 7) >> 3, jx = blockIdx.x >> 3;
+    const unsigned total = (unsigned)NP * FFN_PAIR;
+    const unsigned per = (((total + nx - 1) / nx) + 8191u) & ~8191u;
+    for (unsigned off = jx * per + wave * 1024; off < min(total, (jx + 1) * per); off += 8192)
+      blds16(rW, lane16, off, lds0 + (RING - 1) * FFN_PAIR + wave * 1024);
+  }
+#endif
   // ---- DMA: token panel (source-side swizzle, rows past M read as zeros), constants, then the weight stream
   {
     const int prow = 8 * wave + (lane >> 3), pchunk = lane & 7;           // one 1-KB piece per wave = 8 rows x 128 B
@@ -76,22 +131,24 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     const unsigned voff = m < a.M ? (unsigned)m * (unsigned)a.ldy * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
     const i32x4_t rY = make_rsrc(a.yn, (unsigned long long)a.M * a.ldy * 2ull);
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) blds16(rY, voff, (unsigned)(kt * 128), lds0 + FFN_RING * FFN_PAIR + kt * 8192 + wave * 1024);
+    for (int kt = 0; kt < KT; ++kt) blds16(rY, voff, (unsigned)(kt * 128), lds0 + RING * FFN_PAIR + kt * 8192 + wave * 1024);
     const i32x4_t rC = make_rsrc(a.consts, (unsigned long long)G::CONSTS);
 #pragma unroll
     for (int j = 0; j < G::CONSTS / 8192; ++j)
-      blds16(rC, (unsigned)(lane * 16), (unsigned)((j * 8 + wave) * 1024), lds0 + FFN_RING * FFN_PAIR + G::PANEL + (j * 8 + wave) * 1024);
+      blds16(rC, (unsigned)(lane * 16), (unsigned)((j * 8 + wave) * 1024), lds0 + RING * FFN_PAIR + G::PANEL + (j * 8 + wave) * 1024);
   }
-  const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * FFN_PAIR);
-  const unsigned lane16 = (unsigned)(lane * 16);
-  auto issue_pair = [&](int p) __attribute__((always_inline)) {           // 32 pieces of 1 KB: four per wave, all addresses scalar
-    const int slot = p % FFN_RING;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      blds16(rW, lane16, (unsigned)(p * FFN_PAIR + (j * 8 + wave) * 1024), lds0 + slot * FFN_PAIR + (j * 8 + wave) * 1024);
+  // a pair = 32 pieces of 1 KB: four per wave, all addresses scalar
+  auto issue_piece = [&](int p, int j) __attribute__((always_inline)) {
+    const int slot = p % RING;
+    blds16(rW, lane16, (unsigned)(p * FFN_PAIR + (j * 8 + wave) * 1024), lds0 + slot * FFN_PAIR + (j * 8 + wave) * 1024);
   };
-  issue_pair(0);
-  if (NP > 1) issue_pair(1);
+  auto issue_pair = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issue_piece(p, j);
+  };
+#pragma unroll
+  for (int q = 0; q < RING - 1; ++q)
+    if (q < NP) issue_pair(q);
 
   // ---- LayerNorm statistics of this lane's token (ordinary loads: the compiler waits for them -- and, not seeing the
   // DMA above, for everything issued so far: that is the prologue's wait for the first tiles anyway)
@@ -120,15 +177,21 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   for (int i = 0; i < NB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accO[i][r] = 0.f;
+  FFN_TR(1, FFN_NOW());
 
   int p = 0;                                        // next pair to consume
   auto step_begin = [&]() __attribute__((always_inline)) -> const char* {
-    // pair p has landed when only the four pieces of pair p+1 may still be in flight
-    if (p + 1 < NP) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    // pair p has landed when only the pieces (four per wave and pair) of the RING - 2 pairs behind it may still be in flight
+    const int after = min(RING - 2, NP - 1 - p);
+    if (RING >= 4 && after >= 2) wait_vmcnt<8>();
+    else if (after >= 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragment reads of the slot about to be refilled are done
     __builtin_amdgcn_s_barrier();
-    if (p + 2 < NP) issue_pair(p + 2);                         // into the slot of pair p-1, free for everyone after the barrier
-    return ring + (p % FFN_RING) * FFN_PAIR;
+    // refill: pair p + RING - 1 into the slot of pair p-1, free for everyone after the barrier.  (Issuing the four
+    // pieces one by one between the MFMA groups instead was measured slower: 4.44 vs 4.32 ms/step same-box.)
+    if (p + RING - 1 < NP) issue_pair(p + RING - 1);
+    return ring + (p % RING) * FFN_PAIR;
   };
   const char* const bpanel = panel + (32 * tw + l31) * 128;    // this lane's token row inside a panel tile (+ kt * 8192)
 
@@ -138,22 +201,31 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     f32x16_t av, ag;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { av[r] = 0.f; ag[r] = 0.f; }
+    t_mark = FFN_NOW();
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
       const char* T = step_begin();
-      ++p;
       const char* wrow = T + (hw >> 1) * FFN_TILE + (64 * (hw & 1) + l31) * 128;      // value row; gate row = + 32 rows
+      // all twelve fragment reads of the step are issued before its first MFMA (left to itself the compiler issues two
+      // reads per MFMA and waits for them: ~180 exposed cycles of LDS latency per MFMA, 1700 cycles per step at dim 256)
+      u32x4_t fb[4], fv[4], fg[4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int c = ((2 * ks + hi) ^ sw) * 16;
-        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(bpanel + kt * 8192 + c);
-        const u32x4_t wv = *reinterpret_cast<const u32x4_t*>(wrow + c);
-        const u32x4_t wg = *reinterpret_cast<const u32x4_t*>(wrow + 32 * 128 + c);
-        MmaT<TM>::mma(av, wv, b);
-        MmaT<TM>::mma(ag, wg, b);
+        fb[ks] = *reinterpret_cast<const u32x4_t*>(bpanel + kt * 8192 + c);
+        fv[ks] = *reinterpret_cast<const u32x4_t*>(wrow + c);
+        fg[ks] = *reinterpret_cast<const u32x4_t*>(wrow + 32 * 128 + c);
       }
+      FFN_FRAG_FENCE();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        MmaT<TM>::mma(av, fv[ks], fb[ks]);
+        MmaT<TM>::mma(ag, fg[ks], fb[ks]);
+      }
+      ++p;
     }
     // ---- LayerNorm fix-up + bias + GEGLU in registers; register r <-> unit (r&3) + 8 (r>>2) + 4 hi of this wave's 32
+    if (NS2VC_GEMM_TRACE) { asm volatile("" : "+v"(av), "+v"(ag)); const unsigned long long t = FFN_NOW(); t_ff1 += t - t_mark; t_mark = t; }
     u32x4_t hf[2];
     {
       const float* cv = consts + (size_t)(256 * ss + 64 * hw) * 2;           // (rowsum, bias) of the value rows; gate rows = + 32
@@ -179,25 +251,32 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
                         Op16<TM>::pack(h[8 * s + 4], h[8 * s + 5]), Op16<TM>::pack(h[8 * s + 6], h[8 * s + 7])};
     }
     // ---- O^T[n][token] += W2'[n][this wave's 32 units] h^T : 32 units = half of a 64-unit tile
+    if (NS2VC_GEMM_TRACE) { asm volatile("" : "+v"(hf[0]), "+v"(hf[1])); const unsigned long long t = FFN_NOW(); t_gg += t - t_mark; t_mark = t; }
 #pragma unroll
     for (int nb = 0; nb < NB128; ++nb) {
       const char* T = step_begin();
-      ++p;
       const char* wrow = T + (hw >> 1) * FFN_TILE + l31 * 128;
+      u32x4_t fw[2][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const u32x4_t w = *reinterpret_cast<const u32x4_t*>(wrow + i * 32 * 128 + ((4 * (hw & 1) + 2 * s + hi) ^ sw) * 16);
-          MmaT<TM>::mma(accO[4 * nb + i], w, hf[s]);
-        }
+        for (int i = 0; i < 4; ++i)
+          fw[s][i] = *reinterpret_cast<const u32x4_t*>(wrow + i * 32 * 128 + ((4 * (hw & 1) + 2 * s + hi) ^ sw) * 16);
+      FFN_FRAG_FENCE();
+#pragma unroll
+      for (int s = 0; s < 2; ++s)            // (s outer: four independent accumulators between two MFMAs on the same one)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) MmaT<TM>::mma(accO[4 * nb + i], fw[s][i], hf[s]);
+      ++p;
     }
+    if (NS2VC_GEMM_TRACE) { asm volatile("" : "+v"(accO[0])); const unsigned long long t = FFN_NOW(); t_ff2 += t - t_mark; }
   }
   // ---- the Wpo segment: O^T += Wpo y^T; wave hw takes k-slab hw of every 64-wide K tile
+  FFN_TR(2, t_ff1); FFN_TR(3, t_gg); FFN_TR(4, t_ff2);
+  t_mark = FFN_NOW();
 #pragma unroll
   for (int j = 0; j < G::PO_STEPS; ++j) {
     const char* T = step_begin();
-    ++p;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int q = 2 * j + t, nb = q / KT, kt = q % KT;                     // (compile-time after unrolling)
@@ -209,18 +288,19 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
         MmaT<TM>::mma(accO[4 * nb + i], w, b);
       }
     }
+    ++p;
   }
 
   // ---- epilogue: the four hidden-group partials of a token half meet in LDS (re-using the ring); 512 lanes = 2 halves x
   // 32 tokens x 8 channel quads take one float4 each per 32-channel block: bias, residual, stores, GroupNorm statistics
   __syncthreads();
-  float* const E = reinterpret_cast<float*>(ring);
-  double* const S = reinterpret_cast<double*>(ring + 2 * 4 * 32 * EP * 4);     // [wave][2 NB blocks][2 items][2 moments]
+  if (NS2VC_GEMM_TRACE) { const unsigned long long t = FFN_NOW(); FFN_TR(5, t - t_mark); t_mark = t; }
+  float* const E = reinterpret_cast<float*>(ring);        // [2 blocks][token half][hidden group][32 tokens][EP] partial tiles
+  float2* const P = reinterpret_cast<float2*>(panel);     // [NB][512 lanes] (sum, sum of squares) of each lane's float4 (panel is free now)
+  constexpr int EBLK = 2 * 4 * 32 * EP;                   // floats per staged 32-channel block
   const int L = tid, eth = L >> 8, etok = (L >> 3) & 31, equad = L & 7;
   const int em = m0 + 32 * eth + etok;
   const bool eok = em < a.M;
-  const int b0 = min(m0, a.M - 1) / a.T;                 // first batch item of this 64-token block (T >= 64: at most two)
-  const int mB = (b0 + 1) * a.T;
   float4 rr[NB];                                          // residual rows + bias: every load in flight before the first store
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -232,54 +312,68 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   const float* const Er = E + (eth * 4 * 32 + etok) * EP + 4 * equad;
   TM* const oo = reinterpret_cast<TM*>(a.out_op);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    if (nb) __syncthreads();
+  for (int r2 = 0; r2 < NB / 2; ++r2) {                   // two 32-channel blocks per barrier pair
+    if (r2) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<float4*>(Ew + 8 * j) = make_float4(accO[nb][4 * j], accO[nb][4 * j + 1], accO[nb][4 * j + 2], accO[nb][4 * j + 3]);
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(Ew + u * EBLK + 8 * j) =
+            make_float4(accO[2 * r2 + u][4 * j], accO[2 * r2 + u][4 * j + 1], accO[2 * r2 + u][4 * j + 2], accO[2 * r2 + u][4 * j + 3]);
     __syncthreads();
-    float4 v = *reinterpret_cast<const float4*>(Er);
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const float4 u = *reinterpret_cast<const float4*>(Er + k * 32 * EP);
-      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    const int n = 32 * nb + 4 * equad;
-    float ps = 0.f, pq = 0.f;
-    if (eok) {
-      v.x += rr[nb].x; v.y += rr[nb].y; v.z += rr[nb].z; v.w += rr[nb].w;
-      if (a.out_f32) out_f4(a.out_f32 + (size_t)em * a.ldo_f32 + n, v.x, v.y, v.z, v.w);
-      if (oo) out_op4<TM>(oo + (size_t)em * a.ldo_op + n, v.x, v.y, v.z, v.w);
-      ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-    }
-    if (a.stats) {
-      // fixed shuffle tree inside the wave (8 tokens x 8 quads): the 4 quads of a 16-channel block, then the 8 tokens
-      double d0 = (eok && em < mB) ? ps : 0.0, d1 = (eok && em < mB) ? pq : 0.0;
-      double d2 = (eok && em >= mB) ? ps : 0.0, d3 = (eok && em >= mB) ? pq : 0.0;
+    for (int u = 0; u < 2; ++u) {
+      const int nb = 2 * r2 + u;
+      float4 v = *reinterpret_cast<const float4*>(Er + u * EBLK);
 #pragma unroll
-      for (int o = 1; o <= 2; o <<= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
-      if ((lane & 59) == 0) {                          // lanes 0 and 4: first token lane of channel quads 0-3 / 4-7
-        double* sp = S + ((wave * 2 * NB) + 2 * nb + (lane >> 2)) * 4;
-        sp[0] = d0; sp[1] = d1; sp[2] = d2; sp[3] = d3;
+      for (int k = 1; k < 4; ++k) {
+        const float4 w = *reinterpret_cast<const float4*>(Er + u * EBLK + k * 32 * EP);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
       }
+      const int n = 32 * nb + 4 * equad;
+      float ps = 0.f, pq = 0.f;
+      if (eok) {
+        v.x += rr[nb].x; v.y += rr[nb].y; v.z += rr[nb].z; v.w += rr[nb].w;
+        if (a.out_f32) out_f4(a.out_f32 + (size_t)em * a.ldo_f32 + n, v.x, v.y, v.z, v.w);
+        if (oo) out_op4<TM>(oo + (size_t)em * a.ldo_op + n, v.x, v.y, v.z, v.w);
+        ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      if (a.stats) P[nb * 512 + L] = make_float2(ps, pq);
     }
   }
   if (a.stats) {
+    // GroupNorm statistics of the result: per 16-channel block, the 64 tokens x 4 channel quads are summed in a FIXED order
+    // (lane partials above -> per-token sums -> shuffle tree over the tokens) and leave as ONE int64 fixed-point atomic
+    // per (batch item, block, moment): deterministic, 8 .. 64 atomics per workgroup
     __syncthreads();
-    if (tid < 2 * NB * 4) {                            // one thread per (16-channel block, item slot, moment): waves summed in fixed order
-      const int blk = tid >> 2, which = tid & 3;
-      double acc = 0.0;
+    constexpr int TPB = 512 / (2 * NB);                   // threads per 16-channel block: 64 (dim 128) / 32 (dim 256)
+    constexpr int TPT = 64 / TPB;                         // tokens per thread
+    const int blk = tid / TPB, tl = tid % TPB;
+    const int b0 = min(m0, a.M - 1) / a.T;                // first batch item of this 64-token block (T >= 64: at most two)
+    const int mB = (b0 + 1) * a.T;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) acc += S[((w * 2 * NB) + blk) * 4 + which];
-      const int item = which >> 1, moment = which & 1;
-      if (item == 0 || (mB < a.M && mB < m0 + 64)) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(a.stats) + ((size_t)(b0 + item) * (D / 16) + blk) * 2 + moment;
-        atomicAdd(st, (unsigned long long)llrint(acc * (moment ? GN_SQ_SCALE : GN_SUM_SCALE)));
+    for (int k = 0; k < TPT; ++k) {
+      const int tok = tl * TPT + k;                       // 0..63 inside the block of tokens
+      const float2* pp = P + (blk >> 1) * 512 + (tok >> 5) * 256 + (tok & 31) * 8 + 4 * (blk & 1);
+      float ss = 0.f, qq = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const float2 v = pp[c]; ss += v.x; qq += v.y; }
+      if (m0 + tok < mB) { s0 += ss; q0 += qq; } else { s1 += ss; q1 += qq; }
+    }
+#pragma unroll
+    for (int o = 1; o < TPB; o <<= 1) { s0 += __shfl_xor(s0, o); q0 += __shfl_xor(q0, o); s1 += __shfl_xor(s1, o); q1 += __shfl_xor(q1, o); }
+    if (tl == 0) {
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(a.stats) + ((size_t)b0 * (D / 16) + blk) * 2;
+      atomicAdd(st, (unsigned long long)llrint((double)s0 * GN_SUM_SCALE));
+      atomicAdd(st + 1, (unsigned long long)llrint((double)q0 * GN_SQ_SCALE));
+      if (mB < a.M && mB < m0 + 64) {
+        atomicAdd(st + 2 * (D / 16), (unsigned long long)llrint((double)s1 * GN_SUM_SCALE));
+        atomicAdd(st + 2 * (D / 16) + 1, (unsigned long long)llrint((double)q1 * GN_SQ_SCALE));
       }
     }
   }
+  if (NS2VC_GEMM_TRACE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long t = FFN_NOW(); FFN_TR(6, t - t_mark); FFN_TR(7, t); }
 }
 
 // ---------------------------------------------------------------------------
