@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
   const int half = tdim >> 1;
   for (int i = tid; i < half; i += 256) {
     const float expo = (-9.210340371976184f * (float)i) / (float)half;
-    const float f = (float)exp((double)expo);
+    const float f = (float)exp((double)expo);          // (double: the reference's torch.exp of a float32 tensor is correctly rounded)
     const float ang = t * f;
     s_sin[i] = cosf(ang);
     s_sin[half + i] = sinf(ang);
@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
   __syncthreads();
   for (int o = tid; o < edim; o += 256) {
     float y0 = b1[o], y1 = 0.f, y2 = 0.f, y3 = 0.f;
+#pragma unroll 8                                          // 32 independent weight loads in flight: the loop was one L2 round trip per 4 MACs
     for (int i = 0; i < tdim; i += 4) {
       y0 += w1t[(size_t)i * edim + o] * s_sin[i];
       y1 += w1t[(size_t)(i + 1) * edim + o] * s_sin[i + 1];
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
     float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
     const float* wp = w2t + (size_t)(ks * kn) * edim + o;
     const float* hp = s_h + ks * kn;
+#pragma unroll 8
     for (int i = 0; i < kn; i += 4) {
       y0 += wp[(size_t)i * edim] * hp[i];
       y1 += wp[(size_t)(i + 1) * edim] * hp[i + 1];
