@@ -1,0 +1,82 @@
+"""Batched voice-conversion service on top of the denoiser engine -- SURVEY 8(f) rank 3.
+
+The reference's ``Svc.infer`` (``inference/infer_tool.py:189-206``) converts ONE audio segment per call (batch 1,
+``infer.py:99-140`` loops over the slicer's segments).  Here segments are converted in batches:
+
+* segments are grouped by their latent length T.  The reference applies no masking to padded LATENT frames (no
+  self-attention / GroupNorm mask, ``model.py:411`` is commented out), so padding a shorter segment would change its
+  result; grouping EQUAL lengths keeps every segment's result what a batch-1 run gives (to within the precision's
+  rounding noise).  Prompts (reference clips) may have any length inside a group: they are padded and masked, which the
+  reference supports (``encoder_attention_mask``).
+* each group runs ``PreModel.infer`` -> ``Denoiser.sample`` -> ``decode_fn`` through ``OverlappedPipeline``: the
+  PyTorch-ROCm front / back end of group k+1 / k-1 overlaps the HIP denoiser of group k on their own streams.
+
+``decode_fn(latent (B, 100, T)) -> audio (B, samples)`` is the vocoder (Vocos in the reference, ``model.py:689-691``;
+not a dependency of this repository: pass ``vocos.decode``); with ``decode_fn=None`` the latents are returned.
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from .frontend import PreModel
+from .pipeline import Denoiser, OverlappedPipeline
+
+
+@dataclass
+class Segment:
+    """one unit of work: ContentVec features (256, T) already repeat-expanded to the mel frame rate
+    (``utils.repeat_expand_2d``, ``infer_tool.py:158-168``) and the reference mel (100, Lp) (``infer_tool.py:170-182``)"""
+    content: torch.Tensor
+    refer: torch.Tensor
+    tag: object = None
+
+
+class GroupedConverter:
+    def __init__(self, pre_model: PreModel, denoiser: Denoiser, decode_fn: Optional[Callable] = None, max_batch: int = 32,
+                 solver: str = "unipc", steps: int = 30, order: int = 2, seed: int = 1234):
+        self.pre, self.den, self.decode = pre_model, denoiser, decode_fn
+        self.max_batch, self.seed = max_batch, seed
+        self.kw = dict(solver=solver, steps=steps, order=order)
+
+    def plan(self, segments: Sequence[Segment]) -> List[List[int]]:
+        """indices of `segments` grouped by latent length, groups of at most ``max_batch``, longest first"""
+        by_len: Dict[int, List[int]] = defaultdict(list)
+        for i, s in enumerate(segments):
+            by_len[int(s.content.shape[-1])].append(i)
+        groups = []
+        for T in sorted(by_len, reverse=True):
+            idx = by_len[T]
+            groups += [idx[k:k + self.max_batch] for k in range(0, len(idx), self.max_batch)]
+        return groups
+
+    def convert(self, segments: Sequence[Segment]) -> List[torch.Tensor]:
+        """returns one tensor per segment, in input order: audio (samples,) with a ``decode_fn``, else the latent (100, T)"""
+        dev = next(self.pre.parameters()).device
+        groups = self.plan(segments)
+
+        def pre_fn(idx):
+            T = int(segments[idx[0]].content.shape[-1])
+            Lp = max(int(segments[i].refer.shape[-1]) for i in idx)
+            c = torch.stack([segments[i].content.to(dev, torch.float32) for i in idx])
+            refer = torch.zeros((len(idx), segments[idx[0]].refer.shape[0], Lp), device=dev)
+            lens = [int(segments[i].refer.shape[-1]) for i in idx]
+            for b, i in enumerate(idx):
+                refer[b, :, :lens[b]] = segments[i].refer.to(dev, torch.float32)
+            content, prompt, mask = self.pre.infer(c, refer, torch.full((len(idx),), T, device=dev), torch.tensor(lens, device=dev))
+            # x_T per SEGMENT (seeded by its position in the input), so a segment's result does not depend on its group
+            noise = torch.stack([torch.randn((100, T), generator=torch.Generator().manual_seed(self.seed + i)) for i in idx]).to(dev)
+            return {"content": content, "prompt": prompt, "prompt_mask": mask, "noise": noise}
+
+        def post_fn(latent, idx):
+            return latent if self.decode is None else self.decode(latent)
+
+        outs = OverlappedPipeline(self.den, pre_fn, post_fn, **self.kw).run(groups)
+        result: List[Optional[torch.Tensor]] = [None] * len(segments)
+        for idx, o in zip(groups, outs):
+            for b, i in enumerate(idx):
+                result[i] = o[b]
+        return result

@@ -258,6 +258,64 @@ def test_text_time_embedding_matches_reference_golden():
         assert rel_l2(y, g[f"{tag}.y"]) < 1e-5, tag
 
 
+def test_frontend_pre_model_matches_reference_golden():
+    """ns2vc_amd.frontend.PreModel (the PyTorch-ROCm conditioning stage) against outputs of the
+    reference's own Pre_model.infer (model.py:359-376) on a ragged batch: same state-dict names (strict load of the
+    reference's key list), content / prompt within fp32 noise, padded frames exactly zero."""
+    import json
+    import torch
+    from ns2vc_amd.frontend import PreModel
+    from ns2vc_amd.weights import hash_normal
+    from util import procedural_params
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "pre_model_state_keys.json")))
+    cfg = {"phoneme_encoder": {"in_channels": 256, "hidden_channels": 256, "out_channels": 256, "n_layers": 6, "p_dropout": 0.2},
+           "prompt_encoder": {"in_channels": 100, "hidden_channels": 256, "out_channels": 256, "n_layers": 6, "p_dropout": 0.2}}
+    m = PreModel(cfg).eval()
+    assert sorted(k for k, _ in keys["keys"]) == sorted(m.state_dict().keys())     # exactly the reference's 251 names
+    assert keys["n_params"] == sum(p.numel() for p in m.parameters()) == 34923404     # demo.ipynb:447 "pre params"
+    m.load_state_dict(procedural_params(keys["keys"], "pre"), strict=True)
+    B, T, Lp = 2, 65, 40
+    lengths, rlens = torch.from_numpy(g["g10.lengths"]), torch.from_numpy(g["g10.refer_lengths"])
+    c = torch.from_numpy(hash_normal("g10.c", (B, 256, T))) * (torch.arange(T)[None, None, :] < lengths[:, None, None])
+    refer = torch.from_numpy(hash_normal("g10.refer", (B, 100, Lp))) * (torch.arange(Lp)[None, None, :] < rlens[:, None, None])
+    content, prompt, mask = m.infer(c, refer, lengths, rlens)
+    assert content.shape == (B, 256, T) and prompt.shape == (B, Lp, 256) and mask.shape == (B, Lp)
+    assert rel_l2(content.numpy(), g["g10.content"]) < 1e-5 and rel_l2(prompt.numpy(), g["g10.prompt"]) < 1e-5
+    assert float(content[1, :, 50:].abs().max()) == 0.0 and float(prompt[1, 27:].abs().max()) == 0.0
+    assert mask[1].sum() == 27
+
+
+def test_dropin_training_path_matches_reference_and_backpropagates():
+    """train.py drop-in (SURVEY 8(b) 'Threading / streams'): under autograd the drop-in module evaluates with PyTorch ops
+    (unet1d/torch_path.py).  Forward == the reference golden (g3b: B=2, odd T, ragged mask), gradients reach every one of
+    the 701 parameters, and the no-grad inference path still refuses CPU tensors (no CPU fallback)."""
+    import torch
+    from unet1d import UNet1DConditionModel
+    from ns2vc_amd.weights import hash_normal, procedural_state_dict
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    m = UNet1DConditionModel(in_channels=356, out_channels=100, block_out_channels=(128, 256, 384, 512), norm_num_groups=8,
+                             cross_attention_dim=256, attention_head_dim=8, addition_embed_type="text", resnet_time_scale_shift="scale_shift")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in procedural_state_dict(seed=0).items()}, strict=True)
+    m.train()
+    B, T, Lp = 2, 37, 21
+    x = torch.from_numpy(hash_normal("g3b.x", (B, 100, T)))
+    content = torch.from_numpy(hash_normal("g3b.content", (B, 256, T)))
+    prompt = torch.from_numpy(hash_normal("g3b.prompt", (B, Lp, 256)))
+    mask = torch.arange(Lp)[None, :] < torch.tensor([21, 13])[:, None]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = m(torch.cat([x, content], dim=1), torch.tensor([499.50003, 499.50003]), prompt, encoder_attention_mask=mask).sample
+    assert m.autograd_calls == 1 and m.engine_calls == 0
+    assert rel_l2(out.detach().numpy(), gold["g3b.y"]) < 2e-5
+    out.square().mean().backward()
+    missing = [n for n, p in m.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing[:5]
+    assert sum(float(p.grad.abs().sum()) > 0 for p in m.parameters()) >= 690      # (a few biases can see exactly zero gradient)
+    m.eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU inference path"):
+        m(torch.cat([x, content], dim=1), 3, prompt)
+
+
 # ---- C ABI ------------------------------------------------------------------------------
 def test_cabi_library_exports_every_declared_symbol():
     from ns2vc_amd import _lib

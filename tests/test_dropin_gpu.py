@@ -44,8 +44,12 @@ def test_dropin_module_forward_matches_reference_golden(state, diag):
     e = rel_l2(out.sample.cpu().numpy(), gold["g3b.y"])
     diag(f"drop-in nn.Module forward (fp32 engine) vs reference golden: {e:.3e}")
     assert e < 1e-3 and isinstance(tup, tuple) and rel_l2(tup[0].cpu().numpy(), gold["g3b.y"]) < 1e-3
-    with pytest.raises(NotImplementedError):       # autograd / training is out of scope and must fail loudly
-        m(torch.cat([x, content], dim=1), 3, prompt)
+    assert m.engine_calls == 2 and m.autograd_calls == 0          # inference ran on the HIP engine, not on the training path
+    y_train = m(torch.cat([x, content], dim=1), torch.tensor([499.50003, 499.50003]).cuda(), prompt, encoder_attention_mask=mask).sample
+    assert m.autograd_calls == 1 and y_train.requires_grad        # autograd recording -> PyTorch-ROCm ops (train.py drop-in)
+    e_train = rel_l2(y_train.detach().cpu().numpy(), gold["g3b.y"])
+    diag(f"drop-in nn.Module under autograd (PyTorch-ROCm training path) vs reference golden: {e_train:.3e}")
+    assert e_train < 1e-3
     # weights edited in place are picked up (the engine re-packs when a parameter version changes)
     with torch.no_grad():
         m.conv_out.bias.add_(1.0)

@@ -1,0 +1,159 @@
+"""GPU tests of the stages either side of the denoiser: the PyTorch-ROCm ``PreModel`` on the
+device against the reference golden, the real front end inside the three-stream pipeline, and the batched converter that
+groups equal-length segments (reference: one segment per call, inference/infer_tool.py:189-206)."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from util import procedural_params, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRE_CFG = {"phoneme_encoder": {"in_channels": 256, "hidden_channels": 256, "out_channels": 256, "n_layers": 6, "p_dropout": 0.2},
+           "prompt_encoder": {"in_channels": 100, "hidden_channels": 256, "out_channels": 256, "n_layers": 6, "p_dropout": 0.2}}
+
+
+@pytest.fixture(scope="module")
+def weights():
+    from ns2vc_amd.weights import procedural_state_dict
+    return procedural_state_dict(seed=0)
+
+
+@pytest.fixture(scope="module")
+def pre_model():
+    import torch
+    from ns2vc_amd.frontend import PreModel
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "pre_model_state_keys.json")))
+    m = PreModel(PRE_CFG).eval()
+    m.load_state_dict(procedural_params(keys["keys"], "pre"), strict=True)
+    return m.to(torch.device("cuda", 0))
+
+
+def _segments(lengths, refer_lengths, tag="svc"):
+    import torch
+    from ns2vc_amd.service import Segment
+    from ns2vc_amd.weights import hash_normal
+    return [Segment(torch.from_numpy(hash_normal(f"{tag}.c{i}", (256, T))), torch.from_numpy(hash_normal(f"{tag}.r{i}", (100, L))), tag=i)
+            for i, (T, L) in enumerate(zip(lengths, refer_lengths))]
+
+
+def test_frontend_on_device_matches_reference_golden(pre_model, diag):
+    """the conditioning front end on the MI355X (rocBLAS / SDPA kernels) against the reference's Pre_model.infer outputs"""
+    import torch
+    from ns2vc_amd.weights import hash_normal
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v2.npz"))
+    dev = torch.device("cuda", 0)
+    B, T, Lp = 2, 65, 40
+    lengths, rlens = torch.from_numpy(g["g10.lengths"]).to(dev), torch.from_numpy(g["g10.refer_lengths"]).to(dev)
+    c = torch.from_numpy(hash_normal("g10.c", (B, 256, T))).to(dev) * (torch.arange(T, device=dev)[None, None, :] < lengths[:, None, None])
+    refer = torch.from_numpy(hash_normal("g10.refer", (B, 100, Lp))).to(dev) * (torch.arange(Lp, device=dev)[None, None, :] < rlens[:, None, None])
+    content, prompt, mask = pre_model.infer(c, refer, lengths, rlens)
+    e = rel_l2(content.cpu().numpy(), g["g10.content"]), rel_l2(prompt.cpu().numpy(), g["g10.prompt"])
+    diag(f"frontend on device vs reference Pre_model.infer: content {e[0]:.2e} prompt {e[1]:.2e}")
+    assert max(e) < 1e-4                                  # fp32 library kernels: accumulation order differs from the CPU reference
+    assert float(content[1, :, 50:].abs().max()) == 0.0 and float(prompt[1, 27:].abs().max()) == 0.0 and int(mask[1].sum()) == 27
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("fp16", 2e-3)])
+def test_grouped_converter_equals_per_segment_runs(pre_model, precision, tol, diag):
+    """batched conversion == one-segment-at-a-time conversion (the reference's batch-1 loop): segments are grouped by latent
+    length (no padded latent frames, so no change of semantics), prompts inside a group are ragged (padded + masked).
+    fp32 agrees to accumulation noise; the 16-bit mode to its rounding noise (a batched and a single run round
+    differently: DESIGN.md 'batch independence')."""
+    import torch
+    from ns2vc_amd.pipeline import Denoiser
+    from ns2vc_amd.service import GroupedConverter
+    from ns2vc_amd.weights import procedural_state_dict
+    den = Denoiser(procedural_state_dict(seed=0), precision=precision)
+    lengths = [96, 130, 96, 64, 130, 96, 96]
+    rlens = [40, 64, 33, 64, 17, 64, 50]
+    segs = _segments(lengths, rlens)
+    conv = GroupedConverter(pre_model, den, max_batch=3, solver="unipc", steps=6)
+    groups = conv.plan(segs)
+    assert groups == [[1, 4], [0, 2, 5], [6], [3]]                      # longest first, at most max_batch, input order inside
+    out = conv.convert(segs)
+    one = GroupedConverter(pre_model, den, max_batch=1, solver="unipc", steps=6).convert(segs)
+    errs = []
+    for i, (a, b) in enumerate(zip(out, one)):
+        assert a.shape == (100, lengths[i]) and torch.isfinite(a).all()
+        errs.append(rel_l2(a.cpu().numpy(), b.cpu().numpy()))
+    diag(f"grouped converter ({precision}) vs per-segment runs: max rel {max(errs):.3e}")
+    assert max(errs) < tol
+
+
+def test_grouped_converter_segment_vs_oracle(pre_model, weights, diag):
+    """one converted segment against the CPU oracle's sampler fed the same front-end outputs: the service adds grouping and
+    stream plumbing, not arithmetic"""
+    import torch
+    from ns2vc_amd.pipeline import Denoiser
+    from ns2vc_amd.service import GroupedConverter
+    from ns2vc_amd.spec import UNetConfig
+    from oracle import sampler_ref, unet_ref
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    den = Denoiser(weights, precision="fp32")
+    segs = _segments([80, 80, 112], [32, 48, 20], tag="svc2")
+    out = GroupedConverter(pre_model, den, max_batch=4, solver="unipc", steps=5, seed=7).convert(segs)
+    i, T = 1, 80
+    dev = torch.device("cuda", 0)
+    content, prompt, mask = pre_model.infer(segs[i].content[None].to(dev), segs[i].refer[None].to(dev), torch.tensor([T], device=dev),
+                                            torch.tensor([48], device=dev))
+    P = {k: torch.from_numpy(v) for k, v in weights.items()}
+    xT = torch.randn((100, T), generator=torch.Generator().manual_seed(7 + i))[None]
+    tc, tp, tm = content.cpu(), prompt.cpu(), mask.cpu()
+    ref = sampler_ref.unipc_bh2(lambda xx, tt: unet_ref.denoiser(P, UNetConfig(), xx, tc, tp, tm, tt), sampler_ref.linear_betas(1000), xT, 5)
+    e = rel_l2(out[i].cpu().numpy(), ref[0].numpy())
+    diag(f"grouped converter segment vs oracle sampler (fp32 engine): {e:.3e}")
+    assert e < 1e-4
+
+
+def test_pipeline_with_real_front_end_end_to_end_rtf(pre_model, diag):
+    """BASELINE config-3 shape (32 x 10 s, 20-step UniPC) with the REAL conditioning front end as the pipeline's first stage:
+    end-to-end (front end + denoiser) wall time per batch beside the denoiser alone, sequential and stream-overlapped."""
+    import torch
+    from ns2vc_amd.pipeline import Denoiser, OverlappedPipeline
+    from ns2vc_amd.weights import procedural_state_dict
+    dev = torch.device("cuda", 0)
+    den = Denoiser(procedural_state_dict(seed=0))
+    B, T, Lp, steps, n_batches = 32, 938, 469, 20, 4
+    g = torch.Generator(device=dev).manual_seed(5)
+    c = torch.randn((B, 256, T), device=dev, generator=g)
+    refer = torch.randn((B, 100, Lp), device=dev, generator=g)
+    lengths, rlens = torch.full((B,), T, device=dev), torch.full((B,), Lp, device=dev)
+    noise = torch.randn((B, 100, T), device=dev, generator=g)
+
+    def pre_fn(k):
+        content, prompt, mask = pre_model.infer(c, refer, lengths, rlens)
+        return {"content": content, "prompt": prompt, "prompt_mask": mask, "noise": noise}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return r, time.perf_counter() - t0
+
+    cond = pre_fn(0)
+    den.sample(**{"content": cond["content"], "prompt": cond["prompt"], "prompt_mask": cond["prompt_mask"], "noise": noise}, solver="unipc", steps=steps)
+    _, t_pre = timed(lambda: [pre_fn(k) for k in range(n_batches)])
+    _, t_den = timed(lambda: [den.sample(cond["content"], cond["prompt"], cond["prompt_mask"], noise, solver="unipc", steps=steps) for _ in range(n_batches)])
+
+    def sequential():
+        outs = []
+        for k in range(n_batches):
+            cd = pre_fn(k)
+            outs.append(den.sample(cd["content"], cd["prompt"], cd["prompt_mask"], cd["noise"], solver="unipc", steps=steps))
+        return outs
+    seq, t_seq = timed(sequential)
+    pipe = OverlappedPipeline(den, pre_fn, lambda latent, k: latent, solver="unipc", steps=steps)
+    pipe.run([0])
+    ovl, t_ovl = timed(lambda: pipe.run(list(range(n_batches))))
+    for a, b in zip(ovl, seq):
+        assert torch.equal(a, b)
+    audio_s = n_batches * B * T * 256 / 24000.0
+    diag(f"end-to-end, {n_batches} batches of 32 x 10 s, 20-step UniPC: front end alone {t_pre / n_batches * 1e3:.1f} ms/batch, denoiser alone "
+         f"{t_den / n_batches * 1e3:.1f} ms/batch, sequential {t_seq / n_batches * 1e3:.1f} ms/batch (RTF {t_seq / audio_s:.2e}), "
+         f"overlapped {t_ovl / n_batches * 1e3:.1f} ms/batch (RTF {t_ovl / audio_s:.2e}); denoiser-only RTF {t_den / audio_s:.2e}")
+    assert t_ovl < 1.10 * t_seq

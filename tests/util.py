@@ -76,3 +76,23 @@ def tte_state(prefix: str, dim: int, out_dim: int) -> dict:
         sd[f"pool.{p}.weight"] = s * hash_normal(prefix + p + "w", (dim, dim))
         sd[f"pool.{p}.bias"] = 0.1 * hash_normal(prefix + p + "b", (dim,))
     return {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in sd.items()}
+
+
+def procedural_params(shapes, tag: str) -> dict:
+    """deterministic parameters for a {name: shape} list (torch tensors): matrices ~ N(0, 1/fan_in), norm weights ~ 1,
+    biases / vectors ~ 0.1 N(0, 1); the same integer-hash generator as the denoiser's procedural weights"""
+    import torch
+    from ns2vc_amd.weights import hash_normal
+    out = {}
+    for name, shape in shapes:
+        shape = tuple(shape)
+        v = hash_normal(f"{tag}.{name}", shape)
+        if len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:])) if "conv.weight" not in name else shape[0] * shape[1]
+            v = v / np.sqrt(max(fan_in, 1))
+        elif "norm" in name and name.endswith("weight"):
+            v = 1.0 + 0.1 * v
+        else:
+            v = 0.1 * v
+        out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out

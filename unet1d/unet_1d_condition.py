@@ -8,8 +8,11 @@ Boundary kept:
   * ``forward(sample, timestep, encoder_hidden_states, ..., encoder_attention_mask=,
     return_dict=)`` -> object with ``.sample`` (``:743-757, 1034-1037``).
 
-The forward itself is NOT PyTorch: it hands device pointers to libns2vc_hip.so.
-There is no CPU path and no autograd path — both raise.  The fast path for sampling
+The inference forward is NOT PyTorch: it hands device pointers to libns2vc_hip.so;
+without a GPU / with CPU tensors it raises (there is no CPU inference path).  TRAINING
+(autograd recording: ``model.py:720`` under ``Trainer.train``) is the one case routed to
+plain PyTorch ops (``unet1d/torch_path.py``) so that ``train.py`` stays drop-in; the
+counters ``engine_calls`` / ``autograd_calls`` tell which path ran.  The fast path for sampling
 is ``ns2vc_amd.pipeline.Denoiser`` (captured loop, condition hoisted once).  Here the
 reference API concatenates x and content into a NEW ``sample`` tensor on every solver
 step (``model.py:409``), so the content half of conv_in is redone per call, but the
@@ -102,6 +105,9 @@ class UNet1DConditionModel(nn.Module):
         self._prompt_key = None         # ((data_ptr, _version, shape) of prompt and mask) the engine's prompt half was built from
         self._prompt_hold = None        # ... and the tensors themselves: while they live their storage cannot be re-used
         self.prompt_hoists = 0          # how often the prompt half of the condition was (re)computed: tests / diagnostics
+        self.engine_calls = 0           # forwards served by the HIP engine (inference)
+        self.autograd_calls = 0         # forwards served by unet1d/torch_path.py (training: autograd was recording)
+        self._torch_path = None
 
     # ---------------------------------------------------------------------------------
     def _weights_key(self):
@@ -138,12 +144,23 @@ class UNet1DConditionModel(nn.Module):
                       ("mid_block_additional_residual", mid_block_additional_residual)):
             if v is not None:
                 raise NotImplementedError(f"{nm} is not used by NS2VC and not supported by the HIP engine")
-        if not sample.is_cuda:
-            raise RuntimeError("UNet1DConditionModel (HIP engine) needs CUDA/ROCm tensors: there is no CPU path")
-        if torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("the HIP engine is inference-only: call under torch.no_grad() "
-                                      "(training through this module is out of scope)")
         cfg = self.cfg
+        if torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # TRAINING: autograd is recording (model.py:720).  Plain PyTorch ops on this module's parameters; never taken
+            # under torch.no_grad(), i.e. never by NaturalSpeech2.sample / Svc.infer / the benchmarks.
+            if self._torch_path is None:
+                from .torch_path import TorchDenoiser
+                self._torch_path = TorchDenoiser(self, cfg)
+            Bq = sample.shape[0]
+            tt = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)], device=sample.device)
+            tt = tt.to(sample.device).reshape(-1).expand(Bq)
+            mask_b = None if encoder_attention_mask is None else encoder_attention_mask.to(sample.device).reshape(Bq, -1).bool()
+            out = self._torch_path(sample, tt, encoder_hidden_states, mask_b)
+            self.autograd_calls += 1
+            return UNet1DConditionOutput(sample=out) if return_dict else (out,)
+        if not sample.is_cuda:
+            raise RuntimeError("UNet1DConditionModel (HIP engine) needs CUDA/ROCm tensors for inference: there is no CPU inference path "
+                               "(autograd / training calls use PyTorch ops: unet1d/torch_path.py)")
         B, Cin, T = sample.shape
         if Cin != cfg.in_channels:
             raise RuntimeError(f"expected {cfg.in_channels} input channels, got {Cin}")
@@ -182,6 +199,7 @@ class UNet1DConditionModel(nn.Module):
                 eng.set_mask(mask, stream=stream)
             eng.set_content(content, stream=stream)
             eng.forward(x, ts, out, stream=stream)
+            self.engine_calls += 1
         out = out.to(sample.dtype)
         if not return_dict:
             return (out,)
