@@ -220,6 +220,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
 int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev); /* [N] fp32: sum_k round_to_operand(rows[n][k]) */
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
+int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream); /* test tool: leave `pattern` in every CU's LDS (first lds_bytes) and in vector registers, as a foreign kernel would */
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile: stages 2..4 = 4-wave kernel ring depth, 12|13 = 8-wave K-split kernel ring 2|3; 0,0,0 = heuristic */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
 /* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,

@@ -227,6 +227,9 @@ hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipS
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride,
                              const float* w1t, const float* b1, const float* w2t, const float* b2,
                              const float* aug, float* emb, void* emb_act_op, int prec, int B, int tdim, int edim, hipStream_t s);
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);                                  // bytes: any; p 16-byte aligned
+hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);           // bytes % 16 == 0
+hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStream_t s);
 hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s);
 hipError_t launch_btc_to_nct(const float* src, int lds, int C, int T, int B, float* dst, hipStream_t s);
 hipError_t launch_mask_bias(const uint8_t* mask, int n, float* bias, hipStream_t s);

@@ -905,7 +905,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     P.stats_cap = cap; P.stats_used = 0;
     long long* pool = P.stats_pool;
     ns2vc_unet* hq = h;
-    P.add("gn_stats.clear", [=](hipStream_t s) { return hipMemsetAsync(pool, 0, hq->stats_bytes, s); }, 4);
+    P.add("gn_stats.clear", [=](hipStream_t s) { return launch_zero(pool, hq->stats_bytes, s); }, 4);
   }
   {
     ns2vc_unet* hh = h;
@@ -1312,9 +1312,9 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
     if (e != hipSuccess) { h->step_graph = nullptr; return fail("hipGraphInstantiate: %s", hipGetErrorString(e)); }
   }
   HIPCHK(launch_nct_to_btc(x_inout_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
-  HIPCHK(hipMemcpyAsync(h->xbar, h->xe, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(h->d1, 0, n * sizeof(float), s));
-  HIPCHK(hipMemsetAsync(h->mprev, 0, n * sizeof(float), s));
+  HIPCHK(launch_copy16(h->xe, h->xbar, n * sizeof(float), s));
+  HIPCHK(launch_zero(h->d1, n * sizeof(float), s));
+  HIPCHK(launch_zero(h->mprev, n * sizeof(float), s));
   HIPCHK(launch_fill_i32(h->step_dev, 0, s));
   for (int i = 0; i < h->steps; ++i) {
     if (use_graph) HIPCHK(hipGraphLaunch(h->step_graph, s));
@@ -1439,6 +1439,14 @@ int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, flo
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) {
   set_gemm_trace((unsigned long long*)dev_u64_blocks_x8);
   set_ffn_trace((unsigned long long*)dev_u64_blocks_x8);
+  return 0;
+}
+int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream) {
+  static unsigned* sink = nullptr;
+  if (lds_bytes < 4 || lds_bytes > 160 * 1024) return fail("poison: LDS bytes out of range");
+  if (!sink) HIPCHK(hipMalloc((void**)&sink, 64));
+  hipError_t e = launch_poison(pattern, lds_bytes & ~3, sink, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_poison: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages) { set_forced_gemm_tile(bm, bn, stages); return 0; }

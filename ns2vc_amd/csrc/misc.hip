@@ -612,6 +612,38 @@ hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_p
                                          w1t, b1, w2t, b2, aug, emb, (TMX*)emb_act_op, tdim, edim));
   return hipGetLastError();
 }
+// ---------------------------------------------------------------------------
+// Test tool: leave a bit pattern in the LDS of every CU (and in a slab of vector registers of the waves that ran),
+// as a foreign kernel (rocBLAS, MIOpen, flash attention ...) scheduled before ours would.  The GPU clears neither
+// between kernels, so a kernel that reads LDS / registers it has not written gives results that depend on whatever ran
+// before it; the parity tests run with this poison in front of the launches under test.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void poison_kernel(unsigned pattern, int lds_words, unsigned* __restrict__ sink) {
+  extern __shared__ unsigned s_poison[];
+  for (int i = threadIdx.x; i < lds_words; i += 256) s_poison[i] = pattern;
+  __syncthreads();
+  // hold the CU for a while so that the grid spreads over all CUs instead of cycling through a few
+  unsigned acc = 0;
+  for (int rep = 0; rep < 64; ++rep)
+    for (int i = threadIdx.x; i < lds_words; i += 256 * 64) acc += s_poison[(i + rep) % lds_words];
+  unsigned v[96];
+#pragma unroll
+  for (int i = 0; i < 96; ++i) { v[i] = pattern; asm volatile("" : "+v"(v[i])); }
+  unsigned fold = 0;
+#pragma unroll
+  for (int i = 0; i < 96; ++i) fold ^= v[i];
+  if (acc == 0x12345u && fold == 0x54321u) sink[0] = acc;      // never true for the patterns used; keeps everything live
+}
+hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStream_t s) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(poison_kernel, dim3(2048), dim3(256), (size_t)lds_bytes, s, pattern, lds_bytes / 4, sink);
+  return hipGetLastError();
+}
 hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s) {
   dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
   NS2VC_BY_PREC(prec, hipLaunchKernelGGL(nct_to_btc_kernel<TMX>, grid, dim3(256), 0, s, src, C, T, dst_f32, (TMX*)dst_op, ldd, cpad));
@@ -636,6 +668,31 @@ hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoe
 }
 hipError_t launch_step_advance(int* step_ptr, hipStream_t s) {
   hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_ptr);
+  return hipGetLastError();
+}
+// Plain kernels for clearing / copying workspace buffers.  The step loop is replayed from a captured hipGraph; memset /
+// memcpy NODES in that graph (what hipMemsetAsync / hipMemcpyAsync become under capture) were seen to make replays of the
+// 32 x 938 plan return garbage depending on what ran before (tools/order_probe.py), kernel nodes never -- so everything
+// inside and next to the captured loop is a kernel.
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+__global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
+  if (((uintptr_t)p & 15) != 0) return hipErrorInvalidValue;
+  const size_t n16 = bytes / 16;
+  const int blocks = (int)std::min<size_t>(2048, std::max<size_t>(1, (n16 + 255) / 256));
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)p, n16, (unsigned char*)p + n16 * 16, (int)(bytes & 15));
+  return hipGetLastError();
+}
+hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s) {
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) != 0 || (bytes & 15) != 0) return hipErrorInvalidValue;
+  const size_t n16 = bytes / 16;
+  const int blocks = (int)std::min<size_t>(2048, std::max<size_t>(1, (n16 + 255) / 256));
+  hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
   return hipGetLastError();
 }
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s) {

@@ -21,7 +21,7 @@ procedural parameters (tests/golden/make_golden_v2.py -> golden_v2.npz ``g10.*``
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -142,15 +142,18 @@ class PreModel(nn.Module):
         self.ref_enc = TextTimeEmbedding(100, 100, 1)
 
     @torch.no_grad()
-    def infer(self, c_padded: torch.Tensor, refer_padded: torch.Tensor, lengths: torch.Tensor,
-              refer_lengths: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    def infer(self, c_padded: torch.Tensor, refer_padded: torch.Tensor, lengths: torch.Tensor, refer_lengths: torch.Tensor,
+              autocast: Optional[torch.dtype] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """c_padded (B, 256, T) ContentVec features, refer_padded (B, 100, Lp) reference mel, lengths / refer_lengths (B,).
-        Returns content (B, 256, T), prompt (B, Lp, 256), prompt_mask (B, Lp) bool -- what ``Denoiser.sample`` takes."""
-        g = self.ref_enc(refer_padded.transpose(1, 2)).unsqueeze(-1)                   # (B, 100, 1)
-        prompt = self.prompt_encoder(refer_padded, refer_lengths)
-        content = self.phoneme_encoder(c_padded, lengths, g).transpose(1, 2).contiguous()
+        Returns content (B, 256, T), prompt (B, Lp, 256), prompt_mask (B, Lp) bool -- what ``Denoiser.sample`` takes.
+        ``autocast`` = torch.float16 / torch.bfloat16 runs the GEMMs, convolutions and attention of the two encoders with
+        16-bit operands (``torch.autocast``; LayerNorm and the outputs stay fp32) -- the reference's own inference runs fp32."""
+        with torch.autocast(c_padded.device.type, dtype=autocast, enabled=autocast is not None):
+            g = self.ref_enc(refer_padded.transpose(1, 2)).unsqueeze(-1)               # (B, 100, 1)
+            prompt = self.prompt_encoder(refer_padded, refer_lengths)
+            content = self.phoneme_encoder(c_padded, lengths, g).transpose(1, 2)
         mask = torch.arange(refer_padded.shape[2], device=refer_padded.device)[None, :] < refer_lengths[:, None]
-        return content, prompt.contiguous(), mask
+        return content.float().contiguous(), prompt.float().contiguous(), mask
 
 
 def pre_model_state_from_checkpoint(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

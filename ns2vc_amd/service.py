@@ -3,11 +3,14 @@
 The reference's ``Svc.infer`` (``inference/infer_tool.py:189-206``) converts ONE audio segment per call (batch 1,
 ``infer.py:99-140`` loops over the slicer's segments).  Here segments are converted in batches:
 
-* segments are grouped by their latent length T.  The reference applies no masking to padded LATENT frames (no
-  self-attention / GroupNorm mask, ``model.py:411`` is commented out), so padding a shorter segment would change its
-  result; grouping EQUAL lengths keeps every segment's result what a batch-1 run gives (to within the precision's
-  rounding noise).  Prompts (reference clips) may have any length inside a group: they are padded and masked, which the
-  reference supports (``encoder_attention_mask``).
+* segments are grouped by (latent length T, prompt length Lp) and never padded.  The reference applies no masking to
+  padded LATENT frames (no self-attention / GroupNorm mask, ``model.py:411`` is commented out), and although padded
+  PROMPT frames are masked out of cross-attention (``encoder_attention_mask``) they still enter both attention-pooled
+  embeddings (``ref_enc`` ``model.py:362`` and the UNet's ``add_embedding``, which take no mask) -- so padding either
+  side changes a segment's result (measured: 0.2-0.5 relative on the latent for a prompt padded 40 -> 64).  Grouping
+  EQUAL shapes keeps every segment's result what the reference's batch-1 call gives, to within the precision's rounding
+  noise.  A conversion job normally shares ONE reference clip over all its segments (``infer.py:92-122``: the segment loop sits inside the loop over reference clips), so Lp rarely
+  splits a group.
 * each group runs ``PreModel.infer`` -> ``Denoiser.sample`` -> ``decode_fn`` through ``OverlappedPipeline``: the
   PyTorch-ROCm front / back end of group k+1 / k-1 overlaps the HIP denoiser of group k on their own streams.
 
@@ -43,13 +46,13 @@ class GroupedConverter:
         self.kw = dict(solver=solver, steps=steps, order=order)
 
     def plan(self, segments: Sequence[Segment]) -> List[List[int]]:
-        """indices of `segments` grouped by latent length, groups of at most ``max_batch``, longest first"""
-        by_len: Dict[int, List[int]] = defaultdict(list)
+        """indices of `segments` grouped by (latent length, prompt length), groups of at most ``max_batch``, longest first"""
+        by_len: Dict[tuple, List[int]] = defaultdict(list)
         for i, s in enumerate(segments):
-            by_len[int(s.content.shape[-1])].append(i)
+            by_len[(int(s.content.shape[-1]), int(s.refer.shape[-1]))].append(i)
         groups = []
-        for T in sorted(by_len, reverse=True):
-            idx = by_len[T]
+        for key in sorted(by_len, reverse=True):
+            idx = by_len[key]
             groups += [idx[k:k + self.max_batch] for k in range(0, len(idx), self.max_batch)]
         return groups
 
@@ -59,14 +62,10 @@ class GroupedConverter:
         groups = self.plan(segments)
 
         def pre_fn(idx):
-            T = int(segments[idx[0]].content.shape[-1])
-            Lp = max(int(segments[i].refer.shape[-1]) for i in idx)
+            T, Lp = int(segments[idx[0]].content.shape[-1]), int(segments[idx[0]].refer.shape[-1])
             c = torch.stack([segments[i].content.to(dev, torch.float32) for i in idx])
-            refer = torch.zeros((len(idx), segments[idx[0]].refer.shape[0], Lp), device=dev)
-            lens = [int(segments[i].refer.shape[-1]) for i in idx]
-            for b, i in enumerate(idx):
-                refer[b, :, :lens[b]] = segments[i].refer.to(dev, torch.float32)
-            content, prompt, mask = self.pre.infer(c, refer, torch.full((len(idx),), T, device=dev), torch.tensor(lens, device=dev))
+            refer = torch.stack([segments[i].refer.to(dev, torch.float32) for i in idx])
+            content, prompt, mask = self.pre.infer(c, refer, torch.full((len(idx),), T, device=dev), torch.full((len(idx),), Lp, device=dev))
             # x_T per SEGMENT (seeded by its position in the input), so a segment's result does not depend on its group
             noise = torch.stack([torch.randn((100, T), generator=torch.Generator().manual_seed(self.seed + i)) for i in idx]).to(dev)
             return {"content": content, "prompt": prompt, "prompt_mask": mask, "noise": noise}

@@ -53,7 +53,7 @@ def test_dropin_module_state_dict_and_loud_failures():
                              resnet_time_scale_shift="scale_shift")
     ref = json.load(open(os.path.join(GOLD, "unet_state_keys.json")))
     assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == ref["keys"]
-    with pytest.raises(RuntimeError, match="no CPU path"):
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU inference path"):      # inference never falls back to the CPU
         m(torch.zeros(1, 356, 8), 3, torch.zeros(1, 4, 256))
     with pytest.raises(ValueError):
         UNet1DConditionModel(in_channels=356, out_channels=100, block_out_channels=(128, 256), norm_num_groups=8,

@@ -59,8 +59,8 @@ def test_frontend_on_device_matches_reference_golden(pre_model, diag):
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("fp16", 2e-3)])
 def test_grouped_converter_equals_per_segment_runs(pre_model, precision, tol, diag):
-    """batched conversion == one-segment-at-a-time conversion (the reference's batch-1 loop): segments are grouped by latent
-    length (no padded latent frames, so no change of semantics), prompts inside a group are ragged (padded + masked).
+    """batched conversion == one-segment-at-a-time conversion (the reference's batch-1 loop): segments are grouped by
+    (latent length, prompt length) and never padded, so every segment keeps its batch-1 semantics.
     fp32 agrees to accumulation noise; the 16-bit mode to its rounding noise (a batched and a single run round
     differently: DESIGN.md 'batch independence')."""
     import torch
@@ -69,11 +69,11 @@ def test_grouped_converter_equals_per_segment_runs(pre_model, precision, tol, di
     from ns2vc_amd.weights import procedural_state_dict
     den = Denoiser(procedural_state_dict(seed=0), precision=precision)
     lengths = [96, 130, 96, 64, 130, 96, 96]
-    rlens = [40, 64, 33, 64, 17, 64, 50]
+    rlens = [40, 64, 40, 64, 64, 40, 50]
     segs = _segments(lengths, rlens)
     conv = GroupedConverter(pre_model, den, max_batch=3, solver="unipc", steps=6)
     groups = conv.plan(segs)
-    assert groups == [[1, 4], [0, 2, 5], [6], [3]]                      # longest first, at most max_batch, input order inside
+    assert groups == [[1, 4], [6], [0, 2, 5], [3]]                      # longest first, at most max_batch, input order inside
     out = conv.convert(segs)
     one = GroupedConverter(pre_model, den, max_batch=1, solver="unipc", steps=6).convert(segs)
     errs = []
@@ -94,7 +94,7 @@ def test_grouped_converter_segment_vs_oracle(pre_model, weights, diag):
     from oracle import sampler_ref, unet_ref
     torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     den = Denoiser(weights, precision="fp32")
-    segs = _segments([80, 80, 112], [32, 48, 20], tag="svc2")
+    segs = _segments([80, 80, 112], [48, 48, 20], tag="svc2")
     out = GroupedConverter(pre_model, den, max_batch=4, solver="unipc", steps=5, seed=7).convert(segs)
     i, T = 1, 80
     dev = torch.device("cuda", 0)
@@ -157,3 +157,17 @@ def test_pipeline_with_real_front_end_end_to_end_rtf(pre_model, diag):
          f"{t_den / n_batches * 1e3:.1f} ms/batch, sequential {t_seq / n_batches * 1e3:.1f} ms/batch (RTF {t_seq / audio_s:.2e}), "
          f"overlapped {t_ovl / n_batches * 1e3:.1f} ms/batch (RTF {t_ovl / audio_s:.2e}); denoiser-only RTF {t_den / audio_s:.2e}")
     assert t_ovl < 1.10 * t_seq
+    # the same front end with 16-bit operands (torch.autocast): time, and what it does to the conditioning and the sampled latent
+    def pre16(k):
+        content, prompt, mask = pre_model.infer(c, refer, lengths, rlens, autocast=torch.float16)
+        return {"content": content, "prompt": prompt, "prompt_mask": mask, "noise": noise}
+    c16 = pre16(0)
+    _, t_pre16 = timed(lambda: [pre16(k) for k in range(n_batches)])
+    pipe16 = OverlappedPipeline(den, pre16, lambda latent, k: latent, solver="unipc", steps=steps)
+    pipe16.run([0])
+    ovl16, t_ovl16 = timed(lambda: pipe16.run(list(range(n_batches))))
+    e_c, e_p = rel_l2(c16["content"].cpu().numpy(), cond["content"].cpu().numpy()), rel_l2(c16["prompt"].cpu().numpy(), cond["prompt"].cpu().numpy())
+    e_y = rel_l2(ovl16[0].cpu().numpy(), seq[0].cpu().numpy())
+    diag(f"  fp16-autocast front end: {t_pre16 / n_batches * 1e3:.1f} ms/batch alone, overlapped end-to-end {t_ovl16 / n_batches * 1e3:.1f} ms/batch "
+         f"(RTF {t_ovl16 / audio_s:.2e}); vs the fp32 front end: content {e_c:.2e}, prompt {e_p:.2e}, sampled latent {e_y:.2e}")
+    assert e_c < 5e-3 and e_p < 5e-3
