@@ -365,6 +365,16 @@ def main():
     walls, gpu_ms, t_gather = timed_jobs(eng, a.warmup, reps, world > 1)
     wall = statistics.median(walls)
     finite = bool(torch.isfinite(x).all().item())
+    # the timed (captured-graph) loop must return exactly what the same loop launched eagerly returns
+    loop_check = None
+    if use_graph:
+        with torch.cuda.stream(stream):
+            x_graph = x.clone()
+            x.copy_(noise)
+            eng.set_condition(content, prompt, mask, stream=stream)
+            eng.sample(x, use_graph=False, stream=stream)
+            stream.synchronize()
+            loop_check = {"graph_loop_equals_eager_loop": bool(torch.equal(x, x_graph)), "steps": K}
     per_rank_ms = [wall * 1e3 / K]
     if world > 1:
         mine = torch.tensor([statistics.median(walls) * 1e3 / K, t_gather * 1e3], device=dev, dtype=torch.float64)
@@ -428,7 +438,7 @@ def main():
                        "global_batch": B * world, "frames": T, "prompt_frames": Lp, "solver": solver, "parallelism": f"dp{world}"},
             "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,
                        "max_ms_per_step": max(walls) * 1e3 / K},
-            "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite,
+            "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
             "launches_per_step": launches, "workspace_gb": workspace_gb, "device": E.device_info(),
             "rccl_ranks": world if world > 1 else 0, "per_rank_ms_per_step": per_rank_ms,
             "roofline": roof, "parity": parity, "fp32_parity_mode": fp32_block, "cpu_baseline": cpu,

@@ -101,8 +101,9 @@ class Denoiser:
 
     def sample_sharded(self, content, prompt, prompt_mask, noise, **kw):
         """Data-parallel: every rank receives the GLOBAL batch description, runs its contiguous slice and the
-        finished latents are all-gathered (RCCL).  Results are identical for any world size because the noise
-        is drawn for the global batch and sliced."""
+        finished latents are all-gathered (RCCL).  The noise is drawn for the global batch and sliced, so an utterance's
+        result does not depend on the world size beyond the precision's rounding noise (fp32: ~1e-6; 16-bit: a shard of
+        3 and a shard of 2 round differently, ~7e-4 -- tests/test_dropin_gpu.py::test_sample_sharded_rccl_*)."""
         import torch
         import torch.distributed as td
         rank = td.get_rank() if td.is_initialized() else 0

@@ -11,6 +11,7 @@ from util import rel_l2
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _inputs(tag, B, T, Lp):
@@ -225,3 +226,65 @@ def test_overlapped_pipeline_matches_sequential(diag):
                  f"differing {int((a != b).sum())}/{a.numel()}")
         assert torch.equal(a, b)
     diag(f"overlapped pipeline: 5 batches sequential {t_seq * 1e3:.1f} ms, three-stream {t_ovl * 1e3:.1f} ms")
+
+
+_SHARD_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ns2vc_amd.pipeline import Denoiser
+from ns2vc_amd.weights import hash_normal, procedural_state_dict
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))   # nccl == RCCL on ROCm
+dev = torch.device("cuda", rank)
+n, T, Lp = 5, 96, 24                                  # uneven shards at world 2: 3 + 2
+mk = lambda tag, shape: torch.from_numpy(hash_normal(tag, shape)).to(dev)
+content, prompt, noise = mk("sh.c", (n, 256, T)), mk("sh.p", (n, Lp, 256)), mk("sh.n", (n, 100, T))
+mask = (torch.arange(Lp)[None, :] < torch.tensor([24, 24, 11, 24, 17])[:, None]).to(dev)
+den = Denoiser(procedural_state_dict(seed=0), precision=sys.argv[3])
+out = den.sample_sharded(content, prompt, mask, noise, solver="unipc", steps=6)
+assert out.shape == (n, 100, T)
+if rank == 0:
+    np.save(sys.argv[2], out.cpu().numpy())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16"])
+def test_sample_sharded_rccl_world1_and_world2(precision, tmp_path, diag):
+    """Denoiser.sample_sharded over RCCL (SURVEY 8(e)): every rank gets the global batch description, denoises its contiguous
+    shard and all-gathers the latents.  World 1 always; world 2 when two devices are visible.  Each utterance is compared with
+    its own batch-1 run on this process's engine: fp32 to accumulation noise, fp16 to its rounding noise (a shard of 3 and a
+    batch of 1 round differently), and world 1 vs world 2 the same way."""
+    import subprocess
+    import sys
+    import torch
+    from ns2vc_amd.pipeline import Denoiser
+    from ns2vc_amd.weights import hash_normal, procedural_state_dict
+    script = tmp_path / "shard_worker.py"
+    script.write_text(_SHARD_WORKER)
+    worlds = [1] + ([2] if torch.cuda.device_count() >= 2 else [])
+    outs = {}
+    for world in worlds:
+        path = str(tmp_path / f"out_w{world}.npy")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, str(script), ROOT, path, precision], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+        logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), logs
+        outs[world] = np.load(path)
+    dev = torch.device("cuda", 0)
+    n, T, Lp = 5, 96, 24
+    mk = lambda tag, shape: torch.from_numpy(hash_normal(tag, shape)).to(dev)
+    content, prompt, noise = mk("sh.c", (n, 256, T)), mk("sh.p", (n, Lp, 256)), mk("sh.n", (n, 100, T))
+    mask = (torch.arange(Lp)[None, :] < torch.tensor([24, 24, 11, 24, 17])[:, None]).to(dev)
+    den = Denoiser(procedural_state_dict(seed=0), precision=precision)
+    tol = 1e-5 if precision == "fp32" else 2e-3
+    single = np.concatenate([den.sample(content[i:i + 1], prompt[i:i + 1], mask[i:i + 1], noise[i:i + 1], solver="unipc", steps=6).cpu().numpy()
+                             for i in range(n)])
+    errs = {w: max(rel_l2(o[i], single[i]) for i in range(n)) for w, o in outs.items()}
+    diag(f"sample_sharded ({precision}) vs per-utterance runs: " + ", ".join(f"world {w}: {e:.2e}" for w, e in errs.items())
+         + (f"; world 1 vs world 2: {rel_l2(outs[2], outs[1]):.2e}" if 2 in outs else "; one device visible: world 2 not run"))
+    assert all(e < tol for e in errs.values())
+    if 2 in outs:
+        assert rel_l2(outs[2], outs[1]) < tol
