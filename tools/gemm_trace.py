@@ -8,19 +8,16 @@ from ns2vc_amd._lib import GemmArgs, check
 from ns2vc_amd.engine import DevBuf, sync
 
 lib = _lib.load()
-cases = [("L0.conv3", 30016, 128, 384, 3, 0, "f32", (64, 128, 2)), ("L1.geglu", 15008, 2048, 256, 1, 1, "op", (64, 128, 2)),
-         ("L1.qkv", 15008, 768, 256, 1, 0, "op", (64, 128, 2)), ("L0.lin+res", 30016, 128, 128, 1, 0, "f32", (64, 128, 2)),
-         ("L3.conv3big", 3776, 512, 3072, 3, 0, "f32", (64, 64, 4)),
-         # stages 12 / 13 = the 8-wave K-split kernel
-         ("L0.conv3", 30016, 128, 384, 3, 0, "f32", (128, 128, 13)), ("L0.ff_out", 30016, 128, 512, 1, 0, "f32", (128, 128, 13)),
-         ("L1.geglu", 15008, 2048, 256, 1, 1, "op", (128, 128, 12)), ("L1.ff_out", 15008, 256, 1024, 1, 0, "f32", (128, 128, 13)),
-         ("L1.ff_out", 15008, 256, 1024, 1, 0, "f32", (64, 128, 13)), ("L1.ff_out", 15008, 256, 1024, 1, 0, "f32", (64, 128, 2)),
+PREC = 2          # fp16 operands
+cases = [  # (name, M, N, K, taps, geglu, output, (bm, bn, stages)); stages 12 / 13 = the 8-wave K-split kernel with ring 2 / 3
+         ("L0.conv3", 30016, 128, 384, 3, 0, "f32", (64, 128, 13)), ("L0.conv3", 30016, 128, 384, 3, 0, "f32", (128, 128, 13)),
+         ("L0.conv3cat", 30016, 128, 768, 3, 0, "f32", (64, 128, 13)), ("L0.conv3cat", 30016, 128, 768, 3, 0, "f32", (128, 128, 13)),
+         ("L0.lin+res", 30016, 128, 128, 1, 0, "f32", (64, 128, 13)), ("L0.qkv", 30016, 384, 128, 1, 0, "op", (128, 128, 12)),
+         ("L1.conv3", 15008, 256, 768, 3, 0, "f32", (128, 128, 13)), ("L1.conv3", 15008, 256, 768, 3, 0, "f32", (64, 128, 13)),
+         ("L1.lin", 15008, 256, 256, 1, 0, "f32", (64, 128, 13)),
+         ("L2.conv3", 7520, 384, 1152, 3, 0, "f32", (128, 128, 13)), ("L2.conv3", 7520, 384, 1152, 3, 0, "f32", (64, 128, 13)),
          ("L3.conv3big", 3776, 512, 3072, 3, 0, "f32", (64, 128, 13)),
-         # latency floor: a handful of workgroups on an otherwise idle chip
-         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 13)), ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 12)),
-         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 13)),
-         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 2)), ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 3)),
-         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 64, 4)), ("tiny.lin", 192, 128, 128, 1, 0, "f32", (64, 128, 13))]
+         ("tiny.conv3", 192, 512, 1536, 3, 0, "f32", (64, 128, 13)), ("tiny.lin", 192, 128, 128, 1, 0, "f32", (64, 128, 13))]
 for name, M, N, K, taps, geglu, outk, cfg in cases:
     Cin = K // taps; Tt = M // 32; Bb = 32; M = Bb * Tt
     A = DevBuf(M * Cin * 2 + 4096); W = DevBuf(N * K * 2); bias = DevBuf.from_numpy(np.zeros(N, np.float32))
@@ -33,10 +30,10 @@ for name, M, N, K, taps, geglu, outk, cfg in cases:
     nblk = (N // cfg[1]) * ((M + cfg[0] - 1) // cfg[0])
     T = DevBuf(nblk * 8 * 8)
     check(lib.ns2vc_debug_set_gemm_tile(*cfg), "tile")
-    for _ in range(3): check(lib.ns2vc_k_gemm(C.byref(g), 1, None), "gemm")
+    for _ in range(3): check(lib.ns2vc_k_gemm(C.byref(g), PREC, None), "gemm")
     sync()
     check(lib.ns2vc_debug_set_gemm_trace(T.ptr), "trace")
-    check(lib.ns2vc_k_gemm(C.byref(g), 1, None), "gemm"); sync()
+    check(lib.ns2vc_k_gemm(C.byref(g), PREC, None), "gemm"); sync()
     check(lib.ns2vc_debug_set_gemm_trace(None), "trace")
     t = T.to_numpy((nblk, 8), dtype=np.uint64).astype(np.float64)
     t0 = t[:, 0].min()
