@@ -211,6 +211,26 @@ typedef struct ns2vc_ffn_args {
 int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, int precision, void** out_stream_dev);
 int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream);
 
+/* Two token-local GEMMs with a LayerNorm in between, in one launch (csrc/rowchain.hip; 16-bit precisions, dim 128 / 256):
+ *   y = A W1^T + bias1 (+ res)  -> out1_f32 (optional);   z = LayerNorm(y) W2'^T + b2'  -> out2_op   (gamma/beta folded into W2' / b2')
+ * Replaces Transformer2DModel.proj_in + BasicTransformerBlock.norm1 + attn1.to_q|to_k|to_v (transformer_1d.py:270-279,
+ * attention.py:130-140; n2 = 3 dim) and attn1.to_out + residual + norm2 + attn2.to_q (attention_processor.py:1040-1050,
+ * attention.py:141-160; n2 = dim).  a_op [M][lda] operand rows; wstream from ns2vc_pack_rowchain; consts2 [n2][2] =
+ * (sum_k of the rounded W2' row, folded bias).  res may alias out1_f32 element for element. */
+typedef struct ns2vc_rowchain_args {
+  const void* a_op; int32_t lda;
+  const void* wstream; const float* bias1; const float* consts2;
+  const float* res; int32_t ldres;          /* optional fp32 residual added to y */
+  float* out1_f32; int32_t ldo1;            /* fp32 y, or NULL */
+  void* out2_op; int32_t ldo2;              /* operand-typed z [M][ldo2] */
+  float ln_eps; int32_t M, dim, n2;
+  unsigned* ln_health;                      /* optional, as in ns2vc_gemm_args */
+} ns2vc_rowchain_args;
+/* w1 [dim][dim], w2 [n2][dim]: fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
+int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int n2, int precision, void** out_stream_dev);
+int ns2vc_k_rowchain(const ns2vc_rowchain_args* a, int precision, void* stream);
+int ns2vc_debug_set_rowchain_tokens(int nt); /* tests: force 64-token (1) / 128-token (2, dim 128 only) workgroups; 0 = heuristic */
+
 /* operand-typed conversions for tests: fp32 host [n] -> device operand buffer and back */
 int ns2vc_to_operand(const float* host, size_t n, int precision, void** out_dev);
 int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);

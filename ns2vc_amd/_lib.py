@@ -63,6 +63,18 @@ class FfnArgs(C.Structure):
     ]
 
 
+class RowchainArgs(C.Structure):
+    _fields_ = [
+        ("a_op", C.c_void_p), ("lda", C.c_int32),
+        ("wstream", C.c_void_p), ("bias1", C.c_void_p), ("consts2", C.c_void_p),
+        ("res", C.c_void_p), ("ldres", C.c_int32),
+        ("out1_f32", C.c_void_p), ("ldo1", C.c_int32),
+        ("out2_op", C.c_void_p), ("ldo2", C.c_int32),
+        ("ln_eps", C.c_float), ("M", C.c_int32), ("dim", C.c_int32), ("n2", C.c_int32),
+        ("ln_health", C.c_void_p),
+    ]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
@@ -127,6 +139,9 @@ PROTOTYPES = {
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
     "ns2vc_pack_ffn": (_I, [_P, _P, _I, _I, _PP]),
     "ns2vc_k_ffn": (_I, [C.POINTER(FfnArgs), _I, _P]),
+    "ns2vc_pack_rowchain": (_I, [_P, _P, _I, _I, _I, _PP]),
+    "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),
+    "ns2vc_debug_set_rowchain_tokens": (_I, [_I]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),

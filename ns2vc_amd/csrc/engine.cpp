@@ -23,6 +23,7 @@ using namespace ns2vc;
 
 namespace ns2vc {
 hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
+hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
 }
 
@@ -75,6 +76,9 @@ struct AttnW {
   PackedW ffpo;    // ff.net.2 folded into proj_out: [W_po W_2 | W_po], K = 4*dim + dim (see pack_all)
   void* ffn_stream = nullptr;     // fused feed-forward + proj_out (ffn.hip): weight tile stream ...
   float* ffn_consts = nullptr;    // ... and (rowsum, bias) per packed ff.net.0 row; 16-bit precisions, dim <= 256 only
+  // token-local chains (rowchain.hip; 16-bit precisions, dim <= 256): proj_in -> norm1 -> q|k|v and attn1.to_out -> norm2 -> attn2.to_q
+  void *chain_in = nullptr, *chain_mid = nullptr;          // weight tile streams
+  float *chain_in_consts = nullptr, *chain_mid_consts = nullptr;   // (rowsum, bias) per LayerNorm-folded stage-2 row
 };
 struct BlockW {
   std::string kind;   // down | mid | up
@@ -135,6 +139,7 @@ struct ns2vc_unet {
   // GEGLU feed-forward + ff.net.2 + proj_out in ONE launch per transformer block (csrc/ffn.hip) where eligible
   // (16-bit precisions, dim 128 / 256, LayerNorm by linearity and the fold on).  NS2VC_FUSE_FFN=0 restores the two GEMMs.
   bool fuse_ffn = true;
+  bool fuse_rows = true;     // proj_in+q|k|v and attn1.to_out+attn2.to_q as one launch each (rowchain.hip)
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -386,6 +391,28 @@ struct Packer {
   }
 };
 
+// weight stream + stage-2 constants of one token-local chain (rowchain.hip): w1 [d][d] plain, w2 [n2][d] LayerNorm-folded
+// with its folded bias; only for the shapes / precisions the kernel serves, otherwise both outputs stay null
+static int chain_stream(Packer& P, const std::vector<float>& w1, const std::vector<float>& w2, const std::vector<float>& b2, int d, int n2,
+                        void*& stream_dev, float*& consts_dev) {
+  ns2vc_unet* h = P.h;
+  stream_dev = nullptr; consts_dev = nullptr;
+  if (P.err) return 1;
+  if (!rowchain_eligible(d, n2, 64, h->prec)) return 0;
+  std::vector<unsigned short> st;
+  if (pack_rowchain_stream(w1.data(), w2.data(), d, n2, h->prec, st) != hipSuccess) return fail("row-chain stream packing failed");
+  void* dev = nullptr;
+  if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
+  h->weight_allocs.push_back(dev);
+  if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
+  const std::vector<float> ws = rounded_rowsum(w2.data(), n2, d, n2, h->prec);
+  std::vector<float> cs((size_t)n2 * 2);
+  for (int r = 0; r < n2; ++r) { cs[2 * r] = ws[r]; cs[2 * r + 1] = b2[r]; }
+  stream_dev = dev;
+  consts_dev = P.upload_f32(cs);
+  return P.err;
+}
+
 int pack_all(ns2vc_unet* h) {
   Packer P{h};
   const auto& c = h->cfg;
@@ -469,6 +496,7 @@ int pack_all(ns2vc_unet* h) {
         for (const char* nm : {"to_q", "to_k", "to_v"}) P.ln_fold(P.T(t + ".attn1." + nm + ".weight"), nullptr, P.T(t + ".norm1.weight"), P.T(t + ".norm1.bias"), rows, bias);
         if (P.err) return 1;
         a.qkv = P.pack(rows, 3 * d, d, bias, true);
+        if (chain_stream(P, P.T(a.prefix + ".proj_in.weight").data, rows, bias, d, 3 * d, a.chain_in, a.chain_in_consts)) return 1;
       }
       a.o1 = P.pack(P.T(t + ".attn1.to_out.0.weight").data, d, d, P.T(t + ".attn1.to_out.0.bias").data);
       {
@@ -476,6 +504,7 @@ int pack_all(ns2vc_unet* h) {
         P.ln_fold(P.T(t + ".attn2.to_q.weight"), nullptr, P.T(t + ".norm2.weight"), P.T(t + ".norm2.bias"), rows, bias);
         if (P.err) return 1;
         a.q2 = P.pack(rows, d, d, bias, true);
+        if (chain_stream(P, P.T(t + ".attn1.to_out.0.weight").data, rows, bias, d, d, a.chain_mid, a.chain_mid_consts)) return 1;
       }
       a.o2 = P.pack(P.T(t + ".attn2.to_out.0.weight").data, d, d, P.T(t + ".attn2.to_out.0.bias").data);
       std::vector<float> ff1_rows, ff1_bias;     // packed ff.net.0 (kept for the fused feed-forward stream below)
@@ -728,24 +757,44 @@ struct Planner {
       if (rs) { gg.ln_stats = rs; gg.ln_wsum = w.wsum; gg.ln_eps = 1e-5f; gg.ln_dim = d; gg.ln_health = h->ln_health; }
     };
     float* r1 = lin ? rs1 : nullptr;
-    g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
-    g.rowstats = r1;
-    gemm(a.prefix + ".proj_in", g);
-    // self attention
-    if (!r1) layernorm(t + ".norm1");
-    g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
-    consume(g, r1, a.qkv);
-    gemm(t + ".attn1.qkv", g);
+    // token-local chains in one launch each (rowchain.hip): same arithmetic and rounding points as the two GEMMs they replace
+    auto rowchain = [&](const std::string& nm, const void* a_op, void* stream, const float* bias1, const float* consts2, const float* res,
+                        void* z_op, int n2) {
+      ns2vc_rowchain_args c;
+      memset(&c, 0, sizeof(c));
+      c.a_op = a_op; c.lda = d; c.wstream = stream; c.bias1 = bias1; c.consts2 = consts2;
+      c.res = res; c.ldres = d; c.out1_f32 = y; c.ldo1 = d; c.out2_op = z_op; c.ldo2 = n2;
+      c.ln_eps = 1e-5f; c.M = M; c.dim = d; c.n2 = n2; c.ln_health = h->ln_health;
+      add(nm, [=](hipStream_t s) { return launch_rowchain(c, pr, s); }, 1, 2.0 * M * (double)d * (d + n2),
+          (double)M * (d * (opsz + 4.0 + (res ? 4.0 : 0.0)) + n2 * opsz) + (double)(d + n2) * d * opsz);
+    };
+    const bool rows_ok = lin && h->fuse_rows && a.chain_in && a.chain_mid && rowchain_eligible(d, d, Tl, pr);
+    if (rows_ok) {
+      rowchain(a.prefix + ".rows[proj_in+qkv]", xn, a.chain_in, a.proj_in.bias, a.chain_in_consts, nullptr, qkv, 3 * d);
+    } else {
+      g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
+      g.rowstats = r1;
+      gemm(a.prefix + ".proj_in", g);
+      // self attention
+      if (!r1) layernorm(t + ".norm1");
+      g = base(yn, d, d, Tl, Tl, a.qkv, nullptr, qkv, 3 * d);
+      consume(g, r1, a.qkv);
+      gemm(t + ".attn1.qkv", g);
+    }
     attention(t + ".attn1.sdpa", qkv, 3 * d, op_off(qkv, d), 3 * d, op_off(qkv, 2 * d), 3 * d, Tl, Tl, nullptr, hd, ao, d);
     float* r2 = lin ? rs2 : nullptr;
-    g = base(ao, d, d, Tl, Tl, a.o1, y, r2 ? yn : nullptr, d);
-    g.res = y; g.ldres = d;
-    g.rowstats = r2;
-    gemm(t + ".attn1.to_out", g);
-    if (!r2) layernorm(t + ".norm2");
-    g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
-    consume(g, r2, a.q2);
-    gemm(t + ".attn2.to_q", g);
+    if (rows_ok) {
+      rowchain(t + ".rows[attn1.to_out+attn2.to_q]", ao, a.chain_mid, a.o1.bias, a.chain_mid_consts, y, qb, d);
+    } else {
+      g = base(ao, d, d, Tl, Tl, a.o1, y, r2 ? yn : nullptr, d);
+      g.res = y; g.ldres = d;
+      g.rowstats = r2;
+      gemm(t + ".attn1.to_out", g);
+      if (!r2) layernorm(t + ".norm2");
+      g = base(yn, d, d, Tl, Tl, a.q2, nullptr, qb, d);
+      consume(g, r2, a.q2);
+      gemm(t + ".attn2.to_q", g);
+    }
     // cross attention (k|v hoisted into h->kv by set_condition)
     const int nkv = h->kv_all.N;
     attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
@@ -1101,6 +1150,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   hipError_t e = init_gemm_attributes();
   if (e == hipSuccess) e = init_attn_attributes();
   if (e == hipSuccess) e = init_ffn_attributes();
+  if (e == hipSuccess) e = init_rowchain_attributes();
   if (e != hipSuccess) return fail("kernel attribute setup failed: %s (is a gfx950 GPU visible?)", hipGetErrorString(e));
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
@@ -1108,6 +1158,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FOLD_FF")) h->fold_ff = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1181,7 +1232,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!strcmp(name, "ln_linear")) opt = &h->ln_linear;
   else if (!strcmp(name, "fold_ff")) opt = &h->fold_ff;
   else if (!strcmp(name, "fuse_ffn")) opt = &h->fuse_ffn;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn)", name);
+  else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_rows)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1411,6 +1463,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
     hipError_t e = init_gemm_attributes();
     if (e == hipSuccess) e = init_attn_attributes();
     if (e == hipSuccess) e = init_ffn_attributes();
+    if (e == hipSuccess) e = init_rowchain_attributes();
     if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
     inited = true;
   }
@@ -1470,6 +1523,34 @@ int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, 
   HIPCHK(hipMalloc(&d, st.size() * 2));
   HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
   *out_stream_dev = d;
+  return 0;
+}
+int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int n2, int precision, void** out_stream_dev) {
+  if (!w1_host || !w2_host || !out_stream_dev) return fail("null argument");
+  static bool inited = false;
+  if (!inited) {
+    hipError_t e = init_rowchain_attributes();
+    if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
+    inited = true;
+  }
+  std::vector<unsigned short> st;
+  if (pack_rowchain_stream(w1_host, w2_host, dim, n2, precision, st) != hipSuccess)
+    return fail("rowchain: dim must be 128 or 256, n2 = dim or 3 dim, and the precision 16-bit");
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, st.size() * 2));
+  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  *out_stream_dev = d;
+  return 0;
+}
+int ns2vc_debug_set_rowchain_tokens(int nt) {
+  if (nt < 0 || nt > 2) return fail("rowchain tokens: 0 (heuristic), 1 (64-token blocks) or 2 (128-token blocks)");
+  set_forced_rowchain_tokens(nt);
+  return 0;
+}
+int ns2vc_k_rowchain(const ns2vc_rowchain_args* a, int precision, void* stream) {
+  if (!a) return fail("null args");
+  hipError_t e = launch_rowchain(*a, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_rowchain: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream) {

@@ -1,0 +1,351 @@
+// Two token-local GEMMs of a transformer block in ONE launch, CDNA4 (gfx950), 16-bit operand types.
+//
+// Inside BasicTransformerBlock (reference unet1d/attention.py:130-176) and Transformer2DModel (transformer_1d.py:256-286) two
+// pairs of linears follow each other with nothing but a LayerNorm in between, and both act on every token by itself:
+//
+//   proj_in (1x1 conv) -> norm1 -> to_q | to_k | to_v          (transformer_1d.py:270-279, attention.py:130-140)
+//   attn1.to_out + residual -> norm2 -> attn2.to_q               (attention_processor.py:1040-1050, attention.py:141-160)
+//
+//     y   = A W1^T + b1 (+ res)                     -> fp32 residual stream (kept), LayerNorm statistics of the row
+//     z   = LayerNorm(y) W2^T + b2                  =  rstd (y_op W2'^T - mean rowsum(W2')) + b2'     (gamma/beta folded at pack time)
+//
+// As separate launches every one of these small-K GEMMs lasts one workgroup latency (8-19 us at 10 s x batch 32: set-up, a
+// cold first tile, an LDS-staged epilogue, a store drain) and y's operand copy makes a round trip through HBM.  Here one
+// workgroup owns 64 tokens for the chain, exactly like the fused feed-forward (ffn.hip): the token panel sits in LDS, the
+// weights are ONE flat stream of pre-swizzled 16-KB tiles consumed in pairs through a ring by lane-linear LDS-DMA, and
+// everything is computed TRANSPOSED (out^T = W a^T) so that a lane owns ONE token: bias, residual, the LayerNorm sums and
+// the fix-up are per-lane arithmetic, y's operand copy is written straight back into the panel (it replaces A, which is
+// dead by then) and never leaves the CU.  8 waves = 2 token halves x 4 row groups: wave (tw, cg) takes rows 32 cg .. + 31
+// of EVERY 128-row weight tile for its 32 tokens.
+#include "common.h"
+#include "mma.h"
+#include <cstdlib>
+#include <vector>
+
+namespace ns2vc {
+
+typedef ::ns2vc_rowchain_args RowchainArgs;
+
+constexpr int RC_TILE = 128 * 128;        // bytes: [128 rows][128 B of K]
+constexpr int RC_PAIR = 2 * RC_TILE;
+
+template <int D, int R2, int NT> struct RowchainGeom {
+  static constexpr int TOK = 64 * NT;       // tokens per workgroup: every wave owns NT blocks of 32
+  static constexpr int KT = D / 64;         // K tiles of both stages (K = D)
+  static constexpr int NB1 = D / 128;       // 128-row blocks of W1 (N1 = D)
+  static constexpr int S1 = KT * NB1, S2 = KT * R2;           // tiles per stage, k-tile outer, row block inner
+  static_assert(S1 % 2 == 0 && S2 % 2 == 0, "stages start on pair boundaries");
+  static constexpr int NP = (S1 + S2) / 2;
+  static constexpr int RING = 3;
+  static constexpr int PTILE = TOK * 128;                     // bytes of one panel k tile: [TOK][128 B], swizzled
+  static constexpr int PANEL = KT * PTILE;
+  static constexpr int CONSTS = R2 * 128 * 8;                 // (rowsum, bias) per stage-2 row
+  static constexpr int STATS = TOK * 4 * 8;                   // (sum, sumsq) per token and row group
+  static constexpr int LDS = RING * RC_PAIR + PANEL + CONSTS + STATS;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <typename TM, int D, int R2, int NT>
+__global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
+  op_mode_init<TM>();
+  using G = RowchainGeom<D, R2, NT>;
+  constexpr int KT = G::KT, NB1 = G::NB1, S1 = G::S1, S2 = G::S2, NP = G::NP, RING = G::RING, TOK = G::TOK, PTILE = G::PTILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const ring = smem;
+  char* const panel = smem + RING * RC_PAIR;
+  const float* const consts = reinterpret_cast<const float*>(panel + G::PANEL);
+  float2* const stats = reinterpret_cast<float2*>(panel + G::PANEL + G::CONSTS);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = wave & 1, cg = wave >> 1;          // token half, row group
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int sw = (l31 >> 1) & 7;                    // XOR swizzle of every fragment / panel row this lane touches
+  const unsigned lds0 = (unsigned)(size_t)smem;
+  const int m0 = blockIdx.x * TOK;
+  const int tok0 = 32 * NT * tw + l31;              // this lane's tokens inside the block: tok0 + 32 u (both lane halves)
+
+  const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * RC_PAIR);
+  const unsigned lane16 = (unsigned)(lane * 16);
+  // ---- DMA: token panel (source-side swizzle, rows past M read as zeros), stage-2 constants, then the weight stream
+  {
+    const int pchunk = lane & 7;
+    const i32x4_t rA = make_rsrc(a.a_op, (unsigned long long)a.M * a.lda * 2ull);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int prow = 64 * u + 8 * wave + (lane >> 3);                  // one 1-KB piece per wave = 8 rows x 128 B
+      const int m = m0 + prow;
+      const unsigned voff = m < a.M ? (unsigned)m * (unsigned)a.lda * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+        blds16(rA, voff, (unsigned)(kt * 128), lds0 + RING * RC_PAIR + kt * PTILE + u * 8192 + wave * 1024);
+    }
+    const i32x4_t rC = make_rsrc(a.consts2, (unsigned long long)G::CONSTS);
+    if (wave < G::CONSTS / 1024) blds16(rC, lane16, (unsigned)(wave * 1024), lds0 + RING * RC_PAIR + G::PANEL + wave * 1024);
+  }
+  static_assert(G::CONSTS / 1024 <= 8, "constants fit one DMA piece per wave");
+  auto issue_pair = [&](int p) __attribute__((always_inline)) {
+    const int slot = p % RING;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      blds16(rW, lane16, (unsigned)(p * RC_PAIR + (j * 8 + wave) * 1024), lds0 + slot * RC_PAIR + (j * 8 + wave) * 1024);
+  };
+#pragma unroll
+  for (int q = 0; q < RING - 1; ++q)
+    if (q < NP) issue_pair(q);
+
+  // stage-1 bias of this lane's rows: row = 128 rb + 32 cg + 8 g + 4 hi + i  <->  register 4 g + i of block rb
+  float4 b1[NB1][4];
+#pragma unroll
+  for (int rb = 0; rb < NB1; ++rb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b1[rb][g] = *reinterpret_cast<const float4*>(a.bias1 + 128 * rb + 32 * cg + 8 * g + 4 * hi);
+  // residual rows of this lane's tokens: independent of everything else, so their latency hides under the first tiles
+  // (res may alias out1 element for element: the same lane reads here and writes in the stage-1 epilogue)
+  float4 rr[NT][NB1][4];
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int rb = 0; rb < NB1; ++rb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m = m0 + tok0 + 32 * u;
+        rr[u][rb][g] = (a.res && m < a.M) ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.ldres + 128 * rb + 32 * cg + 8 * g + 4 * hi)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+
+  int p = 0;                                        // next pair to consume (compile-time after unrolling)
+  auto step_begin = [&]() __attribute__((always_inline)) -> const char* {
+    // pair p has landed when only the pieces (four per wave and pair) of the pair behind it may still be in flight.  Loads
+    // complete in issue order among themselves, so other outstanding memory operations (the result stores of the stage-1
+    // epilogue) can only make this wait longer than necessary, never shorter.
+    if (NP - 1 - p >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragment reads of the slot about to be refilled are done
+    __builtin_amdgcn_s_barrier();
+    if (p + RING - 1 < NP) issue_pair(p + RING - 1);
+    return ring + (p % RING) * RC_PAIR;
+  };
+  const char* const bpanel = panel + tok0 * 128;    // this lane's first token row inside a panel tile (+ kt * PTILE + u * 4096)
+
+  // one 16-KB tile: acc[u] += W[rows 32 cg ..][64 k] * panel[kt][tokens of block u]^T; the weight fragments serve all NT blocks
+  auto tile_mma = [&](f32x16_t (&acc)[NT], const char* T, int kt) __attribute__((always_inline)) {
+    const char* wrow = T + (32 * cg + l31) * 128;
+    u32x4_t fb[NT][4], fw[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ((2 * ks + hi) ^ sw) * 16;
+      fw[ks] = *reinterpret_cast<const u32x4_t*>(wrow + c);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) fb[u][ks] = *reinterpret_cast<const u32x4_t*>(bpanel + kt * PTILE + u * 4096 + c);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int u = 0; u < NT; ++u) MmaT<TM>::mma(acc[u], fw[ks], fb[u][ks]);
+  };
+
+  // ---- stage 1: y^T = W1 A^T
+  f32x16_t acc1[NB1][NT];
+#pragma unroll
+  for (int i = 0; i < NB1; ++i)
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[i][u][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < S1 / 2; ++j) {
+    const char* T = step_begin();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = 2 * j + t;
+      tile_mma(acc1[i % NB1], T + t * RC_TILE, i / NB1);
+    }
+    ++p;
+  }
+
+  // ---- stage-1 epilogue, per lane: + bias (+ fp32 residual), fp32 result row segments, LayerNorm sums, operand copy
+  // into the panel
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                     // every wave is done reading A: the panel may be overwritten with y
+  float mean[NT], rstd[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    const int tok = tok0 + 32 * u, mtok = m0 + tok;
+    const bool tok_ok = mtok < a.M;
+    float ps = 0.f, pq = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NB1; ++rb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = acc1[rb][u][4 * g + 0] + b1[rb][g].x + rr[u][rb][g].x;
+        v.y = acc1[rb][u][4 * g + 1] + b1[rb][g].y + rr[u][rb][g].y;
+        v.z = acc1[rb][u][4 * g + 2] + b1[rb][g].z + rr[u][rb][g].z;
+        v.w = acc1[rb][u][4 * g + 3] + b1[rb][g].w + rr[u][rb][g].w;
+        const int n = 128 * rb + 32 * cg + 8 * g + 4 * hi;
+        if (tok_ok) {
+          if (a.out1_f32) out_f4(a.out1_f32 + (size_t)mtok * a.ldo1 + n, v.x, v.y, v.z, v.w);
+          ps += (v.x + v.y) + (v.z + v.w);
+          pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        } else {
+          v = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past M: a zero operand row (nothing of it is stored)
+        }
+        // operand copy: channel n -> k tile n / 64, 16-B chunk (n % 64) / 8, bytes 8 hi .. + 7 of the chunk
+        char* dst = panel + (n >> 6) * PTILE + tok * 128 + ((((n & 63) >> 3) ^ sw) * 16) + 8 * hi;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(v.x, v.y), Op16<TM>::pack(v.z, v.w));
+      }
+    // the two lane halves of a token, then the four row groups through LDS
+    const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
+    const auto q2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pq), __float_as_uint(pq), false, false);
+    ps = __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+    pq = __uint_as_float(q2[0]) + __uint_as_float(q2[1]);
+    if (hi == 0) stats[tok * 4 + cg] = make_float2(ps, pq);
+  }
+  __syncthreads();                                  // y panel and statistics complete
+  {
+    float ratio = 0.f;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int tok = tok0 + 32 * u;
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float2 v = stats[tok * 4 + k]; s += v.x; q += v.y; }   // fixed order: deterministic
+      const float inv = 1.0f / (float)D;
+      mean[u] = s * inv;
+      double var = (double)q * (double)inv - (double)mean[u] * (double)mean[u];
+      if (var < 0.0) var = 0.0;
+      rstd[u] = 1.0f / sqrtf((float)var + a.ln_eps);
+      if (m0 + tok < a.M) ratio = fmaxf(ratio, fabsf(mean[u]) * rstd[u]);
+    }
+    if (a.ln_health && cg == 0) {          // same health report as the LayerNorm-consumer GEMMs (gemm.hip ln_row_finish)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
+      if (lane == 0 && ratio > __uint_as_float(__hip_atomic_load(a.ln_health, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+        atomicMax(a.ln_health, __float_as_uint(ratio));
+    }
+  }
+
+  // ---- stage 2: z^T = W2' y_op^T, all R2 row blocks accumulate at once (k-tile outer)
+  f32x16_t acc2[R2][NT];
+#pragma unroll
+  for (int i = 0; i < R2; ++i)
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[i][u][r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < S2 / 2; ++j) {
+    const char* T = step_begin();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = 2 * j + t;
+      tile_mma(acc2[i % R2], T + t * RC_TILE, i / R2);
+    }
+    ++p;
+  }
+
+  // ---- stage-2 epilogue: LayerNorm fix-up + bias per element, operand rows out.  A lane holds 4 consecutive channels per
+  // register group g; the two lane halves trade groups so that every lane stores 8 consecutive channels (16 B)
+  TM* const oo = reinterpret_cast<TM*>(a.out2_op);
+#pragma unroll
+  for (int rb = 0; rb < R2; ++rb) {
+    float4 c0[4], c1[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float* cv = consts + (size_t)(128 * rb + 32 * cg + 8 * g + 4 * hi) * 2;      // (rowsum, bias) x 4 rows
+      c0[g] = *reinterpret_cast<const float4*>(cv); c1[g] = *reinterpret_cast<const float4*>(cv + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int mtok = m0 + tok0 + 32 * u;
+      uint32_t pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float z0 = rstd[u] * (acc2[rb][u][4 * g + 0] - mean[u] * c0[g].x) + c0[g].y;
+        const float z1 = rstd[u] * (acc2[rb][u][4 * g + 1] - mean[u] * c0[g].z) + c0[g].w;
+        const float z2 = rstd[u] * (acc2[rb][u][4 * g + 2] - mean[u] * c1[g].x) + c1[g].y;
+        const float z3 = rstd[u] * (acc2[rb][u][4 * g + 3] - mean[u] * c1[g].z) + c1[g].w;
+        pk[g][0] = Op16<TM>::pack(z0, z1);
+        pk[g][1] = Op16<TM>::pack(z2, z3);
+      }
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {         // groups (2 gp, 2 gp + 1): lower half ends up with group 2 gp, upper half with 2 gp + 1
+        const auto x0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+        const auto x1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+        const int n = 128 * rb + 32 * cg + 8 * (2 * gp + hi);
+        if (mtok < a.M) *reinterpret_cast<u32x4_t*>(oo + (size_t)mtok * a.ldo2 + n) = u32x4_t{x0[0], x1[0], x0[1], x1[1]};
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side: tile-stream packer and launcher
+// ---------------------------------------------------------------------------
+// one 16 KB tile [128 rows][64 k] of a row-major fp32 matrix, rounded to the operand type, in the swizzled LDS image:
+// byte r*128 + pos*16 holds logical chunk pos ^ ((r>>1)&7) of row r
+static void rc_append_tile(std::vector<unsigned short>& out, const float* mat, size_t ld, int row0, int col0, int prec) {
+  for (int r = 0; r < 128; ++r)
+    for (int pos = 0; pos < 8; ++pos) {
+      const int lc = pos ^ ((r >> 1) & 7);
+      for (int e = 0; e < 8; ++e) out.push_back(f32_to_op16_bits(mat[(size_t)(row0 + r) * ld + col0 + lc * 8 + e], prec));
+    }
+}
+
+// w1 [dim][dim], w2 [n2][dim] (LayerNorm-folded), both fp32 host row-major (K contiguous)
+hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out) {
+  if (!rowchain_eligible(dim, n2, 64, prec)) return hipErrorInvalidValue;
+  const int KT = dim / 64;
+  out.clear();
+  out.reserve((size_t)(dim + n2) * dim);
+  for (int kt = 0; kt < KT; ++kt)
+    for (int rb = 0; rb < dim / 128; ++rb) rc_append_tile(out, w1, dim, 128 * rb, 64 * kt, prec);
+  for (int kt = 0; kt < KT; ++kt)
+    for (int rb = 0; rb < n2 / 128; ++rb) rc_append_tile(out, w2, dim, 128 * rb, 64 * kt, prec);
+  return hipSuccess;
+}
+
+bool rowchain_eligible(int dim, int n2, int T, int prec) {
+  return (dim == 128 || dim == 256) && (n2 == dim || n2 == 3 * dim) && T >= 1 && (prec == PREC_BF16 || prec == PREC_F16);
+}
+
+template <typename TM, int D, int R2, int NT> static hipError_t launch_rc(const RowchainArgs& a, hipStream_t s) {
+  const size_t lds = RowchainGeom<D, R2, NT>::LDS;
+  constexpr int TOK = RowchainGeom<D, R2, NT>::TOK;
+  hipLaunchKernelGGL((rowchain_kernel<TM, D, R2, NT>), dim3((a.M + TOK - 1) / TOK), dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+// 64-token workgroups by default.  At dim 128 a workgroup's weights are small and M is large: when 64-token blocks would not
+// fit the chip in one round (one workgroup per CU: the LDS ring), 128-token blocks halve the grid and the weight traffic
+static int g_force_nt = getenv("NS2VC_ROWCHAIN_NT") ? atoi(getenv("NS2VC_ROWCHAIN_NT")) : 0;   // test / tuning hook: 1 / 2 forces the block size (2 only exists for dim 128)
+void set_forced_rowchain_tokens(int nt) { g_force_nt = nt; }
+template <typename TM> static hipError_t launch_rc_tm(const RowchainArgs& a, hipStream_t s) {
+  if (a.dim == 128) {
+    const bool big = g_force_nt ? g_force_nt == 2 : (a.M + 63) / 64 > 256;
+    if (big) return a.n2 == 128 ? launch_rc<TM, 128, 1, 2>(a, s) : launch_rc<TM, 128, 3, 2>(a, s);
+    return a.n2 == 128 ? launch_rc<TM, 128, 1, 1>(a, s) : launch_rc<TM, 128, 3, 1>(a, s);
+  }
+  return a.n2 == 256 ? launch_rc<TM, 256, 2, 1>(a, s) : launch_rc<TM, 256, 6, 1>(a, s);
+}
+
+hipError_t launch_rowchain(const RowchainArgs& a, int prec, hipStream_t s) {
+  if (!rowchain_eligible(a.dim, a.n2, 64, prec) || a.M <= 0) return hipErrorInvalidValue;
+  if (!a.a_op || !a.wstream || !a.bias1 || !a.consts2 || !a.out2_op) return hipErrorInvalidValue;
+  if ((a.lda & 7) || (a.res && (a.ldres & 3)) || (a.out1_f32 && (a.ldo1 & 3)) || (a.ldo2 & 7)) return hipErrorInvalidValue;
+  if ((unsigned long long)a.M * a.lda * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
+  return prec == PREC_BF16 ? launch_rc_tm<bf16_t>(a, s) : launch_rc_tm<f16_t>(a, s);
+}
+
+hipError_t init_rowchain_attributes() {
+  hipError_t e;
+#define NS2VC_RC_ATTR(TM, DD_, RR_, NT_)                                                                                            \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_kernel<TM, DD_, RR_, NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)RowchainGeom<DD_, RR_, NT_>::LDS)) != hipSuccess) return e
+  NS2VC_RC_ATTR(bf16_t, 128, 1, 1); NS2VC_RC_ATTR(bf16_t, 128, 3, 1); NS2VC_RC_ATTR(bf16_t, 256, 2, 1); NS2VC_RC_ATTR(bf16_t, 256, 6, 1);
+  NS2VC_RC_ATTR(f16_t, 128, 1, 1); NS2VC_RC_ATTR(f16_t, 128, 3, 1); NS2VC_RC_ATTR(f16_t, 256, 2, 1); NS2VC_RC_ATTR(f16_t, 256, 6, 1);
+  NS2VC_RC_ATTR(bf16_t, 128, 1, 2); NS2VC_RC_ATTR(bf16_t, 128, 3, 2); NS2VC_RC_ATTR(f16_t, 128, 1, 2); NS2VC_RC_ATTR(f16_t, 128, 3, 2);
+#undef NS2VC_RC_ATTR
+  return hipSuccess;
+}
+
+}  // namespace ns2vc

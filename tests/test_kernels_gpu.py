@@ -780,3 +780,68 @@ def test_layout_roundtrip(diag):
         assert np.array_equal(y[:, :, :C_], x.transpose(0, 2, 1))
         assert np.all(y[:, :, C_:] == 0)
         assert np.array_equal(d_z.to_numpy((B, C_, T)), x)
+
+
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("dim,mult,M,res,nt", [(128, 3, 450, False, 1), (128, 1, 450, True, 1), (256, 3, 194, False, 1), (256, 1, 1000, True, 1),
+                                               (128, 3, 64, False, 1), (256, 1, 5, True, 1), (128, 3, 450, False, 2), (128, 1, 333, True, 2),
+                                               (128, 1, 70, True, 2), (128, 3, 18000, False, 0)], ids=str)
+def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
+    """Two token-local GEMMs with a LayerNorm in between in one launch (csrc/rowchain.hip) against numpy fp64 of
+        y = A W1^T + b1 (+ res);   z = LayerNorm(y) W2^T + b2
+    with the engine's pack-time fold (gamma/beta into W2/b2), the kernel's rounding points modelled (A, the weights and y's
+    operand copy are rounded to the operand type; statistics from the fp32 y), rows with a common offset (LayerNorm by
+    linearity), row counts that are no multiple of 64, res aliasing out1 (as the engine uses it), NaN-filled outputs, and
+    both workgroup sizes (nt = 1: 64 tokens, 2: 128 tokens, 0: the launcher's choice -- 128 once M > 256 x 64 at dim 128)."""
+    from ns2vc_amd._lib import RowchainArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(dim * 1000 + mult * 10 + M)
+    d, n2 = dim, mult * dim
+    A = rng.standard_normal((M, d)).astype(np.float32)
+    R = (rng.standard_normal((M, d)) + 1.5 * rng.standard_normal((M, 1))).astype(np.float32)
+    W1, b1 = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32), (0.3 * rng.standard_normal(d)).astype(np.float32)
+    gamma, beta = (1.0 + 0.2 * rng.standard_normal(d)), 0.2 * rng.standard_normal(d)
+    W2, b2 = rng.standard_normal((n2, d)) / np.sqrt(d), 0.3 * rng.standard_normal(n2)
+    W2f, b2f = (W2 * gamma[None, :]).astype(np.float32), (b2 + W2 @ beta).astype(np.float32)
+    Ar, W1r, W2r = rnd(A, prec).astype(np.float64), rnd(W1, prec).astype(np.float64), rnd(W2f, prec).astype(np.float64)
+    consts = np.stack([W2r.sum(1), b2f.astype(np.float64)], axis=1).astype(np.float32)
+    # ---- reference with the kernel's rounding points
+    y = Ar @ W1r.T + b1.astype(np.float64)[None, :] + (R.astype(np.float64) if res else 0.0)
+    y32 = y.astype(np.float32)
+    yr = rnd(y32, prec).astype(np.float64)
+    mean, var = y.mean(1, keepdims=True), y.var(1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + 1e-5)
+    z = rstd * (yr @ W2r.T - mean * consts[:, 0].astype(np.float64)[None, :]) + b2f.astype(np.float64)[None, :]
+    # ---- device
+    stream = C.c_void_p()
+    check(lib.ns2vc_pack_rowchain(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, prec, C.byref(stream)), "pack_rowchain")
+    d_a, d_b1, d_c = OpBuf(A, prec), _dev(b1), _dev(consts)
+    d_y = DevBuf(M * d * 4)
+    d_y.upload(R if res else np.full((M, d), np.nan, dtype=np.float32))          # res aliases out1 (in-place residual stream)
+    d_z = OpBuf(np.full((M, n2), np.nan, dtype=np.float32), prec)
+    d_health = DevBuf.from_numpy(np.zeros(16, dtype=np.uint32))
+    f = RowchainArgs()
+    f.a_op = d_a.ptr; f.lda = d; f.wstream = stream.value; f.bias1 = d_b1.ptr; f.consts2 = d_c.ptr
+    f.res = d_y.ptr if res else None; f.ldres = d
+    f.out1_f32 = d_y.ptr; f.ldo1 = d; f.out2_op = d_z.ptr; f.ldo2 = n2
+    f.ln_eps = 1e-5; f.M = M; f.dim = d; f.n2 = n2; f.ln_health = d_health.ptr
+    check(lib.ns2vc_debug_set_rowchain_tokens(nt), "set_rowchain_tokens")
+    try:
+        check(lib.ns2vc_k_rowchain(C.byref(f), prec, None), "k_rowchain")
+        sync()
+    finally:
+        lib.ns2vc_debug_set_rowchain_tokens(0)
+    yo, zo = d_y.to_numpy((M, d)), d_z.read()
+    e_y, e_z = rel_l2(yo, y), rel_l2(zo, z)
+    ratio = float(d_health.to_numpy((16,), dtype=np.uint32)[:1].view(np.float32)[0])
+    diag(f"rowchain dim={d} n2={n2} M={M} res={res} nt={nt} prec={prec}: y {e_y:.3e} z {e_z:.3e} nan={int(np.isnan(zo).sum())}  |mean|/std {ratio:.2f}")
+    if not (e_y < 1e-6 and e_z < eps16(prec)):
+        err = np.abs(zo - z)
+        bad = np.argwhere(~(err <= 2e-2 + 2e-2 * np.abs(z)))
+        diag(f"  FAIL: {len(bad)} bad of {zo.size}; rows {sorted(set(bad[:, 0].tolist()))[:16]} cols {sorted(set(bad[:, 1].tolist()))[:24]}")
+    assert np.isfinite(zo).all() and np.isfinite(yo).all()
+    assert e_y < 1e-6                       # fp32 accumulation of exactly rounded operands
+    assert e_z < eps16(prec)                # one operand rounding of the result on top of a near-exact value
+    want = (np.abs(y.mean(1)) / np.sqrt(y.var(1) + 1e-5)).max()
+    assert abs(ratio - want) < 1e-3 * want
