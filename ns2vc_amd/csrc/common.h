@@ -231,6 +231,8 @@ hipError_t launch_rowchain(const ::ns2vc_rowchain_args& a, int prec, hipStream_t
 bool rowchain_eligible(int dim, int n2, int T, int prec);
 hipError_t init_rowchain_attributes();
 void set_forced_rowchain_tokens(int nt);        // test hook: 0 = heuristic, 1 = 64-token blocks, 2 = 128-token blocks (dim 128 only)
+hipError_t launch_emb_from_table(const float* table, const int* step_ptr, const float* aug, float* emb, void* emb_act_op, int prec, int B,
+                                 int edim, hipStream_t s);
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);                                  // bytes: any; p 16-byte aligned
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);           // bytes % 16 == 0
 hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStream_t s);

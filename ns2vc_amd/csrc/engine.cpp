@@ -155,6 +155,8 @@ struct ns2vc_unet {
   int* step_dev = nullptr;
   size_t stats_bytes = 8;
   float* coef_dev = nullptr;
+  float* temb_table = nullptr;   // [kMaxSteps][time_embed_dim]: the timestep MLP of every row of the solver table (sampling loop only)
+  bool temb_table_valid = false;
   int steps = 0;
   bool use_step_table = false;
 
@@ -166,6 +168,7 @@ struct ns2vc_unet {
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (arena) (void)hipFree(arena);
     if (coef_dev) (void)hipFree(coef_dev);
+    if (temb_table) (void)hipFree(temb_table);
     for (void* p : weight_allocs) (void)hipFree(p);
   }
 };
@@ -963,7 +966,8 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     void* emb_act = h->emb_act_op;
     const int tdim = c0;
     P.add("time_embed", [=](hipStream_t s) {
-      if (hh->use_step_table) return launch_time_embed(hh->coef_dev, 0, hh->step_dev, NS2VC_NCOEF, w1t, b1, w2t, b2, aug, emb, emb_act, prec, B, tdim, E, s);
+      // sampling loop: the MLP of every step's timestep was evaluated once for the table (ns2vc_sampler_run), a step adds aug
+      if (hh->use_step_table) return launch_emb_from_table(hh->temb_table, hh->step_dev, aug, emb, emb_act, prec, B, E, s);
       return launch_time_embed(tdev, 1, nullptr, 0, w1t, b1, w2t, b2, aug, emb, emb_act, prec, B, tdim, E, s);
     });
     P.tap("emb", emb, B, E);
@@ -1211,6 +1215,7 @@ int ns2vc_unet_finalize_weights(ns2vc_unet* h, int precision) {
   h->prec = precision;
   if (pack_all(h)) return 1;
   h->finalized = true;
+  h->temb_table_valid = false;
   drop_plan(h);       // a plan built for other weights holds stale pointers
   return 0;
 }
@@ -1332,6 +1337,7 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
   HIPCHK(hipDeviceSynchronize());   // a previous loop may still be reading the table
   HIPCHK(hipMemcpy(h->coef_dev, coef_host, (size_t)steps * NS2VC_NCOEF * sizeof(float), hipMemcpyHostToDevice));
   h->steps = steps;
+  h->temb_table_valid = false;
   return 0;
 }
 
@@ -1351,6 +1357,13 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
   const auto& c = h->cfg;
   const size_t n = (size_t)h->B * h->T * h->CP;
   h->use_step_table = true;
+  if (!h->temb_table_valid) {      // new table or new weights: timestep MLP of every table row (column 0 = t), no prompt term
+    const int E = c.block_out_channels[0] * 4;
+    if (!h->temb_table) HIPCHK(hipMalloc((void**)&h->temb_table, (size_t)1024 * E * sizeof(float)));
+    HIPCHK(launch_time_embed(h->coef_dev, NS2VC_NCOEF, nullptr, 0, h->t_w1t, h->t_b1, h->t_w2t, h->t_b2, nullptr, h->temb_table, nullptr,
+                             h->prec, h->steps, c.block_out_channels[0], E, s));
+    h->temb_table_valid = true;
+  }
   if (use_graph && !h->step_graph) {
     if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;

@@ -432,8 +432,25 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float* __restrict
     float y = b2[o] + ((s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]));
     if (aug) y += aug[(size_t)b * edim + o];
     emb[(size_t)b * edim + o] = y;
-    store_op<TM>(emb_act + (size_t)b * edim + o, y / (1.0f + expf(-y)));
+    if (emb_act) store_op<TM>(emb_act + (size_t)b * edim + o, y / (1.0f + expf(-y)));
   }
+}
+// Sampling loop: every batch item shares the step's timestep and the timesteps of all steps are known when the solver
+// table is loaded, so the timestep MLP is evaluated ONCE per table (time_embed_kernel over the table's rows, aug = NULL)
+// and a step only adds the prompt embedding: emb[b] = table[step] + aug[b] -- the same two fp32 additions in the same
+// order as the direct kernel, hence bit-identical to it.
+template <typename TM>
+__global__ __launch_bounds__(256) void emb_from_table_kernel(const float* __restrict__ table, const int* __restrict__ step_ptr,
+                                                             const float* __restrict__ aug, float* __restrict__ emb,
+                                                             TM* __restrict__ emb_act, int edim, int n) {
+  op_mode_init<TM>();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int o = i % edim;
+  float y = table[(size_t)(*step_ptr) * edim + o];
+  if (aug) y += aug[i];
+  emb[i] = y;
+  store_op<TM>(emb_act + i, y / (1.0f + expf(-y)));
 }
 
 // ---------------------------------------------------------------------------
@@ -642,6 +659,13 @@ hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStr
     attr = true;
   }
   hipLaunchKernelGGL(poison_kernel, dim3(2048), dim3(256), (size_t)lds_bytes, s, pattern, lds_bytes / 4, sink);
+  return hipGetLastError();
+}
+hipError_t launch_emb_from_table(const float* table, const int* step_ptr, const float* aug, float* emb, void* emb_act_op, int prec, int B,
+                                 int edim, hipStream_t s) {
+  const int n = B * edim;
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(emb_from_table_kernel<TMX>, dim3((n + 255) / 256), dim3(256), 0, s, table, step_ptr, aug, emb,
+                                         (TMX*)emb_act_op, edim, n));
   return hipGetLastError();
 }
 hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s) {
