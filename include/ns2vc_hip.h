@@ -225,6 +225,12 @@ typedef struct ns2vc_rowchain_args {
   void* out2_op; int32_t ldo2;              /* operand-typed z [M][ldo2] */
   float ln_eps; int32_t M, dim, n2;
   unsigned* ln_health;                      /* optional, as in ns2vc_gemm_args */
+  /* optional GroupNorm prologue: A = GroupNorm(gn_x) (affine, no activation) built inside the kernel; a_op is ignored.
+   * gn_x fp32 [M][ldx]; gn_stats = the producer's per-(batch item, 16-channel block) int64 (sum, sumsq) as left by
+   * ns2vc_gemm_args.stats; gn_gamma / gn_beta [dim]; T = rows per batch item (>= 64); G = groups (dim/G a multiple of 16) */
+  const float* gn_x; int32_t ldx;
+  const long long* gn_stats; const float* gn_gamma; const float* gn_beta;
+  float gn_eps; int32_t T, G;
 } ns2vc_rowchain_args;
 /* w1 [dim][dim], w2 [n2][dim]: fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
 int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int n2, int precision, void** out_stream_dev);

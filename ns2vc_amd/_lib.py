@@ -72,6 +72,9 @@ class RowchainArgs(C.Structure):
         ("out2_op", C.c_void_p), ("ldo2", C.c_int32),
         ("ln_eps", C.c_float), ("M", C.c_int32), ("dim", C.c_int32), ("n2", C.c_int32),
         ("ln_health", C.c_void_p),
+        ("gn_x", C.c_void_p), ("ldx", C.c_int32),
+        ("gn_stats", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
+        ("gn_eps", C.c_float), ("T", C.c_int32), ("G", C.c_int32),
     ]
 
 

@@ -140,6 +140,7 @@ struct ns2vc_unet {
   // (16-bit precisions, dim 128 / 256, LayerNorm by linearity and the fold on).  NS2VC_FUSE_FFN=0 restores the two GEMMs.
   bool fuse_ffn = true;
   bool fuse_rows = true;     // proj_in+q|k|v and attn1.to_out+attn2.to_q as one launch each (rowchain.hip)
+  bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -748,7 +749,6 @@ struct Planner {
                    void* out_op) {
     const int d = a.dim, M = B * Tl, hd = d / h->cfg.heads, pr = prec;
     const std::string t = a.prefix + ".transformer_blocks.0";
-    groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
     GemmArgs g;
     auto layernorm = [&](const std::string& nm) {
       add(nm, [=](hipStream_t s) { return launch_ln_apply_op(y, d, M, d, 1e-5f, yn, pr, s); }, 3, 8.0 * M * d, (4.0 + opsz) * M * d);
@@ -761,19 +761,25 @@ struct Planner {
     };
     float* r1 = lin ? rs1 : nullptr;
     // token-local chains in one launch each (rowchain.hip): same arithmetic and rounding points as the two GEMMs they replace
-    auto rowchain = [&](const std::string& nm, const void* a_op, void* stream, const float* bias1, const float* consts2, const float* res,
-                        void* z_op, int n2) {
+    auto rowchain = [&](const std::string& nm, const void* a_op, const long long* gn_st, void* stream, const float* bias1, const float* consts2,
+                        const float* res, void* z_op, int n2) {
       ns2vc_rowchain_args c;
       memset(&c, 0, sizeof(c));
       c.a_op = a_op; c.lda = d; c.wstream = stream; c.bias1 = bias1; c.consts2 = consts2;
       c.res = res; c.ldres = d; c.out1_f32 = y; c.ldo1 = d; c.out2_op = z_op; c.ldo2 = n2;
       c.ln_eps = 1e-5f; c.M = M; c.dim = d; c.n2 = n2; c.ln_health = h->ln_health;
+      if (gn_st) {       // A = GroupNorm(x) built in the kernel's prologue from the producer's epilogue statistics
+        c.a_op = nullptr; c.gn_x = x; c.ldx = d; c.gn_stats = gn_st; c.gn_gamma = a.ng; c.gn_beta = a.nb; c.gn_eps = 1e-6f; c.T = Tl; c.G = G;
+      }
       add(nm, [=](hipStream_t s) { return launch_rowchain(c, pr, s); }, 1, 2.0 * M * (double)d * (d + n2),
-          (double)M * (d * (opsz + 4.0 + (res ? 4.0 : 0.0)) + n2 * opsz) + (double)(d + n2) * d * opsz);
+          (double)M * (d * ((gn_st ? 4.0 : opsz) + 4.0 + (res ? 4.0 : 0.0)) + n2 * opsz) + (double)(d + n2) * d * opsz);
     };
     const bool rows_ok = lin && h->fuse_rows && a.chain_in && a.chain_mid && rowchain_eligible(d, d, Tl, pr);
+    const long long* xst = (rows_ok && h->fuse_rows_gn && Tl >= 64 && (d % G) == 0 && ((d / G) % 16) == 0) ? find_stats(x) : nullptr;
+    if (!xst) groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
     if (rows_ok) {
-      rowchain(a.prefix + ".rows[proj_in+qkv]", xn, a.chain_in, a.proj_in.bias, a.chain_in_consts, nullptr, qkv, 3 * d);
+      rowchain(a.prefix + (xst ? ".rows[norm+proj_in+qkv]" : ".rows[proj_in+qkv]"), xn, xst, a.chain_in, a.proj_in.bias, a.chain_in_consts, nullptr, qkv,
+               3 * d);
     } else {
       g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
       g.rowstats = r1;
@@ -787,7 +793,7 @@ struct Planner {
     attention(t + ".attn1.sdpa", qkv, 3 * d, op_off(qkv, d), 3 * d, op_off(qkv, 2 * d), 3 * d, Tl, Tl, nullptr, hd, ao, d);
     float* r2 = lin ? rs2 : nullptr;
     if (rows_ok) {
-      rowchain(t + ".rows[attn1.to_out+attn2.to_q]", ao, a.chain_mid, a.o1.bias, a.chain_mid_consts, y, qb, d);
+      rowchain(t + ".rows[attn1.to_out+attn2.to_q]", ao, nullptr, a.chain_mid, a.o1.bias, a.chain_mid_consts, y, qb, d);
     } else {
       g = base(ao, d, d, Tl, Tl, a.o1, y, r2 ? yn : nullptr, d);
       g.res = y; g.ldres = d;
@@ -1163,6 +1169,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FOLD_FF")) h->fold_ff = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1238,7 +1245,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fold_ff")) opt = &h->fold_ff;
   else if (!strcmp(name, "fuse_ffn")) opt = &h->fuse_ffn;
   else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_rows)", name);
+  else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_rows, fuse_rows_gn)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }

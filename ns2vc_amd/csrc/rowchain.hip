@@ -67,8 +67,11 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
 
   const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * RC_PAIR);
   const unsigned lane16 = (unsigned)(lane * 16);
-  // ---- DMA: token panel (source-side swizzle, rows past M read as zeros), stage-2 constants, then the weight stream
-  {
+  // ---- token panel.  Plain case: LDS-DMA of the operand rows (source-side swizzle, rows past M read as zeros).
+  // GroupNorm case (a.gn_x: the panel is GroupNorm(x), the `norm` of Transformer2DModel, transformer_1d.py:268): the fp32 rows
+  // of x are normalised here with the statistics the producing GEMM's epilogue left -- the same arithmetic as
+  // gn_apply_kernel (misc.hip), so the panel is bit-identical to what that launch would have written.
+  if (a.gn_x == nullptr) {
     const int pchunk = lane & 7;
     const i32x4_t rA = make_rsrc(a.a_op, (unsigned long long)a.M * a.lda * 2ull);
 #pragma unroll
@@ -80,6 +83,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       for (int kt = 0; kt < KT; ++kt)
         blds16(rA, voff, (unsigned)(kt * 128), lds0 + RING * RC_PAIR + kt * PTILE + u * 8192 + wave * 1024);
     }
+  }
+  {
     const i32x4_t rC = make_rsrc(a.consts2, (unsigned long long)G::CONSTS);
     if (wave < G::CONSTS / 1024) blds16(rC, lane16, (unsigned)(wave * 1024), lds0 + RING * RC_PAIR + G::PANEL + wave * 1024);
   }
@@ -113,6 +118,55 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
         rr[u][rb][g] = (a.res && m < a.M) ? *reinterpret_cast<const float4*>(a.res + (size_t)m * a.ldres + 128 * rb + 32 * cg + 8 * g + 4 * hi)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+
+  if (a.gn_x) {
+    constexpr int QPR = D / 4, RPP = 512 / QPR, NPASS = TOK / RPP;      // float4 quads per row, rows per pass
+    const int quad = tid % QPR, r0 = tid / QPR, c = 4 * quad;
+    float4 xv[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int m = m0 + ps * RPP + r0;
+      xv[ps] = m < a.M ? *reinterpret_cast<const float4*>(a.gn_x + (size_t)m * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 ga = *reinterpret_cast<const float4*>(a.gn_gamma + c), be = *reinterpret_cast<const float4*>(a.gn_beta + c);
+    // (mean, rstd) of every (batch item touched by this block, group): at most 4 items (the launcher checks T)
+    const int Cg = D / a.G, nb = Cg >> 4, nblk = D >> 4;
+    const int b_lo = m0 / a.T;
+    const int nbi = (min(m0 + TOK, a.M) - 1) / a.T - b_lo + 1;
+    float2* const gtab = stats;                      // free until the stage-1 epilogue
+    if (tid < nbi * a.G) {
+      const int bi = tid / a.G, g = tid - bi * a.G;
+      const long long* st = a.gn_stats + ((size_t)(b_lo + bi) * nblk + (size_t)g * nb) * 2;
+      double ds = 0.0, dq = 0.0;
+      for (int j = 0; j < nb; ++j) { ds += (double)st[2 * j] * (1.0 / GN_SUM_SCALE); dq += (double)st[2 * j + 1] * (1.0 / GN_SQ_SCALE); }
+      const float inv_nf = 1.0f / ((float)a.T * (float)Cg);
+      const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)a.T * (double)Cg));
+      const double mean = ds * inv_n;
+      double var = dq * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float ve = (float)var + a.gn_eps;
+      float r = rsqrtf(ve);
+      r = r * (1.5f - 0.5f * ve * r * r);
+      gtab[bi * 8 + g] = make_float2((float)mean, r);
+    }
+    __syncthreads();
+    const int g = c / Cg;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + r0, m = m0 + row;
+      int bi = 0;                                    // batch item of this row, relative to b_lo (no division)
+#pragma unroll
+      for (int k = 1; k < 4; ++k) bi += (m >= (b_lo + k) * a.T) ? 1 : 0;
+      const float2 mr = gtab[min(bi, 3) * 8 + g];
+      const float s0 = mr.y * ga.x, s1 = mr.y * ga.y, s2 = mr.y * ga.z, s3 = mr.y * ga.w;
+      float y0 = xv[ps].x * s0 + (be.x - mr.x * s0), y1 = xv[ps].y * s1 + (be.y - mr.x * s1);
+      float y2 = xv[ps].z * s2 + (be.z - mr.x * s2), y3 = xv[ps].w * s3 + (be.w - mr.x * s3);
+      if (m >= a.M) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
+      char* dst = panel + (c >> 6) * PTILE + row * 128 + ((((c & 63) >> 3) ^ ((row >> 1) & 7)) * 16) + (c & 4) * 2;
+      *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(y0, y1), Op16<TM>::pack(y2, y3));
+    }
+    // (no barrier here: the first step_begin drains the LDS writes and synchronises the block before any fragment read)
+  }
 
   int p = 0;                                        // next pair to consume (compile-time after unrolling)
   auto step_begin = [&]() __attribute__((always_inline)) -> const char* {
@@ -330,8 +384,12 @@ template <typename TM> static hipError_t launch_rc_tm(const RowchainArgs& a, hip
 
 hipError_t launch_rowchain(const RowchainArgs& a, int prec, hipStream_t s) {
   if (!rowchain_eligible(a.dim, a.n2, 64, prec) || a.M <= 0) return hipErrorInvalidValue;
-  if (!a.a_op || !a.wstream || !a.bias1 || !a.consts2 || !a.out2_op) return hipErrorInvalidValue;
-  if ((a.lda & 7) || (a.res && (a.ldres & 3)) || (a.out1_f32 && (a.ldo1 & 3)) || (a.ldo2 & 7)) return hipErrorInvalidValue;
+  if ((!a.a_op && !a.gn_x) || !a.wstream || !a.bias1 || !a.consts2 || !a.out2_op) return hipErrorInvalidValue;
+  if (a.gn_x) {      // GroupNorm prologue: per-16-channel-block statistics, groups of whole blocks, <= 4 batch items per 128 tokens
+    if (!a.gn_stats || !a.gn_gamma || !a.gn_beta || a.G < 1 || a.G > 8 || a.T < 64 || (a.dim % a.G) || ((a.dim / a.G) & 15) || (a.ldx & 3))
+      return hipErrorInvalidValue;
+  } else if (a.lda & 7) return hipErrorInvalidValue;
+  if ( (a.res && (a.ldres & 3)) || (a.out1_f32 && (a.ldo1 & 3)) || (a.ldo2 & 7)) return hipErrorInvalidValue;
   if ((unsigned long long)a.M * a.lda * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
   return prec == PREC_BF16 ? launch_rc_tm<bf16_t>(a, s) : launch_rc_tm<f16_t>(a, s);
 }

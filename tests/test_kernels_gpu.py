@@ -845,3 +845,69 @@ def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
     assert e_z < eps16(prec)                # one operand rounding of the result on top of a near-exact value
     want = (np.abs(y.mean(1)) / np.sqrt(y.var(1) + 1e-5)).max()
     assert abs(ratio - want) < 1e-3 * want
+
+
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("dim,B,T,nt", [(128, 3, 150, 1), (128, 5, 64, 2), (256, 2, 97, 1), (128, 2, 300, 2), (256, 4, 64, 1)], ids=str)
+def test_rowchain_groupnorm_prologue(dim, B, T, nt, prec, diag):
+    """The row-chain kernel with the transformer's GroupNorm in its prologue: A = GroupNorm(x) (8 groups, affine, eps 1e-6) is
+    built inside the kernel from the fp32 rows and the int64 per-(item, 16-channel block) statistics a producer's epilogue
+    leaves, for token blocks that straddle up to three batch items and both workgroup sizes.  Reference: numpy fp64 with the
+    kernel's rounding points; additionally the GroupNorm rows the kernel builds are compared with gn_apply's
+    (ns2vc_k_groupnorm), observed through y with W1 = identity."""
+    from ns2vc_amd._lib import RowchainArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(dim + 7 * B + T)
+    d, M, Gn = dim, B * T, 8
+    x = (rng.standard_normal((B, T, d)) * (1.0 + rng.random((B, 1, d))) + rng.standard_normal((B, 1, d))).astype(np.float32)
+    gam, bet = (1.0 + 0.2 * rng.standard_normal(d)).astype(np.float32), (0.2 * rng.standard_normal(d)).astype(np.float32)
+    blk = x.astype(np.float64).reshape(B, T, d // 16, 16)
+    st = np.stack([np.rint(blk.sum(axis=(1, 3)) * 2.0 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2.0 ** 16)], axis=-1).astype(np.int64)
+    xg = x.astype(np.float64).reshape(B, T, Gn, d // Gn)
+    mean, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+    A = (((xg - mean) / np.sqrt(var + 1e-6)).reshape(B, T, d) * gam.astype(np.float64) + bet.astype(np.float64)).reshape(M, d)
+    # gn_apply's own output (operand-typed) for the bit-for-bit comparison
+    d_x, d_gam, d_bet = _dev(x.reshape(M, d)), _dev(gam), _dev(bet)
+    d_gn = OpBuf(np.zeros((M, d), dtype=np.float32), prec)
+    check(lib.ns2vc_k_groupnorm(d_x.ptr, d, d, None, 0, 0, B, T, Gn, 1e-6, d_gam.ptr, d_bet.ptr, None, 0, 0, 0, d_gn.ptr, None, prec, None), "groupnorm")
+    sync()
+    a_gn = d_gn.read()
+    assert rel_l2(a_gn, A) < eps16(prec)
+    for mult, W1 in ((3, (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32)), (1, np.eye(d, dtype=np.float32))):
+        n2 = mult * d
+        b1 = (0.3 * rng.standard_normal(d)).astype(np.float32) if mult == 3 else np.zeros(d, dtype=np.float32)
+        W2f, b2f = (rng.standard_normal((n2, d)) / np.sqrt(d)).astype(np.float32), (0.3 * rng.standard_normal(n2)).astype(np.float32)
+        W1r, W2r = rnd(W1, prec).astype(np.float64), rnd(W2f, prec).astype(np.float64)
+        consts = np.stack([W2r.sum(1), b2f.astype(np.float64)], axis=1).astype(np.float32)
+        y = a_gn.astype(np.float64) @ W1r.T + b1.astype(np.float64)[None, :]          # A as the device rounds it (checked above)
+        yr = rnd(y.astype(np.float32), prec).astype(np.float64)
+        mu, vv = y.mean(1, keepdims=True), y.var(1, keepdims=True)
+        z = (yr @ W2r.T - mu * consts[:, 0].astype(np.float64)[None, :]) / np.sqrt(vv + 1e-5) + b2f.astype(np.float64)[None, :]
+        stream = C.c_void_p()
+        check(lib.ns2vc_pack_rowchain(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, prec, C.byref(stream)), "pack_rowchain")
+        d_b1, d_c, d_st, d_g, d_b = _dev(b1), _dev(consts), DevBuf.from_numpy(st), _dev(gam), _dev(bet)
+        d_y = DevBuf(M * d * 4)
+        d_y.upload(np.full((M, d), np.nan, dtype=np.float32))
+        d_z = OpBuf(np.full((M, n2), np.nan, dtype=np.float32), prec)
+        f = RowchainArgs()
+        f.a_op = None; f.lda = d; f.wstream = stream.value; f.bias1 = d_b1.ptr; f.consts2 = d_c.ptr
+        f.res = None; f.ldres = d; f.out1_f32 = d_y.ptr; f.ldo1 = d; f.out2_op = d_z.ptr; f.ldo2 = n2
+        f.ln_eps = 1e-5; f.M = M; f.dim = d; f.n2 = n2; f.ln_health = None
+        f.gn_x = d_x.ptr; f.ldx = d; f.gn_stats = d_st.ptr; f.gn_gamma = d_g.ptr; f.gn_beta = d_b.ptr; f.gn_eps = 1e-6; f.T = T; f.G = Gn
+        check(lib.ns2vc_debug_set_rowchain_tokens(nt), "set_rowchain_tokens")
+        try:
+            check(lib.ns2vc_k_rowchain(C.byref(f), prec, None), "k_rowchain")
+            sync()
+        finally:
+            lib.ns2vc_debug_set_rowchain_tokens(0)
+        yo, zo = d_y.to_numpy((M, d)), d_z.read()
+        e_y, e_z = rel_l2(yo, y), rel_l2(zo, z)
+        diag(f"rowchain+GroupNorm dim={d} B={B} T={T} nt={nt} n2={n2} prec={prec}: y {e_y:.3e} z {e_z:.3e}")
+        # (ns2vc_k_groupnorm finalises its statistics from a separate fp64 pass, the prologue from the int64 epilogue sums: the two
+        # normalised rows agree except where a value sits on a rounding boundary of the operand type -- a ~1e-4 fraction of
+        # elements, one operand ulp each; inside the engine both paths read the same int64 sums and are bit-identical,
+        # tests/test_engine_gpu.py::test_rows_groupnorm_prologue_is_bit_identical)
+        assert np.isfinite(zo).all() and e_y < 2e-5 and e_z < eps16(prec)
+        if mult == 1:                                  # W1 = I, b1 = 0: y IS the panel the prologue built
+            assert (yo != a_gn).mean() < 2e-3 and np.abs(yo - a_gn).max() <= eps16(prec) * 4 * np.abs(a_gn).max()
