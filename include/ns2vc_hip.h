@@ -205,10 +205,17 @@ typedef struct ns2vc_ffn_args {
   long long* stats;                         /* optional GroupNorm statistics of the result, as in ns2vc_gemm_args */
   int32_t B, T, M, dim;                     /* M = B*T rows */
   unsigned* ln_health;                      /* optional, as in ns2vc_gemm_args */
+  /* optional pre-stage (attn2.to_out + residual, attention_processor.py:1040-1050): y = pre_a Wo^T + pre_bias + pre_res is
+   * computed inside the kernel and never stored; yn / ln_stats are ignored.  wstream must then come from ns2vc_pack_ffn_pre. */
+  const void* pre_a; int32_t pre_lda;       /* attention output rows, operand-typed [M][pre_lda] */
+  const float* pre_bias;                    /* [dim] */
+  const float* pre_res; int32_t pre_ldres;  /* fp32 residual stream before the attention [M][pre_ldres] */
 } ns2vc_ffn_args;
 /* w1_packed [8*dim][dim]: LayerNorm-folded ff.net.0 rows in the packed (32 value | 32 gate) order; w2f [dim][5*dim] =
  * [Wpo W2 | Wpo]; both fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
 int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, int precision, void** out_stream_dev);
+/* the same with the pre-stage matrix w0 [dim][dim] (attn2.to_out) in front */
+int ns2vc_pack_ffn_pre(const float* w1_packed_host, const float* w2f_host, const float* w0_host, int dim, int precision, void** out_stream_dev);
 int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream);
 
 /* Two token-local GEMMs with a LayerNorm in between, in one launch (csrc/rowchain.hip; 16-bit precisions, dim 128 / 256):

@@ -60,6 +60,9 @@ class FfnArgs(C.Structure):
         ("stats", C.c_void_p),
         ("B", C.c_int32), ("T", C.c_int32), ("M", C.c_int32), ("dim", C.c_int32),
         ("ln_health", C.c_void_p),
+        ("pre_a", C.c_void_p), ("pre_lda", C.c_int32),
+        ("pre_bias", C.c_void_p),
+        ("pre_res", C.c_void_p), ("pre_ldres", C.c_int32),
     ]
 
 
@@ -141,6 +144,7 @@ PROTOTYPES = {
     "ns2vc_debug_poison": (_I, [C.c_uint, _I, _P]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
     "ns2vc_pack_ffn": (_I, [_P, _P, _I, _I, _PP]),
+    "ns2vc_pack_ffn_pre": (_I, [_P, _P, _P, _I, _I, _PP]),
     "ns2vc_k_ffn": (_I, [C.POINTER(FfnArgs), _I, _P]),
     "ns2vc_pack_rowchain": (_I, [_P, _P, _I, _I, _I, _PP]),
     "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),

@@ -22,7 +22,7 @@
 using namespace ns2vc;
 
 namespace ns2vc {
-hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
+hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
 hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
 }
@@ -74,6 +74,7 @@ struct AttnW {
   float *ng = nullptr, *nb = nullptr;
   PackedW proj_in, qkv, o1, q2, o2, ff1, ff2, proj_out;
   PackedW ffpo;    // ff.net.2 folded into proj_out: [W_po W_2 | W_po], K = 4*dim + dim (see pack_all)
+  void* ffn_pre_stream = nullptr; // the same stream with attn2.to_out in front (pre-stage of the fused kernel)
   void* ffn_stream = nullptr;     // fused feed-forward + proj_out (ffn.hip): weight tile stream ...
   float* ffn_consts = nullptr;    // ... and (rowsum, bias) per packed ff.net.0 row; 16-bit precisions, dim <= 256 only
   // token-local chains (rowchain.hip; 16-bit precisions, dim <= 256): proj_in -> norm1 -> q|k|v and attn1.to_out -> norm2 -> attn2.to_q
@@ -140,6 +141,7 @@ struct ns2vc_unet {
   // (16-bit precisions, dim 128 / 256, LayerNorm by linearity and the fold on).  NS2VC_FUSE_FFN=0 restores the two GEMMs.
   bool fuse_ffn = true;
   bool fuse_rows = true;     // proj_in+q|k|v and attn1.to_out+attn2.to_q as one launch each (rowchain.hip)
+  bool fuse_ffn_pre = true;  // attn2.to_out + residual computed inside the fused feed-forward kernel
   bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
@@ -559,18 +561,22 @@ int pack_all(ns2vc_unet* h) {
         a.ffpo = P.pack(rows, d, K1 + K2, bias);
         if (h->prec != PREC_F32 && (d == 128 || d == 256)) {   // fused feed-forward + proj_out (csrc/ffn.hip)
           std::vector<unsigned short> st;
-          if (pack_ffn_stream(ff1_rows.data(), rows.data(), d, h->prec, st) != hipSuccess) return fail("ffn stream packing failed");
-          void* dev = nullptr;
-          if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
-          h->weight_allocs.push_back(dev);
-          if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
-          a.ffn_stream = dev;
+          for (int pre = 0; pre < 2; ++pre) {
+            const float* w0 = pre ? P.T(t + ".attn2.to_out.0.weight").data.data() : nullptr;
+            if (P.err) return 1;
+            if (pack_ffn_stream(ff1_rows.data(), rows.data(), w0, d, h->prec, st) != hipSuccess) return fail("ffn stream packing failed");
+            void* dev = nullptr;
+            if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
+            h->weight_allocs.push_back(dev);
+            if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
+            (pre ? a.ffn_pre_stream : a.ffn_stream) = dev;
+          }
           const std::vector<float> ws = rounded_rowsum(ff1_rows.data(), 8 * d, d, 8 * d, h->prec);
           std::vector<float> cs((size_t)8 * d * 2);
           for (int r = 0; r < 8 * d; ++r) { cs[2 * r] = ws[r]; cs[2 * r + 1] = ff1_bias[r]; }
           a.ffn_consts = P.upload_f32(cs);
         } else {
-          a.ffn_stream = nullptr; a.ffn_consts = nullptr;
+          a.ffn_stream = nullptr; a.ffn_pre_stream = nullptr; a.ffn_consts = nullptr;
         }
       }
       {  // cross-attention k|v of this block into the hoisted all-blocks projection
@@ -814,24 +820,34 @@ struct Planner {
     // normalised rows, so there the raw copy goes to qb (the cross-attention query buffer, free by now).
     const bool fold = h->fold_ff;
     void* yraw = r3 ? yn : (fold ? qb : nullptr);
-    g = base(ao, d, d, Tl, Tl, a.o2, y, yraw, d);
-    g.res = y; g.ldres = d;
-    g.rowstats = r3;
-    gemm(t + ".attn2.to_out", g);
+    const bool ffn_ok = fold && r3 && h->fuse_ffn && a.ffn_stream && ffn_eligible(d, Tl, pr);
+    // attn2.to_out + residual as the pre-stage of the fused feed-forward kernel: y after the cross-attention is never stored
+    const bool ffn_pre = ffn_ok && h->fuse_ffn_pre && a.ffn_pre_stream;
+    if (!ffn_pre) {
+      g = base(ao, d, d, Tl, Tl, a.o2, y, yraw, d);
+      g.res = y; g.ldres = d;
+      g.rowstats = r3;
+      gemm(t + ".attn2.to_out", g);
+    }
     // feed-forward (GEGLU)
-    if (fold && r3 && h->fuse_ffn && a.ffn_stream && ffn_eligible(d, Tl, pr)) {
+    if (ffn_ok) {
       // LayerNorm(norm3) -> GEGLU -> ff.net.2 -> + y -> proj_out -> + x in ONE launch: the hidden tensor never exists
       ns2vc_ffn_args f;
       memset(&f, 0, sizeof(f));
       f.yn = yn; f.ldy = d; f.ln_stats = r3; f.ln_eps = 1e-5f;
       f.wstream = a.ffn_stream; f.consts = a.ffn_consts; f.bias2 = a.ffpo.bias;
+      if (ffn_pre) {
+        f.yn = nullptr; f.ln_stats = nullptr; f.wstream = a.ffn_pre_stream;
+        f.pre_a = ao; f.pre_lda = d; f.pre_bias = a.o2.bias; f.pre_res = y; f.pre_ldres = d;
+      }
       f.res = x; f.ldres = d;
       f.out_f32 = out; f.ldo_f32 = d; f.out_op = out_op; f.ldo_op = d;
       f.stats = new_stats(out, Tl, d);
       f.B = B; f.T = Tl; f.M = M; f.dim = d; f.ln_health = h->ln_health;
-      const double fl = 2.0 * M * (double)d * (13.0 * d);
-      add(a.prefix + ".ffn[geglu+ff.out+proj_out]", [=](hipStream_t s) { return launch_ffn(f, pr, s); }, 1, fl,
-          (double)M * d * (opsz + 8.0 + (out_op ? opsz : 0.0)) + 13.0 * d * d * opsz);
+      const double fl = 2.0 * M * (double)d * ((ffn_pre ? 14.0 : 13.0) * d);
+      add(a.prefix + (ffn_pre ? ".ffn[attn2.to_out+geglu+ff.out+proj_out]" : ".ffn[geglu+ff.out+proj_out]"),
+          [=](hipStream_t s) { return launch_ffn(f, pr, s); }, 1, fl,
+          (double)M * d * (opsz + 8.0 + (ffn_pre ? 4.0 : 0.0) + (out_op ? opsz : 0.0)) + (ffn_pre ? 14.0 : 13.0) * d * d * opsz);
       return;
     }
     if (!r3) layernorm(t + ".norm3");
@@ -1170,6 +1186,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1246,7 +1263,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_ffn")) opt = &h->fuse_ffn;
   else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_rows, fuse_rows_gn)", name);
+  else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1539,7 +1557,19 @@ int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, 
     inited = true;
   }
   std::vector<unsigned short> st;
-  if (pack_ffn_stream(w1_packed_host, w2f_host, dim, precision, st) != hipSuccess) return fail("ffn: dim must be 128 or 256 and the precision 16-bit");
+  if (pack_ffn_stream(w1_packed_host, w2f_host, nullptr, dim, precision, st) != hipSuccess) return fail("ffn: dim must be 128 or 256 and the precision 16-bit");
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, st.size() * 2));
+  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  *out_stream_dev = d;
+  return 0;
+}
+int ns2vc_pack_ffn_pre(const float* w1_packed_host, const float* w2f_host, const float* w0_host, int dim, int precision, void** out_stream_dev) {
+  if (!w1_packed_host || !w2f_host || !w0_host || !out_stream_dev) return fail("null argument");
+  hipError_t e = init_ffn_attributes();
+  if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
+  std::vector<unsigned short> st;
+  if (pack_ffn_stream(w1_packed_host, w2f_host, w0_host, dim, precision, st) != hipSuccess) return fail("ffn: dim must be 128 or 256 and the precision 16-bit");
   void* d = nullptr;
   HIPCHK(hipMalloc(&d, st.size() * 2));
   HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));

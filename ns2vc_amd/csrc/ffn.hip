@@ -66,7 +66,7 @@ void set_ffn_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g
 constexpr int FFN_TILE = 128 * 128;        // bytes: [128 rows][128 B of K]
 constexpr int FFN_PAIR = 2 * FFN_TILE;     // the kernel consumes tiles two at a time
 
-template <int D> struct FfnGeom {
+template <int D, bool PRE = false> struct FfnGeom {
   // pairs resident in LDS.  The stream is LATENCY-bound (one workgroup per CU, ~2 us per piece under load: bytes in flight
   // per CU set the rate), so the ring is as deep as the 160 KB allow: 4 pairs at dim 128 (3 in flight), 3 at dim 256
   static constexpr int RING = D <= 128 ? 4 : 3;
@@ -75,20 +75,22 @@ template <int D> struct FfnGeom {
   static constexpr int NSS = D / 32;       // super-steps of 128 hidden units (4 D hidden in all)
   static constexpr int NB128 = D / 128;    // 128-row blocks of W2' / Wpo
   static constexpr int PO_STEPS = NB128 * KT / 2;
-  static constexpr int PAIRS = NSS * (KT + NB128) + PO_STEPS;
+  static constexpr int PRE_PAIRS = PRE ? NB128 * KT / 2 : 0;     // attn2.to_out (dim x dim) in front, k-tile outer / row block inner
+  static constexpr int PAIRS = PRE_PAIRS + NSS * (KT + NB128) + PO_STEPS;
   static constexpr int PANEL = KT * 64 * 128;               // bytes: 64 tokens x D, as KT swizzled [64][128 B] tiles
   static constexpr int CONSTS = 8 * D * 8;                  // bytes: (rowsum, bias) per packed W1 row
-  static constexpr int LDS = RING * FFN_PAIR + PANEL + CONSTS;
+  static constexpr int XCH = PRE ? 64 * 4 * 8 : 0;          // bytes: (sum, sumsq) per token and row group of the pre-stage result
+  static constexpr int LDS = RING * FFN_PAIR + PANEL + CONSTS + XCH;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static constexpr int EP = 36;                             // epilogue staging pitch (floats)
   static_assert(2 * 2 * 4 * 32 * EP * 4 <= RING * FFN_PAIR, "epilogue staging (two 32-channel blocks) fits in the ring");
   static_assert(NB * 512 * 8 <= PANEL, "per-lane statistics partials fit in the panel");
 };
 
-template <typename TM, int D>
+template <typename TM, int D, bool PRE>
 __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   op_mode_init<TM>();
-  using G = FfnGeom<D>;
+  using G = FfnGeom<D, PRE>;
   constexpr int KT = G::KT, NB = G::NB, NSS = G::NSS, NB128 = G::NB128, NP = G::PAIRS, EP = G::EP, RING = G::RING;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const ring = smem;
@@ -128,14 +130,28 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   {
     const int prow = 8 * wave + (lane >> 3), pchunk = lane & 7;           // one 1-KB piece per wave = 8 rows x 128 B
     const int m = m0 + prow;
-    const unsigned voff = m < a.M ? (unsigned)m * (unsigned)a.ldy * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
-    const i32x4_t rY = make_rsrc(a.yn, (unsigned long long)a.M * a.ldy * 2ull);
+    const int ldp = PRE ? a.pre_lda : a.ldy;          // PRE: the panel starts as the attention output rows (pre-stage A operand)
+    const unsigned voff = m < a.M ? (unsigned)m * (unsigned)ldp * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
+    const i32x4_t rY = make_rsrc(PRE ? a.pre_a : a.yn, (unsigned long long)a.M * ldp * 2ull);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) blds16(rY, voff, (unsigned)(kt * 128), lds0 + RING * FFN_PAIR + kt * 8192 + wave * 1024);
     const i32x4_t rC = make_rsrc(a.consts, (unsigned long long)G::CONSTS);
 #pragma unroll
     for (int j = 0; j < G::CONSTS / 8192; ++j)
       blds16(rC, (unsigned)(lane * 16), (unsigned)((j * 8 + wave) * 1024), lds0 + RING * FFN_PAIR + G::PANEL + (j * 8 + wave) * 1024);
+  }
+  // pre-stage bias / residual rows of this lane's token: issued BEFORE the weight pairs so that the counted waits on the
+  // pairs (loads complete in issue order) do not have to sit through them
+  float4 b0[NB128][4], rr0[NB128][4];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int rb = 0; rb < NB128; ++rb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = 128 * rb + 32 * hw + 8 * g + 4 * hi;
+        b0[rb][g] = *reinterpret_cast<const float4*>(a.pre_bias + n);
+        rr0[rb][g] = mtok < a.M ? *reinterpret_cast<const float4*>(a.pre_res + (size_t)mtok * a.pre_ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
   }
   // a pair = 32 pieces of 1 KB: four per wave, all addresses scalar
   auto issue_piece = [&](int p, int j) __attribute__((always_inline)) {
@@ -151,13 +167,10 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     if (q < NP) issue_pair(q);
 
   // ---- LayerNorm statistics of this lane's token (ordinary loads: the compiler waits for them -- and, not seeing the
-  // DMA above, for everything issued so far: that is the prologue's wait for the first tiles anyway)
-  float mean, rstd;
-  {
-    const float4* sp = reinterpret_cast<const float4*>(a.ln_stats + (size_t)min(mtok, a.M - 1) * (D / 64) * 2);
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int i = 0; i < D / 128; ++i) { const float4 v = sp[i]; s += v.x + v.z; q += v.y + v.w; }
+  // DMA above, for everything issued so far: that is the prologue's wait for the first tiles anyway).  With the pre-stage
+  // they come out of it (below) instead of from memory.
+  float mean = 0.f, rstd = 1.f;
+  auto ln_finish = [&](float s, float q) __attribute__((always_inline)) {
     const float inv = 1.0f / (float)D;
     mean = s * inv;
     double var = (double)q * (double)inv - (double)mean * (double)mean;
@@ -170,6 +183,13 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
       if (lane == 0 && ratio > __uint_as_float(__hip_atomic_load(a.ln_health, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
         atomicMax(a.ln_health, __float_as_uint(ratio));
     }
+  };
+  if constexpr (!PRE) {
+    const float4* sp = reinterpret_cast<const float4*>(a.ln_stats + (size_t)min(mtok, a.M - 1) * (D / 64) * 2);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < D / 128; ++i) { const float4 v = sp[i]; s += v.x + v.z; q += v.y + v.w; }
+    ln_finish(s, q);
   }
 
   f32x16_t accO[NB];
@@ -194,6 +214,69 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     return ring + (p % RING) * FFN_PAIR;
   };
   const char* const bpanel = panel + (32 * tw + l31) * 128;    // this lane's token row inside a panel tile (+ kt * 8192)
+
+  if constexpr (PRE) {
+    // ---- pre-stage (attn2.to_out + residual, attention_processor.py:1040-1050, attention.py:160): y^T = Wo o^T + bo + y_prev^T.
+    // Wave (tw, hw) takes rows 32 hw .. + 31 of every 128-row tile for its 32 tokens; y stays on the CU: its operand copy
+    // replaces o in the panel (K panel of ff.net.0 and of the Wpo segment), its row sums give this lane's mean / rstd.
+    f32x16_t acc0[NB128];
+#pragma unroll
+    for (int i = 0; i < NB128; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc0[i][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < G::PRE_PAIRS; ++j) {
+      const char* T = step_begin();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = 2 * j + t, kt = i / NB128, rb = i % NB128;
+        const char* wrow = T + t * FFN_TILE + (32 * hw + l31) * 128;
+        u32x4_t fb[4], fw[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int c = ((2 * ks + hi) ^ sw) * 16;
+          fb[ks] = *reinterpret_cast<const u32x4_t*>(bpanel + kt * 8192 + c);
+          fw[ks] = *reinterpret_cast<const u32x4_t*>(wrow + c);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) MmaT<TM>::mma(acc0[rb], fw[ks], fb[ks]);
+      }
+      ++p;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // every wave is done reading o: the panel may be overwritten with y
+    float2* const xch = reinterpret_cast<float2*>(panel + G::PANEL + G::CONSTS);
+    const int tok = 32 * tw + l31;
+    float ps = 0.f, pq = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < NB128; ++rb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v;
+        v.x = acc0[rb][4 * g + 0] + b0[rb][g].x + rr0[rb][g].x;
+        v.y = acc0[rb][4 * g + 1] + b0[rb][g].y + rr0[rb][g].y;
+        v.z = acc0[rb][4 * g + 2] + b0[rb][g].z + rr0[rb][g].z;
+        v.w = acc0[rb][4 * g + 3] + b0[rb][g].w + rr0[rb][g].w;
+        if (mtok >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        ps += (v.x + v.y) + (v.z + v.w);
+        pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        const int n = 128 * rb + 32 * hw + 8 * g + 4 * hi;
+        char* dst = panel + (n >> 6) * 8192 + tok * 128 + ((((n & 63) >> 3) ^ sw) * 16) + 8 * hi;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(v.x, v.y), Op16<TM>::pack(v.z, v.w));
+      }
+    {
+      const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
+      const auto q2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pq), __float_as_uint(pq), false, false);
+      ps = __uint_as_float(s2[0]) + __uint_as_float(s2[1]);
+      pq = __uint_as_float(q2[0]) + __uint_as_float(q2[1]);
+      if (hi == 0) xch[tok * 4 + hw] = make_float2(ps, pq);
+    }
+    __syncthreads();                                // y panel and row sums complete
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float2 v = xch[tok * 4 + k]; s += v.x; q += v.y; }     // fixed order: deterministic
+    ln_finish(s, q);
+  }
 
 #pragma unroll 1
   for (int ss = 0; ss < NSS; ++ss) {
@@ -393,13 +476,17 @@ static void append_tile(std::vector<unsigned short>& out, const float* mat, size
     }
 }
 
-hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec, std::vector<unsigned short>& out) {
+// w0 (optional): the pre-stage matrix [dim][dim] (attn2.to_out), row-major fp32; its tiles go in front, k-tile outer
+hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, int dim, int prec, std::vector<unsigned short>& out) {
   if ((dim != 128 && dim != 256) || (prec != PREC_BF16 && prec != PREC_F16)) return hipErrorInvalidValue;
   const int KT = dim / 64, NSS = dim / 32, NB128 = dim / 128;
   int perm[64];                          // stored k -> unit offset inside a 64-unit tile: bits 2 and 3 swapped per 16 units
   for (int k = 0; k < 64; ++k) perm[k] = (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1);
   out.clear();
-  out.reserve((size_t)(NSS * (KT + NB128) + NB128 * KT / 2) * FFN_PAIR / 2);
+  out.reserve((size_t)(NSS * (KT + NB128) + NB128 * KT) * FFN_PAIR / 2);
+  if (w0)
+    for (int kt = 0; kt < KT; ++kt)
+      for (int rb = 0; rb < NB128; ++rb) append_tile(out, w0, dim, 128 * rb, 64 * kt, prec, nullptr);
   for (int ss = 0; ss < NSS; ++ss) {
     for (int kt = 0; kt < KT; ++kt)
       for (int half = 0; half < 2; ++half) append_tile(out, w1p, dim, 256 * ss + 128 * half, 64 * kt, prec, nullptr);
@@ -414,26 +501,35 @@ hipError_t pack_ffn_stream(const float* w1p, const float* w2f, int dim, int prec
 bool ffn_eligible(int dim, int T, int prec) { return (dim == 128 || dim == 256) && T >= 64 && (prec == PREC_BF16 || prec == PREC_F16); }
 
 template <typename TM, int D> static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
-  const size_t lds = FfnGeom<D>::LDS;
-  hipLaunchKernelGGL((ffn_kernel<TM, D>), dim3((a.M + 63) / 64), dim3(512), lds, s, a);
+  if (a.pre_a) {
+    const size_t lds = FfnGeom<D, true>::LDS;
+    hipLaunchKernelGGL((ffn_kernel<TM, D, true>), dim3((a.M + 63) / 64), dim3(512), lds, s, a);
+  } else {
+    const size_t lds = FfnGeom<D, false>::LDS;
+    hipLaunchKernelGGL((ffn_kernel<TM, D, false>), dim3((a.M + 63) / 64), dim3(512), lds, s, a);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_ffn(const FfnArgs& a, int prec, hipStream_t s) {
   if (!ffn_eligible(a.dim, a.T, prec) || a.M <= 0 || a.M != a.B * a.T) return hipErrorInvalidValue;
-  if (!a.yn || !a.ln_stats || !a.wstream || !a.consts || !a.bias2 || !a.res || (!a.out_f32 && !a.out_op)) return hipErrorInvalidValue;
-  if ((a.ldy & 7) || (a.ldres & 3) || (a.out_f32 && (a.ldo_f32 & 3)) || (a.out_op && (a.ldo_op & 3))) return hipErrorInvalidValue;
-  if ((unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
+  if (!a.wstream || !a.consts || !a.bias2 || !a.res || (!a.out_f32 && !a.out_op)) return hipErrorInvalidValue;
+  if (a.pre_a ? (!a.pre_bias || !a.pre_res || (a.pre_lda & 7) || (a.pre_ldres & 3) || (unsigned long long)a.M * a.pre_lda * 2ull > 0xFFF00000ull)
+              : (!a.yn || !a.ln_stats))
+    return hipErrorInvalidValue;
+  if ((!a.pre_a && (a.ldy & 7)) || (a.ldres & 3) || (a.out_f32 && (a.ldo_f32 & 3)) || (a.out_op && (a.ldo_op & 3))) return hipErrorInvalidValue;
+  if (!a.pre_a && (unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
   if (prec == PREC_BF16) return a.dim == 128 ? launch_ffn_t<bf16_t, 128>(a, s) : launch_ffn_t<bf16_t, 256>(a, s);
   return a.dim == 128 ? launch_ffn_t<f16_t, 128>(a, s) : launch_ffn_t<f16_t, 256>(a, s);
 }
 
 hipError_t init_ffn_attributes() {
   hipError_t e;
-#define NS2VC_FFN_ATTR(TM, D_)                                                                                          \
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<TM, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                               (int)FfnGeom<D_>::LDS)) != hipSuccess) return e
-  NS2VC_FFN_ATTR(bf16_t, 128); NS2VC_FFN_ATTR(bf16_t, 256); NS2VC_FFN_ATTR(f16_t, 128); NS2VC_FFN_ATTR(f16_t, 256);
+#define NS2VC_FFN_ATTR(TM, D_, PRE_)                                                                                          \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<TM, D_, PRE_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)FfnGeom<D_, PRE_>::LDS)) != hipSuccess) return e
+  NS2VC_FFN_ATTR(bf16_t, 128, false); NS2VC_FFN_ATTR(bf16_t, 256, false); NS2VC_FFN_ATTR(f16_t, 128, false); NS2VC_FFN_ATTR(f16_t, 256, false);
+  NS2VC_FFN_ATTR(bf16_t, 128, true); NS2VC_FFN_ATTR(bf16_t, 256, true); NS2VC_FFN_ATTR(f16_t, 128, true); NS2VC_FFN_ATTR(f16_t, 256, true);
 #undef NS2VC_FFN_ATTR
   return hipSuccess;
 }

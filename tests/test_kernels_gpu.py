@@ -507,14 +507,16 @@ def test_gemm_bench_shapes(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("prestage", [False, True], ids=["plain", "pre"])
 @pytest.mark.parametrize("dim,B,T", [(128, 3, 150), (256, 2, 97), (128, 1, 64), (256, 5, 200)], ids=str)
-def test_ffn_fused(dim, B, T, prec, diag):
+def test_ffn_fused(dim, B, T, prestage, prec, diag):
     """The fused feed-forward + proj_out kernel (csrc/ffn.hip) against numpy fp64 of
         out = Wpo (y + W2 (GEGLU(LayerNorm(y) W1^T + b1)) + b2) + bpo + x
     with the engine's pack-time folds (LayerNorm gamma/beta into W1/b1, [Wpo W2 | Wpo], value|gate row interleave), the
     kernel's own rounding points modelled (operands and the hidden tensor are rounded to the operand type), rows with a
     common offset (LayerNorm by linearity), a row count that is no multiple of 64 and 64-token blocks that straddle batch
-    items (GroupNorm statistics of the result per item)."""
+    items (GroupNorm statistics of the result per item).  prestage: y itself is computed inside the kernel as
+    y = o Wo^T + bo + y_prev (attn2.to_out + residual) from operand-typed attention rows o and never stored."""
     from scipy.special import erf
     from ns2vc_amd._lib import FfnArgs, check
     from ns2vc_amd.engine import DevBuf, sync
@@ -523,6 +525,11 @@ def test_ffn_fused(dim, B, T, prec, diag):
     d, M = dim, B * T
     y = (rng.standard_normal((M, d)) + 1.5 * rng.standard_normal((M, 1))).astype(np.float32)
     x = rng.standard_normal((M, d)).astype(np.float32)
+    if prestage:  # y = o Wo^T + bo + y_prev with the kernel's rounding points (o and Wo rounded, fp32 accumulation)
+        o = rng.standard_normal((M, d)).astype(np.float32)
+        Wo, bo = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32), (0.3 * rng.standard_normal(d)).astype(np.float32)
+        y_prev = y
+        y = (rnd(o, prec).astype(np.float64) @ rnd(Wo, prec).astype(np.float64).T + bo + y_prev).astype(np.float32)
     gamma, beta = (1.0 + 0.2 * rng.standard_normal(d)), 0.2 * rng.standard_normal(d)
     W1, b1 = rng.standard_normal((8 * d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(8 * d)
     W2, b2 = rng.standard_normal((d, 4 * d)) / np.sqrt(4 * d), 0.3 * rng.standard_normal(d)
@@ -548,7 +555,11 @@ def test_ffn_fused(dim, B, T, prec, diag):
     ys = y64.reshape(M, d // 64, 64)
     stats = np.stack([ys.sum(2), (ys ** 2).sum(2)], axis=-1).astype(np.float32)
     stream = C.c_void_p()
-    check(lib.ns2vc_pack_ffn(np.ascontiguousarray(W1p).ctypes.data, np.ascontiguousarray(w2f).ctypes.data, d, prec, C.byref(stream)), "pack_ffn")
+    if prestage:
+        check(lib.ns2vc_pack_ffn_pre(np.ascontiguousarray(W1p).ctypes.data, np.ascontiguousarray(w2f).ctypes.data, np.ascontiguousarray(Wo).ctypes.data,
+                                     d, prec, C.byref(stream)), "pack_ffn_pre")
+    else:
+        check(lib.ns2vc_pack_ffn(np.ascontiguousarray(W1p).ctypes.data, np.ascontiguousarray(w2f).ctypes.data, d, prec, C.byref(stream)), "pack_ffn")
     d_y, d_st, d_c, d_b2, d_x = OpBuf(y, prec), _dev(stats), _dev(consts), _dev(bias2), _dev(x)
     d_o = DevBuf(M * d * 4)
     d_o.upload(np.full((M, d), np.nan, dtype=np.float32))
@@ -563,6 +574,10 @@ def test_ffn_fused(dim, B, T, prec, diag):
     f.stats = d_gs.ptr
     f.B, f.T, f.M, f.dim = B, T, M, d
     f.ln_health = d_health.ptr
+    if prestage:
+        d_oa, d_bo, d_yp = OpBuf(o, prec), _dev(bo), _dev(y_prev)
+        f.yn = None; f.ln_stats = None
+        f.pre_a = d_oa.ptr; f.pre_lda = d; f.pre_bias = d_bo.ptr; f.pre_res = d_yp.ptr; f.pre_ldres = d
     check(lib.ns2vc_k_ffn(C.byref(f), prec, None), "k_ffn")
     sync()
     out, op = d_o.to_numpy((M, d)), d_op.read()
@@ -572,7 +587,7 @@ def test_ffn_fused(dim, B, T, prec, diag):
     e_s = np.abs(gs[..., 0] / 2 ** 28 - blk.sum(axis=(1, 3))).max() / np.abs(blk.sum(axis=(1, 3))).max()
     e_q = np.abs(gs[..., 1] / 2 ** 16 - (blk ** 2).sum(axis=(1, 3))).max() / (blk ** 2).sum(axis=(1, 3)).max()
     ratio = float(d_health.to_numpy((16,), dtype=np.uint32)[:1].view(np.float32)[0])
-    diag(f"ffn fused dim={d} B={B} T={T} prec={prec}: rel_l2 {e:.3e} nan={int(np.isnan(out).sum())}  stats sum {e_s:.2e} sumsq {e_q:.2e}  |mean|/std {ratio:.2f}")
+    diag(f"ffn fused dim={d} B={B} T={T} pre={prestage} prec={prec}: rel_l2 {e:.3e} nan={int(np.isnan(out).sum())}  stats sum {e_s:.2e} sumsq {e_q:.2e}  |mean|/std {ratio:.2f}")
     if not e < 2e-4:
         err = np.abs(out - ref)
         bad = np.argwhere(~(err <= 1e-2 + 1e-2 * np.abs(ref)))
