@@ -192,29 +192,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
   u32x4_t kraw[UPT], vraw[UPT];
   float braw = 0.f;
+  // Rows past Lk are fetched from the LAST valid row instead of being replaced by zeros: their scores carry the -inf of the
+  // aux slab whatever K holds (finite), and their probabilities are exactly 0 against any finite V -- so the loads need no
+  // per-lane select / zero-fill and no divergent branch.  The mask bias is kept RAW here and scaled in store_tile: scaling it
+  // at load time made the compiler wait for this tile's whole prefetch (s_waitcnt vmcnt(0)) in front of the MFMAs.
   auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int key0 = t * 64;
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + 256 * i;
-      const u32x4_t z = {0, 0, 0, 0};
-      {  // K: row-major pieces, coalesced along d
-        const int key = u / PPR, pc = u - key * PPR;
-        const int kk = key0 + key;
-        kraw[i] = (u < NPIECE && kk < a.Lk) ? *reinterpret_cast<const u32x4_t*>(kbase + (size_t)kk * a.ldk + pc * EPC) : z;
-      }
-      {  // V: key-fastest pieces (the transposed LDS write is then conflict-free)
-        const int key = u & 63, pc = u >> 6;
-        const int kk = key0 + key;
-        vraw[i] = (u < NPIECE && kk < a.Lk) ? *reinterpret_cast<const u32x4_t*>(vbase + (size_t)kk * a.ldv + pc * EPC) : z;
+      if (u < NPIECE) {
+        {  // K: row-major pieces, coalesced along d
+          const int key = u / PPR, pc = u - key * PPR;
+          const int kk = min(key0 + key, a.Lk - 1);
+          kraw[i] = *reinterpret_cast<const u32x4_t*>(kbase + (size_t)kk * a.ldk + pc * EPC);
+        }
+        {  // V: key-fastest pieces (the transposed LDS write is then conflict-free)
+          const int key = u & 63, pc = u >> 6;
+          const int kk = min(key0 + key, a.Lk - 1);
+          vraw[i] = *reinterpret_cast<const u32x4_t*>(vbase + (size_t)kk * a.ldv + pc * EPC);
+        }
       }
     }
-    if (tid < 64) {
-      const int kk = key0 + tid;
-      braw = (kk < a.Lk) ? (bias ? bias[kk] * LOG2E : 0.f) : -INFINITY;
-    }
+    if (tid < 64 && bias) braw = bias[min(key0 + tid, a.Lk - 1)];
   };
-  auto store_tile = [&](int stage) __attribute__((always_inline)) {
+  auto store_tile = [&](int stage, int key0s) __attribute__((always_inline)) {
     char* Ks = smem + stage * STAGE;
     char* Vs = Ks + KBYTES;
 #pragma unroll
@@ -232,7 +234,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         }
       }
     }
-    if (tid < 64) *reinterpret_cast<TM*>(Ks + tid * KROWB + HD * SZ + SZ) = op_from_float<TM>(braw);   // K aux element 1 = bias(key)
+    if (tid < 64) {                                   // K aux element 1 = bias(key) in log2 units; -inf for the keys past Lk
+      const float bl = (key0s + tid < a.Lk) ? (bias ? braw * LOG2E : 0.f) : -INFINITY;
+      *reinterpret_cast<TM*>(Ks + tid * KROWB + HD * SZ + SZ) = op_from_float<TM>(bl);
+    }
   };
 
   f32x16_t o[DT];
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const int ntile = (a.Lk + 63) / 64;
   load_tile(0);
   __syncthreads();          // constants written
-  store_tile(0);
+  store_tile(0, 0);
   __syncthreads();
 
   for (int t = 0; t < ntile; ++t) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         }
       }
     }
-    if (t + 1 < ntile) store_tile((t + 1) & 1);
+    if (t + 1 < ntile) store_tile((t + 1) & 1, (t + 1) * 64);
     __syncthreads();
   }
 
