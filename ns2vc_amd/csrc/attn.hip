@@ -19,6 +19,7 @@
 // q/k/v/out are operand-typed tensors (bf16, or fp32 in parity mode): no conversions while staging.
 #include "common.h"
 #include "mma.h"
+#include <cstdlib>
 
 namespace ns2vc {
 
@@ -115,21 +116,22 @@ template <> __device__ __forceinline__ f16_t op_from_float<f16_t>(float x) { f16
 //     by the MFMA is exact too);
 //   * V^T carries a row of ones, so the PV MFMA also accumulates the denominator (of the SAME rounded probabilities
 //     that build the numerator): no per-score add, no separate running sum.
-template <typename TM, int HD>
+template <typename TM, int HD, int KEYS>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   op_mode_init<TM>();
+  constexpr int NSUB = KEYS / 32;         // 32-key sub-tiles per K/V tile (2 or 4): per-tile bookkeeping, barrier and waits amortise over them
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
   constexpr int NS = HD * SZ / 32;        // 32-B d-slabs per key row (QK^T k-steps), + 1 aux slab
   constexpr int KROWB = HD * SZ + 48;     // K tile row bytes: HD elements, 32-B aux slab, pad (stride = 4*odd dwords)
-  constexpr int VROWB = 64 * SZ + 16;     // V^T tile row bytes (64 keys)
+  constexpr int VROWB = KEYS * SZ + 16;   // V^T tile row bytes (KEYS keys)
   constexpr int HDX = (HD + 1 + 31) / 32 * 32;   // V^T rows: HD value rows + the ones row (row HD), padded to 32
   constexpr int DT = HDX / 32;
   constexpr int NSL = SZ;                 // 32-B key-slabs per 32-key sub-tile (f32: 4x8 keys, bf16: 2x16 keys)
-  constexpr int KBYTES = 64 * KROWB, VBYTES = HDX * VROWB;
+  constexpr int KBYTES = KEYS * KROWB, VBYTES = HDX * VROWB;
   constexpr int STAGE = KBYTES + VBYTES;
   constexpr int PPR = HD * SZ / 16;       // 16-B pieces per key row
-  constexpr int NPIECE = 64 * PPR;        // pieces per K (or V) tile
+  constexpr int NPIECE = KEYS * PPR;      // pieces per K (or V) tile
   constexpr int UPT = (NPIECE + 255) / 256;
   constexpr float THRESH = 12.0f;         // move the reference when a score exceeds it by more than this (log2 units)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,11 +160,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   // zero both stages once (V^T pad rows and the aux slabs' tails must read as 0), then the constants
   for (int i = tid * 16; i < 2 * STAGE; i += 256 * 16) *reinterpret_cast<u32x4_t*>(smem + i) = u32x4_t{0, 0, 0, 0};
   __syncthreads();
-  if (tid < 128) {                         // K aux element 0 = 1 for every key row of both stages
-    char* Ks = smem + (tid >> 6) * STAGE;
-    *reinterpret_cast<TM*>(Ks + (tid & 63) * KROWB + HD * SZ) = op_from_float<TM>(1.0f);
-  } else {                                 // V^T row HD = ones (64 keys) in both stages
-    const int st = (tid - 128) >> 6, key = tid & 63;
+  for (int i = tid; i < 2 * KEYS; i += 256) {      // K aux element 0 = 1 for every key row, V^T row HD = ones, both stages
+    const int st = i / KEYS, key = i - st * KEYS;
+    *reinterpret_cast<TM*>(smem + st * STAGE + key * KROWB + HD * SZ) = op_from_float<TM>(1.0f);
     *reinterpret_cast<TM*>(smem + st * STAGE + KBYTES + HD * VROWB + key * SZ) = op_from_float<TM>(1.0f);
   }
 
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   // per-lane select / zero-fill and no divergent branch.  The mask bias is kept RAW here and scaled in store_tile: scaling it
   // at load time made the compiler wait for this tile's whole prefetch (s_waitcnt vmcnt(0)) in front of the MFMAs.
   auto load_tile = [&](int t) __attribute__((always_inline)) {
-    const int key0 = t * 64;
+    const int key0 = t * KEYS;
 #pragma unroll
     for (int i = 0; i < UPT; ++i) {
       const int u = tid + 256 * i;
@@ -208,13 +208,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
           kraw[i] = *reinterpret_cast<const u32x4_t*>(kbase + (size_t)kk * a.ldk + pc * EPC);
         }
         {  // V: key-fastest pieces (the transposed LDS write is then conflict-free)
-          const int key = u & 63, pc = u >> 6;
+          const int key = u % KEYS, pc = u / KEYS;
           const int kk = min(key0 + key, a.Lk - 1);
           vraw[i] = *reinterpret_cast<const u32x4_t*>(vbase + (size_t)kk * a.ldv + pc * EPC);
         }
       }
     }
-    if (tid < 64 && bias) braw = bias[min(key0 + tid, a.Lk - 1)];
+    if (tid < KEYS && bias) braw = bias[min(key0 + tid, a.Lk - 1)];
   };
   auto store_tile = [&](int stage, int key0s) __attribute__((always_inline)) {
     char* Ks = smem + stage * STAGE;
@@ -228,13 +228,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
           *reinterpret_cast<u32x4_t*>(Ks + key * KROWB + pc * 16) = kraw[i];
         }
         {
-          const int key = u & 63, pc = u >> 6;
-          const int pos = (key & 32) + AMma<TM>::vpos(key & 31);
+          const int key = u % KEYS, pc = u / KEYS;
+          const int pos = (key & ~31) + AMma<TM>::vpos(key & 31);
           vt_scatter<TM>(Vs + (pc * EPC) * VROWB + pos * SZ, VROWB, vraw[i]);
         }
       }
     }
-    if (tid < 64) {                                   // K aux element 1 = bias(key) in log2 units; -inf for the keys past Lk
+    if (tid < KEYS) {                                 // K aux element 1 = bias(key) in log2 units; -inf for the keys past Lk
       const float bl = (key0s + tid < a.Lk) ? (bias ? braw * LOG2E : 0.f) : -INFINITY;
       *reinterpret_cast<TM*>(Ks + tid * KROWB + HD * SZ + SZ) = op_from_float<TM>(bl);
     }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 
-  const int ntile = (a.Lk + 63) / 64;
+  const int ntile = (a.Lk + KEYS - 1) / KEYS;
   load_tile(0);
   __syncthreads();          // constants written
   store_tile(0, 0);
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     const char* Vs = Ks + KBYTES;
 
     // ---- S'^T[key][q] = sum_d K[key][d] * (Q[q][d]*scale*log2e) + 1*(-m_ref[q]) + bias[key]*1   (two 32-key sub-tiles)
-    f32x16_t s[2];
+    f32x16_t s[NSUB];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < NSUB; ++k2) {
       const char* kr = Ks + (k2 * 32 + l31) * KROWB + hi * 16;
       s[k2] = AMma<TM>::mma0(*reinterpret_cast<const u32x4_t*>(kr + NS * 32), qaux);      // aux slab first: no zero-init movs
 #pragma unroll
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     // ---- reference check (per query = per lane; both lane halves agree): lane's keys are k2*32 + 8*g + 4*hi + i
     float mx = s[0][0];
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < NSUB; ++k2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
     mx = half_max(mx);
@@ -286,20 +286,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
           for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
       }
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
+      for (int k2 = 0; k2 < NSUB; ++k2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[k2][r] -= dsh;
       m_ref = m_new;
       if (hi == 0) qaux = aux_chunk<TM>(-m_ref, 1.0f);
     }
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2)
+    for (int k2 = 0; k2 < NSUB; ++k2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[k2][r] = __builtin_amdgcn_exp2f(s[k2][r]);
 
     // ---- [O^T ; l][d][q] += sum_key [V^T ; 1][d][key] * P^T[key][q]
 #pragma unroll
-    for (int k2 = 0; k2 < 2; ++k2) {
+    for (int k2 = 0; k2 < NSUB; ++k2) {
 #pragma unroll
       for (int sl = 0; sl < NSL; ++sl) {
         u32x4_t pf;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         }
       }
     }
-    if (t + 1 < ntile) store_tile((t + 1) & 1, (t + 1) * 64);
+    if (t + 1 < ntile) store_tile((t + 1) & 1, (t + 1) * KEYS);
     __syncthreads();
   }
 
@@ -340,17 +340,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   }
 }
 
-template <typename TM, int HD> static constexpr size_t attn_lds() {
+template <typename TM, int HD, int KEYS> static constexpr size_t attn_lds() {
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int HDX = (HD + 1 + 31) / 32 * 32;
-  return 2 * (size_t)(64 * (HD * SZ + 48) + HDX * (64 * SZ + 16));
+  return 2 * (size_t)(KEYS * (HD * SZ + 48) + HDX * (KEYS * SZ + 16));
 }
 
-template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
+// 64-key tiles everywhere.  128-key tiles (half the per-tile bookkeeping, barriers and waits; round-1 review item) exist for
+// the narrow heads of the 16-bit precisions (hd 16 / 32) behind the tuning hook, and LOSE: same-box 3.93 (64) vs 3.98 ms/step
+// (128), attention 0.68 vs 0.73 ms -- 64 more score registers and twice the LDS per workgroup cost more occupancy than the
+// bookkeeping saves in a VALU-bound loop.
+template <typename TM, int HD> static constexpr bool attn_has128() { return sizeof(TM) == 2 && HD <= 32; }
+static int g_force_keys = getenv("NS2VC_ATTN_KEYS") ? atoi(getenv("NS2VC_ATTN_KEYS")) : 0;   // test / tuning hook: 128 selects the 128-key kernels
+void set_forced_attn_keys(int keys) { g_force_keys = keys; }
+
+template <typename TM, int HD, int KEYS> static hipError_t launch_hdk(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);
-  const size_t lds = attn_lds<TM, HD>();
-  hipLaunchKernelGGL((attn_kernel<TM, HD>), grid, dim3(256), lds, s, a);
+  const size_t lds = attn_lds<TM, HD, KEYS>();
+  hipLaunchKernelGGL((attn_kernel<TM, HD, KEYS>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
+}
+template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
+  if constexpr (attn_has128<TM, HD>()) {
+    if (g_force_keys == 128) return launch_hdk<TM, HD, 128>(a, s);
+  }
+  return launch_hdk<TM, HD, 64>(a, s);
 }
 
 template <typename TM> static hipError_t launch_tm(const AttnArgs& a, int hd, hipStream_t s) {
@@ -364,8 +378,14 @@ template <typename TM> static hipError_t launch_tm(const AttnArgs& a, int hd, hi
 }
 
 template <typename TM, int HD> static hipError_t set_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)attn_lds<TM, HD>());
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)attn_lds<TM, HD, 64>());
+  if constexpr (attn_has128<TM, HD>()) {
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)attn_lds<TM, HD, 128>());
+  }
+  return e;
 }
 template <typename TM> static hipError_t set_attr_tm() {
   hipError_t e;

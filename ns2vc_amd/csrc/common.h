@@ -210,6 +210,7 @@ hipError_t init_gemm_attributes();
 void set_forced_gemm_tile(int bm, int bn, int stages);
 void set_gemm_trace(unsigned long long* p);
 hipError_t init_attn_attributes();
+void set_forced_attn_keys(int keys);            // test hook: 0 = heuristic, 64 / 128 = K/V tile size where the kernel exists
 // fused feed-forward + proj_out (ffn.hip), 16-bit operand types only
 hipError_t launch_ffn(const ::ns2vc_ffn_args& a, int prec, hipStream_t s);
 bool ffn_eligible(int dim, int T, int prec);

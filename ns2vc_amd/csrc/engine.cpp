@@ -1593,6 +1593,11 @@ int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int
   *out_stream_dev = d;
   return 0;
 }
+int ns2vc_debug_set_attn_keys(int keys) {
+  if (keys != 0 && keys != 64 && keys != 128) return fail("attention K/V tile: 0 (heuristic), 64 or 128 keys");
+  set_forced_attn_keys(keys);
+  return 0;
+}
 int ns2vc_debug_set_rowchain_tokens(int nt) {
   if (nt < 0 || nt > 2) return fail("rowchain tokens: 0 (heuristic), 1 (64-token blocks) or 2 (128-token blocks)");
   set_forced_rowchain_tokens(nt);

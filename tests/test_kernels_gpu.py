@@ -627,12 +627,18 @@ ATTN_CASES = [
     ("cross_hd32_mask", 2, 8, 32, 70, 130, True, False),
     ("cross_hd48_mask", 2, 8, 48, 33, 21, True, False),
     ("cross_hd64_mask", 2, 8, 64, 40, 469, True, False),
+    ("self_hd16_long", 1, 8, 16, 470, 470, False, True),
+    ("cross_hd32_469", 2, 8, 32, 100, 469, True, False),
+    ("cross_hd16_129", 1, 8, 16, 140, 129, True, False),
 ]
 
 
+@pytest.mark.parametrize("keys", [0, 128], ids=["keys64", "keys128"])
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
-def test_attention(case, prec, diag):
+def test_attention(case, prec, keys, diag):
+    """keys: K/V tile size -- 0 = the default 64-key tiles; 128 = the 128-key kernels of the 16-bit hd 16 / 32 cases (tuning
+    hook; measured slower in the step, kept tested)"""
     from ns2vc_amd._lib import AttnArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     name, B, H, hd, Lq, Lk, use_bias, packed = case
@@ -668,8 +674,12 @@ def test_attention(case, prec, diag):
     a.scale = 1.0 / np.sqrt(hd)
     d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
     a.out, a.ldo = d_out.ptr, D
-    check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
-    sync()
+    check(lib.ns2vc_debug_set_attn_keys(keys), "set_attn_keys")
+    try:
+        check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
+        sync()
+    finally:
+        lib.ns2vc_debug_set_attn_keys(0)
     out = d_out.read((B, Lq, D))
     e = rel_l2(out, ref)
     diag(f"attn {name} prec={prec} rel_l2={e:.3e} nan={int(np.isnan(out).sum())}")
