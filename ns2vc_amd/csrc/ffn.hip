@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   FFN_TR(1, FFN_NOW());
 
   int p = 0;                                        // next pair to consume
-  auto step_begin = [&]() __attribute__((always_inline)) -> const char* {
+  auto step_begin = [&](bool first = false) __attribute__((always_inline)) -> const char* {
     // pair p has landed when only the pieces (four per wave and pair) of the RING - 2 pairs behind it may still be in flight
     const int after = min(RING - 2, NP - 1 - p);
     if (RING >= 4 && after >= 2) wait_vmcnt<8>();
@@ -210,6 +210,18 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     __builtin_amdgcn_s_barrier();
     // refill: pair p + RING - 1 into the slot of pair p-1, free for everyone after the barrier.  (Issuing the four
     // pieces one by one between the MFMA groups instead was measured slower: 4.44 vs 4.32 ms/step same-box.)
+    if (PRE && first) {
+      // the compiler does not see the DMA: consume the pre-stage bias / residual registers HERE, before any younger memory
+      // operation exists -- otherwise its `s_waitcnt vmcnt(0)` at their first use also covers the prefetched pairs (see
+      // rowchain.hip step_begin)
+#pragma unroll
+      for (int rb = 0; rb < NB128; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          asm volatile("" : "+v"(b0[rb][g].x), "+v"(b0[rb][g].y), "+v"(b0[rb][g].z), "+v"(b0[rb][g].w));
+          asm volatile("" : "+v"(rr0[rb][g].x), "+v"(rr0[rb][g].y), "+v"(rr0[rb][g].z), "+v"(rr0[rb][g].w));
+        }
+    }
     if (p + RING - 1 < NP) issue_pair(p + RING - 1);
     return ring + (p % RING) * FFN_PAIR;
   };
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
       for (int r = 0; r < 16; ++r) acc0[i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < G::PRE_PAIRS; ++j) {
-      const char* T = step_begin();
+      const char* T = step_begin(j == 0);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int i = 2 * j + t, kt = i / NB128, rb = i % NB128;

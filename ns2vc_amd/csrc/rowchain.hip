@@ -169,13 +169,28 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   }
 
   int p = 0;                                        // next pair to consume (compile-time after unrolling)
-  auto step_begin = [&]() __attribute__((always_inline)) -> const char* {
+  auto step_begin = [&](bool first = false) __attribute__((always_inline)) -> const char* {
     // pair p has landed when only the pieces (four per wave and pair) of the pair behind it may still be in flight.  Loads
     // complete in issue order among themselves, so other outstanding memory operations (the result stores of the stage-1
     // epilogue) can only make this wait longer than necessary, never shorter.
     if (NP - 1 - p >= 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragment reads of the slot about to be refilled are done
     __builtin_amdgcn_s_barrier();
+    if (first) {
+      // The compiler does not see the DMA instructions.  Left alone it waits for the bias / residual rows (issued above)
+      // only where the stage-1 epilogue first uses them -- with `s_waitcnt vmcnt(0)`, which by then also covers the
+      // prefetched stage-2 weight pairs and, from the second register group on, every result STORE issued so far: eight
+      // serialised store round trips per wave.  Consuming the registers here, before any younger memory operation exists,
+      // moves that wait to a point where it costs nothing.
+#pragma unroll
+      for (int rb = 0; rb < NB1; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          asm volatile("" : "+v"(b1[rb][g].x), "+v"(b1[rb][g].y), "+v"(b1[rb][g].z), "+v"(b1[rb][g].w));
+#pragma unroll
+          for (int u = 0; u < NT; ++u) asm volatile("" : "+v"(rr[u][rb][g].x), "+v"(rr[u][rb][g].y), "+v"(rr[u][rb][g].z), "+v"(rr[u][rb][g].w));
+        }
+    }
     if (p + RING - 1 < NP) issue_pair(p + RING - 1);
     return ring + (p % RING) * RC_PAIR;
   };
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       for (int r = 0; r < 16; ++r) acc1[i][u][r] = 0.f;
 #pragma unroll
   for (int j = 0; j < S1 / 2; ++j) {
-    const char* T = step_begin();
+    const char* T = step_begin(j == 0);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int i = 2 * j + t;
