@@ -408,3 +408,66 @@ def test_gather_latents_gloo_world2(tmp_path):
              for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_repeat_expand_matches_reference_golden():
+    """ns2vc_amd.audio.repeat_expand_2d (index map + one gather) against outputs of the reference's own utils.repeat_expand_2d
+    (utils.py:482-496): bit-identical, including non-integer ratios, target shorter than source, and batched input."""
+    import json
+    from ns2vc_amd.audio import repeat_expand_2d
+    from ns2vc_amd.weights import hash_normal
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v3.npz"))
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_v3_report.json")))["cases"]
+    assert len(cases) >= 9
+    for h, s, t in cases:
+        x = torch.from_numpy(hash_normal(f"g11.{h}.{s}.{t}", (h, s)))
+        y = repeat_expand_2d(x, t)
+        assert y.dtype == torch.float32 and np.array_equal(y.numpy(), g[f"g11.{h}_{s}_{t}.y"]), (h, s, t)
+        assert torch.equal(repeat_expand_2d(torch.stack([x, 2 * x]), t)[1], 2 * y)
+
+
+def test_log_mel_against_a_direct_dft():
+    """ns2vc_amd.audio.log_mel (torch.stft + HTK filter bank; the reference uses torchaudio.transforms.MelSpectrogram, absent here:
+    parity unpinned) against an independent numpy restatement of the published algorithm -- explicit reflect padding, framing,
+    periodic Hann window, rfft magnitude, triangular HTK filters -- plus shape and a pure-tone sanity check."""
+    from ns2vc_amd.audio import log_mel, mel_filterbank
+    sr, n_fft, hop, n_mels = 24000, 1024, 256, 100
+    rng = np.random.default_rng(3)
+    t = np.arange(6000) / sr
+    wav = (0.5 * np.sin(2 * np.pi * 1000.0 * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
+    got = log_mel(torch.from_numpy(wav)[None]).numpy()[0]
+    assert got.shape == (n_mels, 1 + wav.size // hop)
+    # ---- numpy restatement
+    x = np.pad(wav.astype(np.float64), n_fft // 2, mode="reflect")
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)                       # periodic Hann
+    frames = np.stack([x[i * hop:i * hop + n_fft] * win for i in range(1 + wav.size // hop)], axis=1)
+    mag = np.abs(np.fft.rfft(frames, axis=0))                                            # (513, frames)
+    hz = lambda m: 700.0 * (10.0 ** (m / 2595.0) - 1.0)
+    mel = lambda f: 2595.0 * np.log10(1.0 + f / 700.0)
+    f_pts = hz(np.linspace(mel(0.0), mel(sr / 2), n_mels + 2))
+    freqs = np.linspace(0, sr // 2, n_fft // 2 + 1)
+    fb = np.zeros((n_fft // 2 + 1, n_mels))
+    for m in range(n_mels):
+        lo, ce, hi = f_pts[m], f_pts[m + 1], f_pts[m + 2]
+        fb[:, m] = np.clip(np.minimum((freqs - lo) / (ce - lo), (hi - freqs) / (hi - ce)), 0.0, None)
+    ref = np.log(np.clip(fb.T @ mag, 1e-7, None))
+    assert rel_l2(mel_filterbank().numpy(), fb) < 1e-5
+    assert np.abs(got - ref).max() < 2e-3                                                # log domain, fp32 stft vs fp64 dft
+    peak = int(np.argmax(got.mean(axis=1)))
+    assert f_pts[peak] <= 1000.0 <= f_pts[peak + 2]                                      # the 1 kHz tone sits in the right filter
+
+
+def test_grouped_converter_plan_groups_equal_shapes():
+    """ns2vc_amd.service.GroupedConverter.plan: segments are grouped by (latent length, prompt length), never padded, groups of at
+    most max_batch, longest first, input order inside a group (host logic; the GPU behaviour is tests/test_service_gpu.py)."""
+    from ns2vc_amd.service import GroupedConverter, Segment
+    gc = GroupedConverter.__new__(GroupedConverter)
+    gc.max_batch = 3
+    lengths = [96, 130, 96, 64, 130, 96, 96, 96]
+    rlens = [40, 64, 40, 64, 64, 40, 50, 40]
+    segs = [Segment(torch.zeros(256, T), torch.zeros(100, L)) for T, L in zip(lengths, rlens)]
+    groups = gc.plan(segs)
+    assert groups == [[1, 4], [6], [0, 2, 5], [7], [3]]
+    assert sorted(i for g_ in groups for i in g_) == list(range(len(segs)))
+    for g_ in groups:
+        assert len({(lengths[i], rlens[i]) for i in g_}) == 1 and len(g_) <= 3
