@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--solver", default="unipc", choices=["unipc", "dpmsolver++"])
     ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--attn-fp8", action="store_true", help="PV product of every attention on the fp8 MFMA (BASELINE config 5's fp8 path; "
+                    "costs parity, see DESIGN.md section 4)")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-baseline / parity legs")
     ap.add_argument("--skip-fp32", action="store_true", help="skip the fp32_parity_mode block")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the baseline legs")
@@ -306,6 +308,8 @@ def main():
 
     def build(precision):
         eng = E.Engine(cfg, precision=precision)
+        if a.attn_fp8 and precision != "fp32":
+            eng.set_option("attn_fp8", True)
         eng.load_state_dict(W)
         eng.prepare(B, T, Lp)
         eng.load_sampler(solver, K, order=order)
@@ -433,7 +437,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded hash inputs, procedural weights of the production UNet1DConditionModel)",
             "config": {"workload": f"{a.seconds:g} s utterance (T={T} Vocos frames), batch {B}/GPU, prompt Lp={Lp}, {K}-step {solver} order {order}, "
-                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision} MFMA operands; timed job = set_condition + {K} steps"
+                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision} MFMA operands{' + fp8 PV in attention' if a.attn_fp8 else ''}; timed job = set_condition + {K} steps"
                                    + (" + all-gather of latents" if world > 1 else ""),
                        "global_batch": B * world, "frames": T, "prompt_frames": Lp, "solver": solver, "parallelism": f"dp{world}"},
             "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,

@@ -187,6 +187,7 @@ typedef struct ns2vc_attn_args {
   const float* bias;              /* additive [B][Lk] or NULL */
   float scale;
   void* out; int32_t ldo;         /* operand-typed */
+  int32_t pv_fp8;                 /* 16-bit precisions only: 1 = the PV product on the fp8 MFMA (V and the probabilities rounded to OCP e4m3) */
 } ns2vc_attn_args;
 
 /* Fused feed-forward + proj_out of one transformer block (attention.py:178-203 GEGLU feed-forward, transformer_1d.py:287-295),

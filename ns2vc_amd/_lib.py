@@ -88,6 +88,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("bias", C.c_void_p), ("scale", C.c_float),
         ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("pv_fp8", C.c_int32),
     ]
 
 

@@ -116,15 +116,26 @@ template <> __device__ __forceinline__ f16_t op_from_float<f16_t>(float x) { f16
 //     by the MFMA is exact too);
 //   * V^T carries a row of ones, so the PV MFMA also accumulates the denominator (of the SAME rounded probabilities
 //     that build the numerator): no per-score add, no separate running sum.
-template <typename TM, int HD, int KEYS>
+// P8 (16-bit operand types only): the PV product runs on the fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8, OCP e4m3 on gfx950): V^T is
+// staged in LDS as fp8 (converted while staging), the probabilities are packed to fp8 instead of the 16-bit type; QK^T, the
+// softmax state and all accumulators are unchanged.  BASELINE config 5 names an fp8 attention path; see DESIGN section 4 for
+// why it is an option and not the default (the kernel is VALU-bound 3 : 1, and 3 mantissa bits in P cost the parity bar).
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (uint32_t)v;
+}
+template <typename TM, int HD, int KEYS, bool P8>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   op_mode_init<TM>();
+  static_assert(!P8 || sizeof(TM) == 2, "the fp8 PV path exists for the 16-bit operand types");
   constexpr int NSUB = KEYS / 32;         // 32-key sub-tiles per K/V tile (2 or 4): per-tile bookkeeping, barrier and waits amortise over them
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
   constexpr int NS = HD * SZ / 32;        // 32-B d-slabs per key row (QK^T k-steps), + 1 aux slab
   constexpr int KROWB = HD * SZ + 48;     // K tile row bytes: HD elements, 32-B aux slab, pad (stride = 4*odd dwords)
-  constexpr int VROWB = KEYS * SZ + 16;   // V^T tile row bytes (KEYS keys)
+  constexpr int VSZ = P8 ? 1 : SZ;        // bytes per V^T / P element
+  constexpr int VROWB = KEYS * VSZ + 16;  // V^T tile row bytes (KEYS keys)
   constexpr int HDX = (HD + 1 + 31) / 32 * 32;   // V^T rows: HD value rows + the ones row (row HD), padded to 32
   constexpr int DT = HDX / 32;
   constexpr int NSL = SZ;                 // 32-B key-slabs per 32-key sub-tile (f32: 4x8 keys, bf16: 2x16 keys)
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int PPR = HD * SZ / 16;       // 16-B pieces per key row
   constexpr int NPIECE = KEYS * PPR;      // pieces per K (or V) tile
   constexpr int UPT = (NPIECE + 255) / 256;
-  constexpr float THRESH = 12.0f;         // move the reference when a score exceeds it by more than this (log2 units)
+  constexpr float THRESH = P8 ? 8.0f : 12.0f;   // move the reference when a score exceeds it by more than this (log2 units; fp8: p <= 2^8 < 448)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   for (int i = tid; i < 2 * KEYS; i += 256) {      // K aux element 0 = 1 for every key row, V^T row HD = ones, both stages
     const int st = i / KEYS, key = i - st * KEYS;
     *reinterpret_cast<TM*>(smem + st * STAGE + key * KROWB + HD * SZ) = op_from_float<TM>(1.0f);
-    *reinterpret_cast<TM*>(smem + st * STAGE + KBYTES + HD * VROWB + key * SZ) = op_from_float<TM>(1.0f);
+    if constexpr (P8) *reinterpret_cast<uint8_t*>(smem + st * STAGE + KBYTES + HD * VROWB + key) = (uint8_t)pack_fp8x4(1.0f, 0.f, 0.f, 0.f);
+    else *reinterpret_cast<TM*>(smem + st * STAGE + KBYTES + HD * VROWB + key * SZ) = op_from_float<TM>(1.0f);
   }
 
   // ---- Q fragments (B operand of S^T = K Q^T), pre-multiplied by scale*log2e: lane (q, hi) holds d = s*2*EPC + hi*EPC .. +EPC
@@ -230,7 +242,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         {
           const int key = u % KEYS, pc = u / KEYS;
           const int pos = (key & ~31) + AMma<TM>::vpos(key & 31);
-          vt_scatter<TM>(Vs + (pc * EPC) * VROWB + pos * SZ, VROWB, vraw[i]);
+          if constexpr (P8) {       // eight 16-bit values of one key -> eight fp8 bytes down the V^T column
+            const u32x4_t w = vraw[i];
+            const uint32_t b0 = pack_fp8x4(Op16<TM>::lo(w.x), Op16<TM>::hi(w.x), Op16<TM>::lo(w.y), Op16<TM>::hi(w.y));
+            const uint32_t b1 = pack_fp8x4(Op16<TM>::lo(w.z), Op16<TM>::hi(w.z), Op16<TM>::lo(w.w), Op16<TM>::hi(w.w));
+            uint8_t* vp = reinterpret_cast<uint8_t*>(Vs + (pc * EPC) * VROWB + pos);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { vp[j * VROWB] = (uint8_t)(b0 >> (8 * j)); vp[(4 + j) * VROWB] = (uint8_t)(b1 >> (8 * j)); }
+          } else {
+            vt_scatter<TM>(Vs + (pc * EPC) * VROWB + pos * SZ, VROWB, vraw[i]);
+          }
         }
       }
     }
@@ -298,6 +319,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) s[k2][r] = __builtin_amdgcn_exp2f(s[k2][r]);
 
     // ---- [O^T ; l][d][q] += sum_key [V^T ; 1][d][key] * P^T[key][q]
+    if constexpr (P8) {
+#pragma unroll
+      for (int k2 = 0; k2 < NSUB; ++k2) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {             // 16 keys per fp8 MFMA: this lane half's 8 probabilities = 8 bytes
+          const uint32_t p0 = pack_fp8x4(s[k2][8 * sl + 0], s[k2][8 * sl + 1], s[k2][8 * sl + 2], s[k2][8 * sl + 3]);
+          const uint32_t p1 = pack_fp8x4(s[k2][8 * sl + 4], s[k2][8 * sl + 5], s[k2][8 * sl + 6], s[k2][8 * sl + 7]);
+          const long pf = (long)(((unsigned long long)p1 << 32) | p0);
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const long vf = *reinterpret_cast<const long*>(Vs + (d * 32 + l31) * VROWB + k2 * 32 + sl * 16 + hi * 8);
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, o[d], 0, 0, 0);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int k2 = 0; k2 < NSUB; ++k2) {
 #pragma unroll
@@ -316,6 +353,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
           AMma<TM>::mma(o[d], vf, pf);
         }
       }
+    }
     }
     if (t + 1 < ntile) store_tile((t + 1) & 1, (t + 1) * KEYS);
     __syncthreads();
@@ -356,11 +394,19 @@ void set_forced_attn_keys(int keys) { g_force_keys = keys; }
 
 template <typename TM, int HD, int KEYS> static hipError_t launch_hdk(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);
-  const size_t lds = attn_lds<TM, HD, KEYS>();
-  hipLaunchKernelGGL((attn_kernel<TM, HD, KEYS>), grid, dim3(256), lds, s, a);
+  const size_t lds = attn_lds<TM, HD, KEYS>();          // (the fp8 variant needs less: its V^T rows are half as long)
+  hipLaunchKernelGGL((attn_kernel<TM, HD, KEYS, false>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
 template <typename TM, int HD> static hipError_t launch_hd(const AttnArgs& a, hipStream_t s) {
+  if constexpr (sizeof(TM) == 2) {
+    if (a.pv_fp8) {
+      dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);
+      const size_t lds = attn_lds<TM, HD, 64>();
+      hipLaunchKernelGGL((attn_kernel<TM, HD, 64, true>), grid, dim3(256), lds, s, a);
+      return hipGetLastError();
+    }
+  } else if (a.pv_fp8) return hipErrorInvalidValue;
   if constexpr (attn_has128<TM, HD>()) {
     if (g_force_keys == 128) return launch_hdk<TM, HD, 128>(a, s);
   }
@@ -378,12 +424,17 @@ template <typename TM> static hipError_t launch_tm(const AttnArgs& a, int hd, hi
 }
 
 template <typename TM, int HD> static hipError_t set_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)attn_lds<TM, HD, 64>());
   if constexpr (attn_has128<TM, HD>()) {
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 128, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)attn_lds<TM, HD, 128>());
+  }
+  if constexpr (sizeof(TM) == 2) {
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<TM, HD, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)attn_lds<TM, HD, 64>());
   }
   return e;
 }

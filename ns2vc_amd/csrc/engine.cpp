@@ -141,6 +141,7 @@ struct ns2vc_unet {
   // (16-bit precisions, dim 128 / 256, LayerNorm by linearity and the fold on).  NS2VC_FUSE_FFN=0 restores the two GEMMs.
   bool fuse_ffn = true;
   bool fuse_rows = true;     // proj_in+q|k|v and attn1.to_out+attn2.to_q as one launch each (rowchain.hip)
+  bool attn_fp8 = false;     // PV product of every attention on the fp8 MFMA (16-bit precisions; BASELINE config 5's fp8 path; costs parity)
   bool fuse_ffn_pre = true;  // attn2.to_out + residual computed inside the fused feed-forward kernel
   bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
   unsigned* ln_health = nullptr;
@@ -745,6 +746,7 @@ struct Planner {
     a.B = B; a.H = h->cfg.heads; a.Lq = Lq; a.Lk = Lk; a.bias = bias;
     a.scale = 1.0f / std::sqrt((float)hd);
     a.out = out; a.ldo = ldo;
+    a.pv_fp8 = (h->attn_fp8 && prec != PREC_F32) ? 1 : 0;
     const int pr = prec;
     add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd,
         (double)opsz * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
@@ -1187,6 +1189,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1264,7 +1267,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn)", name);
+  else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, attn_fp8)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }

@@ -936,3 +936,49 @@ def test_rowchain_groupnorm_prologue(dim, B, T, nt, prec, diag):
         assert np.isfinite(zo).all() and e_y < 2e-5 and e_z < eps16(prec)
         if mult == 1:                                  # W1 = I, b1 = 0: y IS the panel the prologue built
             assert (yo != a_gn).mean() < 2e-3 and np.abs(yo - a_gn).max() <= eps16(prec) * 4 * np.abs(a_gn).max()
+
+
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[0] in ("self_hd16", "self_hd32", "cross_hd48_mask", "cross_hd64_mask", "self_hd16_long", "cross_hd16_129")],
+                         ids=lambda c: c[0])
+def test_attention_fp8_pv(case, prec, diag):
+    """pv_fp8: the PV product on the fp8 MFMA (V and the probabilities rounded to OCP e4m3 inside the kernel; QK^T, softmax state
+    and accumulators unchanged).  Against the exact fp64 attention the error is the fp8 rounding of P and V averaged over the
+    keys -- a few 1e-2 at most, well above the 16-bit kernel's, which is also asserted (so the test notices if the flag were ignored)."""
+    from ns2vc_amd._lib import AttnArgs, check
+    from ns2vc_amd.engine import sync
+    name, B, H, hd, Lq, Lk, use_bias, packed = case
+    lib = _lib()
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 8)
+    D = H * hd
+    q, k, v = (rng.standard_normal((B, L, D)).astype(np.float32) for L in (Lq, Lk, Lk))
+    bias = None
+    if use_bias:
+        keep = rng.random((B, Lk)) > 0.3
+        keep[:, 0] = True
+        bias = ((1.0 - keep.astype(np.float32)) * -10000.0).astype(np.float32)
+    ref = ref_attention(rnd(q, prec), rnd(k, prec), rnd(v, prec), bias, H, prec)
+    errs = {}
+    for flag in (0, 1):
+        a = AttnArgs()
+        d_q, d_k, d_v = OpBuf(q, prec), OpBuf(k, prec), OpBuf(v, prec)
+        a.q, a.k, a.v = d_q.ptr, d_k.ptr, d_v.ptr
+        a.ldq = a.ldk = a.ldv = D
+        a.B, a.H, a.Lq, a.Lk = B, H, Lq, Lk
+        d_bias = _dev(bias) if bias is not None else None
+        if d_bias is not None:
+            a.bias = d_bias.ptr
+        a.scale = 1.0 / np.sqrt(hd)
+        d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
+        a.out, a.ldo = d_out.ptr, D
+        a.pv_fp8 = flag
+        check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
+        sync()
+        out = d_out.read()
+        assert np.isfinite(out).all()
+        errs[flag] = rel_l2(out, ref)
+    diag(f"attention {name} prec={prec}: 16-bit PV {errs[0]:.3e}, fp8 PV {errs[1]:.3e}")
+    assert errs[1] < 4e-2 and errs[1] > 2 * errs[0]
+    a32 = AttnArgs()
+    a32.pv_fp8 = 1
+    assert lib.ns2vc_k_attention(C.byref(a32), hd, 0, None) != 0          # no fp8 variant of the exact-fp32 kernel: loud
