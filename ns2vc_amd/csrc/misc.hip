@@ -283,20 +283,28 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
     if (i < n) o[lane + 64 * i] = (v[i] - mean) * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
 }
 
-// class token = mean_t(LN(prompt)) + positional_embedding  (embeddings.py:524)
+// class token = mean_t(LN(prompt)) + positional_embedding  (embeddings.py:524).  grid (B, C/64): 64 channels x 4 time slices
+// per block, the slices meet in LDS in a fixed order (was: one block per batch item walking all L rows serially, 109 us)
 __global__ __launch_bounds__(256) void pool_cls_kernel(float* __restrict__ seq, int L, int C, const float* __restrict__ pos) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s = 0.f;
+  __shared__ float part[4][64];
+  const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C) {
     const float* p = seq + ((size_t)b * (L + 1) + 1) * C + c;
-    for (int t = 0; t < L; ++t) s += p[(size_t)t * C];
-    seq[(size_t)b * (L + 1) * C + c] = s / (float)L + pos[c];
+    for (int t = sl; t < L; t += 4) s += p[(size_t)t * C];
+  }
+  part[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    const int i = threadIdx.x & 63;
+    seq[(size_t)b * (L + 1) * C + c] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) / (float)L + pos[c];
   }
 }
 
 // AttentionPooling (embeddings.py:499-546): one query (the class token) per
 // (batch, head); keys/values = [cls ; LN(prompt)].  qkv rows hold (q|k|v), each
-// C wide.  One wave per head, lanes stride over keys.  dph = C/heads <= 8.
+// C wide.  One wave per head (grid (B, heads/4): was one block per batch item looping over 16 heads per wave, 188 us),
+// lanes stride over keys.  dph = C/heads <= 8.
 __global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict__ qkv, int L1, int C, int heads,
                                                         float* __restrict__ pooled) {
   extern __shared__ float s_sc[];           // 4 waves x L1 scores
@@ -305,7 +313,9 @@ __global__ __launch_bounds__(256) void pool_attn_kernel(const float* __restrict_
   const float inv = 1.0f / sqrtf((float)dph);   // (q*s).(k*s), s = dph^-1/4
   float* sc = s_sc + wave * L1;
   const float* base = qkv + (size_t)b * L1 * 3 * C;
-  for (int h = wave; h < heads; h += 4) {
+  {
+    const int h = blockIdx.y * 4 + wave;
+    if (h >= heads) return;
     float qv[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) qv[c] = (c < dph) ? base[h * dph + c] : 0.f;      // row 0 = class token
@@ -607,12 +617,12 @@ hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float*
   return hipGetLastError();
 }
 hipError_t launch_pool_cls(float* seq, int B, int L, int C, const float* pos, hipStream_t s) {
-  hipLaunchKernelGGL(pool_cls_kernel, dim3(B), dim3(256), 0, s, seq, L, C, pos);
+  hipLaunchKernelGGL(pool_cls_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, s, seq, L, C, pos);
   return hipGetLastError();
 }
 hipError_t launch_pool_attn(const float* qkv, int B, int L1, int C, int heads, float* pooled, hipStream_t s) {
   if (C % heads || C / heads > 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pool_attn_kernel, dim3(B), dim3(256), 4 * (size_t)L1 * sizeof(float), s, qkv, L1, C, heads, pooled);
+  hipLaunchKernelGGL(pool_attn_kernel, dim3(B, (heads + 3) / 4), dim3(256), 4 * (size_t)L1 * sizeof(float), s, qkv, L1, C, heads, pooled);
   return hipGetLastError();
 }
 hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, const float* b, int E, const float* gamma,
