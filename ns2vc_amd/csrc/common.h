@@ -115,6 +115,14 @@ template <typename TM> __device__ __forceinline__ void store_op(TM* p, float v);
 template <> __device__ __forceinline__ void store_op<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void store_op<bf16_t>(bf16_t* p, float v) { p->v = (uint16_t)pack_bf16x2(v, 0.f); }
 template <> __device__ __forceinline__ void store_op<f16_t>(f16_t* p, float v) { p->v = (uint16_t)pack_f16x2(v, 0.f); }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope memory fence: once a kernel has
+// issued global stores the compiler puts `s_waitcnt vmcnt(0)` in front of the barrier, i.e. every wave sits through the
+// write latency of everything stored so far (1-2 us per barrier in the epilogues, found in the ISA).  Where the barrier only
+// protects an LDS staging buffer this is all that is needed.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
 template <typename TM> __device__ __forceinline__ void store_op4(TM* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store_op4<float>(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);

@@ -408,14 +408,14 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   TM* const oo = reinterpret_cast<TM*>(a.out_op);
 #pragma unroll
   for (int r2 = 0; r2 < NB / 2; ++r2) {                   // two 32-channel blocks per barrier pair
-    if (r2) __syncthreads();
+    if (r2) lds_barrier();          // (LDS-only: the previous round's result stores stay in flight)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<float4*>(Ew + u * EBLK + 8 * j) =
             make_float4(accO[2 * r2 + u][4 * j], accO[2 * r2 + u][4 * j + 1], accO[2 * r2 + u][4 * j + 2], accO[2 * r2 + u][4 * j + 3]);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int nb = 2 * r2 + u;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     // GroupNorm statistics of the result: per 16-channel block, the 64 tokens x 4 channel quads are summed in a FIXED order
     // (lane partials above -> per-token sums -> shuffle tree over the tokens) and leave as ONE int64 fixed-point atomic
     // per (batch item, block, moment): deterministic, 8 .. 64 atomics per workgroup
-    __syncthreads();
+    lds_barrier();
     constexpr int TPB = 512 / (2 * NB);                   // threads per 16-channel block: 64 (dim 128) / 32 (dim 256)
     constexpr int TPT = 64 / TPB;                         // tokens per thread
     const int blk = tid / TPB, tl = tid % TPB;

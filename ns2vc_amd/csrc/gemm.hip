@@ -482,12 +482,13 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    __syncthreads();                                // ring (or the previous slab) is free
+    lds_barrier();                                  // ring (or the previous slab) is free.  (LDS-only barriers: the stores of
+                                                    //  the previous slab are in flight and nobody here waits for them)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) et_mine[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
-    __syncthreads();
+    lds_barrier();
     if (mt == 0) NS2VC_STAMP(5);
     const int mrow0 = mw0 + mt * 32 + kg * 16;      // first of my 16 rows
     if (g.geglu) {
@@ -519,11 +520,22 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
       }
     } else {
       float4 rr[NIT];                               // residual rows first (res may alias out_f32 element-for-element)
+      if (g.res) {                                  // (uniform branch, rows past M read row M-1 and are never stored: straight-line
+#pragma unroll                                      //  loads -- per-lane conditional loads were compiled with a wait after each)
+        for (int k = 0; k < NIT; ++k) {
+          const int m = min(mrow0 + k * RPI + rsub, g.M - 1);
+          rr[k] = *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol);
+        }
+      } else {
 #pragma unroll
-      for (int k = 0; k < NIT; ++k) {
-        const int m = mrow0 + k * RPI + rsub;
-        rr[k] = (g.res && m < g.M) ? *reinterpret_cast<const float4*>(g.res + (size_t)m * g.ldres + ncol) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NIT; ++k) rr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      // Two passes: FIRST every value of the slab is computed into its own registers (this consumes all residual rows and
+      // LDS reads), THEN all stores are issued back to back.  Interleaved, the compiler had to wait for stores to complete
+      // (s_waitcnt vmcnt) before it could reuse a store's data registers for the next row pass, and with loads and stores
+      // both pending it can only wait with vmcnt(0): every pass sat through the write latency of the previous one.
+      float4 vv[NIT];
+      float2 rs2[NIT];
 #pragma unroll
       for (int k = 0; k < NIT; ++k) {
         const int row = k * RPI + rsub, m = mrow0 + row;
@@ -535,15 +547,24 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
           a.x = rs * (a.x - mu * ws.x); a.y = rs * (a.y - mu * ws.y); a.z = rs * (a.z - mu * ws.z); a.w = rs * (a.w - mu * ws.w);
         }
         float ps = 0.f, pq = 0.f;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m < g.M) {
-          float4 v;
           v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
-          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ncol, v.x, v.y, v.z, v.w);
-          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, v.x, v.y, v.z, v.w);
           ps = (v.x + v.y) + (v.z + v.w); pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           if (m < mB) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
         }
-        if (g.rowstats) ln_row_store(g, m, ncol, cq, ps, pq);
+        vv[k] = v;
+        rs2[k] = make_float2(0.f, 0.f);
+        if (g.rowstats) rs2[k] = make_float2(sum16_dpp(ps), sum16_dpp(pq));
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int m = mrow0 + k * RPI + rsub;
+        if (m < g.M) {
+          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
+          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
+          if (g.rowstats && cq == 0) *reinterpret_cast<float2*>(g.rowstats + ((size_t)m * (g.N >> 6) + (ncol >> 6)) * 2) = rs2[k];
+        }
       }
     }
   }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     pq = __uint_as_float(q2[0]) + __uint_as_float(q2[1]);
     if (hi == 0) stats[tok * 4 + cg] = make_float2(ps, pq);
   }
-  __syncthreads();                                  // y panel and statistics complete
+  lds_barrier();                                    // y panel and statistics complete (LDS-only: the fp32 stores of y stay in flight)
   {
     float ratio = 0.f;
 #pragma unroll
