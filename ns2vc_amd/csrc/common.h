@@ -242,7 +242,7 @@ hipError_t init_rowchain_attributes();
 void set_forced_rowchain_tokens(int nt);        // test hook: 0 = heuristic, 1 = 64-token blocks, 2 = 128-token blocks (dim 128 only)
 hipError_t launch_emb_from_table(const float* table, const int* step_ptr, const float* aug, float* emb, void* emb_act_op, int prec, int B,
                                  int edim, hipStream_t s);
-hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);                                  // bytes: any; p 16-byte aligned
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s, int* counter = nullptr);                                  // bytes: any; p 16-byte aligned
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);           // bytes % 16 == 0
 hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStream_t s);
 hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s);
@@ -256,7 +256,6 @@ hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, 
                             const float* gamma, const float* beta, float eps, float* out, hipStream_t s);
 hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0,
                                 float* xe, void* xe_op, int prec, float* xbar, float* d1, float* mprev, size_t n, hipStream_t s);
-hipError_t launch_step_advance(int* step_ptr, hipStream_t s);
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s);
 
 }  // namespace ns2vc

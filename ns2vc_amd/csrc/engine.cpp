@@ -981,7 +981,9 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     P.stats_cap = cap; P.stats_used = 0;
     long long* pool = P.stats_pool;
     ns2vc_unet* hq = h;
-    P.add("gn_stats.clear", [=](hipStream_t s) { return launch_zero(pool, hq->stats_bytes, s); }, 4);
+    // first launch of every forward: clears the statistics pool and, in the sampling loop, advances the step counter
+    // (ns2vc_sampler_run starts it at -1; a plain forward does not read it)
+    P.add("gn_stats.clear", [=](hipStream_t s) { return launch_zero(pool, hq->stats_bytes, s, hq->step_dev); }, 4);
   }
   {
     ns2vc_unet* hh = h;
@@ -1375,7 +1377,6 @@ static int run_step(ns2vc_unet* h, hipStream_t s) {
   if (run_ops(h->fwd_ops, s)) return 1;
   const size_t n = (size_t)h->B * h->T * h->CP;
   HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xe_op, h->prec, h->xbar, h->d1, h->mprev, n, s));
-  HIPCHK(launch_step_advance(h->step_dev, s));
   return 0;
 }
 
@@ -1410,7 +1411,7 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
   HIPCHK(launch_copy16(h->xe, h->xbar, n * sizeof(float), s));
   HIPCHK(launch_zero(h->d1, n * sizeof(float), s));
   HIPCHK(launch_zero(h->mprev, n * sizeof(float), s));
-  HIPCHK(launch_fill_i32(h->step_dev, 0, s));
+  HIPCHK(launch_fill_i32(h->step_dev, -1, s));      // the first launch of every step advances it (gn_stats.clear)
   for (int i = 0; i < h->steps; ++i) {
     if (use_graph) HIPCHK(hipGraphLaunch(h->step_graph, s));
     else if (run_step(h, s)) return 1;

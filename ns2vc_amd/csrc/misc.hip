@@ -547,7 +547,6 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
     out_f4(mprev + 4 * i, om.x, om.y, om.z, om.w);
   }
 }
-__global__ void step_advance_kernel(int* step_ptr) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_ptr += 1; }
 __global__ void fill_i32_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
 
 // ---------------------------------------------------------------------------
@@ -700,26 +699,26 @@ hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoe
                                          xbar, d1, mprev, n4));
   return hipGetLastError();
 }
-hipError_t launch_step_advance(int* step_ptr, hipStream_t s) {
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, s, step_ptr);
-  return hipGetLastError();
-}
 // Plain kernels for clearing / copying workspace buffers.  The step loop is replayed from a captured hipGraph; memset /
 // memcpy NODES in that graph (what hipMemsetAsync / hipMemcpyAsync become under capture) were seen to make replays of the
 // 32 x 938 plan return garbage depending on what ran before (tools/order_probe.py), kernel nodes never -- so everything
 // inside and next to the captured loop is a kernel.
-__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+// `counter` (optional): the sampling loop's step counter, advanced by the FIRST launch of every step (nobody else is running
+// then: every other launch of the step only reads it) -- one launch less than a separate one-thread kernel at the step's end
+__global__ __launch_bounds__(256) void zero_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail,
+                                                   int* __restrict__ counter) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+  if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
 }
 __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
-hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s, int* counter) {
   if (((uintptr_t)p & 15) != 0) return hipErrorInvalidValue;
   const size_t n16 = bytes / 16;
   const int blocks = (int)std::min<size_t>(2048, std::max<size_t>(1, (n16 + 255) / 256));
-  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)p, n16, (unsigned char*)p + n16 * 16, (int)(bytes & 15));
+  hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, s, (uint4*)p, n16, (unsigned char*)p + n16 * 16, (int)(bytes & 15), counter);
   return hipGetLastError();
 }
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s) {
