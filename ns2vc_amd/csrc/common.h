@@ -213,7 +213,6 @@ constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
-bool gemm_gn_fits(const GemmArgs& g, int prec);   // GroupNorm-in-producer (g.gn_*): arguments valid and the whole grid co-resident
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
 void set_forced_gemm_tile(int bm, int bn, int stages);

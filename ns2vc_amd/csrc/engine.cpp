@@ -96,7 +96,6 @@ struct Op {
   int kind = 0;          // 0 other, 1 implicit GEMM, 2 attention, 3 norm statistics, 4 copy
   double flops = 0.0;    // algorithmic FLOPs (2*MAC) of this launch
   double bytes = 0.0;    // algorithmic (compulsory) HBM bytes: operands read once + result written once
-  std::function<hipError_t(hipStream_t)> reset;   // optional: restores what the launch consumes (the per-launch profiler repeats launches)
 };
 struct Tap {
   std::string name;
@@ -145,10 +144,6 @@ struct ns2vc_unet {
   bool attn_fp8 = false;     // PV product of every attention on the fp8 MFMA (16-bit precisions; BASELINE config 5's fp8 path; costs parity)
   bool fuse_ffn_pre = true;  // attn2.to_out + residual computed inside the fused feed-forward kernel
   bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
-  // norm2 (+ time scale / shift + SiLU) of a resnet applied by conv1's own launch, which waits for the whole grid's statistics (gemm.hip,
-  // ns2vc_gemm_args.gn_fault) wherever the launch's grid is co-resident: conv1's fp32 result is never written or re-read and
-  // the gn_apply launch is gone.  NS2VC_GN_PRODUCER=0 restores the separate launch.  Faults: ns2vc_unet_sync_faults.
-  bool gn_producer = true;
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -729,25 +724,9 @@ struct Planner {
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
     g.stats = new_stats(h1, Tl, r.cout);
-    // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut.  norm2 is applied by conv1's own launch where its grid is one
-    // co-resident round of workgroups (h1 is then never written), by a gn_apply launch otherwise
-    bool in_producer = false;
-    if (h->gn_producer && g.stats) {
-      GemmArgs gp = g;
-      gp.out_f32 = nullptr; gp.out_op = hn; gp.ldo_op = r.cout;
-      gp.gn_gamma = r.n2g; gp.gn_beta = r.n2b; gp.gn_temb = h->temb; gp.gn_ldtemb = h->temb_all.N; gp.gn_temb_off = r.temb_off;
-      gp.gn_groups = G; gp.gn_silu = 1; gp.gn_eps = 1e-5f;
-      gp.gn_fault = h->ln_health + 1;
-      if (gemm_gn_fits(gp, prec)) { g = gp; in_producer = true; }
-    }
     gemm(r.prefix + ".conv1", g);
-    if (in_producer && !sizing) {      // the launch waits on the arrival counts in its statistics slots: a repeated launch needs them cleared
-      long long* st = g.stats;
-      const size_t bytes = (size_t)B * (r.cout / 16) * 2 * sizeof(long long);
-      ops->back().reset = [=](hipStream_t s) { return launch_zero(st, bytes, s); };
-    }
-    if (!in_producer)
-      groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
+    // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut
+    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3;
     if (r.shortcut) {      // out = conv2(hn) + conv_shortcut(x): the 1x1 conv rides along as a second K segment
@@ -1211,7 +1190,6 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_GN_PRODUCER")) h->gn_producer = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
@@ -1292,8 +1270,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
-  else if (!strcmp(name, "gn_producer")) opt = &h->gn_producer;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, gn_producer, attn_fp8)", name);
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, attn_fp8)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1306,15 +1283,6 @@ int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio) {
   HIPCHK(hipMemcpy(&bits, h->ln_health, sizeof(bits), hipMemcpyDeviceToHost));
   HIPCHK(hipMemset(h->ln_health, 0, sizeof(bits)));
   memcpy(out_ratio, &bits, sizeof(float));
-  return 0;
-}
-
-int ns2vc_unet_sync_faults(ns2vc_unet* h, unsigned* out_count) {
-  if (check_ready(h, true)) return 1;
-  if (!out_count) return fail("null argument");
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(out_count, h->ln_health + 1, sizeof(unsigned), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(h->ln_health + 1, 0, sizeof(unsigned)));
   return 0;
 }
 
@@ -1494,35 +1462,20 @@ int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, int reps, voi
   hipStream_t s = (hipStream_t)stream;
   h->use_step_table = false;      // time with the (B,) timestep buffer of the plain forward
   std::vector<hipEvent_t> ev(2 * n);
-  std::vector<bool> single(n, false);
   for (auto& e : ev) HIPCHK(hipEventCreate(&e));
   int rc = 0;
   for (size_t i = 0; i < n && !rc; ++i) {
-    const Op& op = h->fwd_ops[i];
-    if (op.reset) {
-      // a launch that waits on state it consumes (GroupNorm in the producer: arrival counts in the statistics slots): restore the
-      // state outside the timed bracket and time ONE launch (the last repetition)
-      for (int r = 0; r < reps && !rc; ++r) {
-        hipError_t e = op.reset(s);
-        if (e == hipSuccess && r == reps - 1 && hipEventRecord(ev[2 * i], s) != hipSuccess) rc = fail("hipEventRecord failed");
-        if (e == hipSuccess) e = op.fn(s);
-        if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
-      }
-      if (!rc && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) rc = fail("hipEventRecord failed");
-      single[i] = true;
-      continue;
-    }
     if (hipEventRecord(ev[2 * i], s) != hipSuccess) rc = fail("hipEventRecord failed");
     for (int r = 0; r < reps && !rc; ++r) {
-      hipError_t e = op.fn(s);
-      if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
+      hipError_t e = h->fwd_ops[i].fn(s);
+      if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", h->fwd_ops[i].name.c_str(), hipGetErrorString(e));
     }
     if (!rc && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) rc = fail("hipEventRecord failed");
   }
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
   for (size_t i = 0; i < n && !rc; ++i) {
     if (hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
-    if (!single[i]) ms[i] /= (float)reps;
+    ms[i] /= (float)reps;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;

@@ -53,9 +53,6 @@ __device__ unsigned long long* g_gemm_trace = nullptr;
 #endif
 
 constexpr int TROW = 128;   // bytes of K per tile row (64 bf16 / 32 f32)
-constexpr long long GN_ARRIVAL = 1LL << 54;   // one contribution to a statistics slot, counted above its fixed-point value (GroupNorm in the producer)
-constexpr int GN_MAX_ARRIVALS = 255;          // contributions per slot the count above the value can hold without touching the sign bit
-constexpr int GN_SPIN_LIMIT = 20000;   // polls (~2 us each) of the in-kernel grid barrier before a workgroup gives up and counts a fault
 
 // ---------------------------------------------------------------------------
 // LayerNorm by linearity.  LayerNorm(x) W^T = rstd * (x W^T - mean * rowsum(W)), so a GEMM whose input is a LayerNorm
@@ -482,26 +479,6 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
     if (g.geglu) { wsv = *reinterpret_cast<const float4*>(g.ln_wsum + pcol); wsg = *reinterpret_cast<const float4*>(g.ln_wsum + pcol + 32); }
     else ws = *reinterpret_cast<const float4*>(g.ln_wsum + ncol);
   }
-  // GroupNorm of the result applied by this launch (g.gn_fault, see the end of this function): the slab values stay in
-  // registers until the whole grid has contributed its statistics; affine / time-conditioning vectors are fetched here
-  const bool gnp = !LNC && g.gn_fault != nullptr;
-  constexpr int KM = LNC ? 1 : MT;
-  float4 keep[KM][NIT];
-  float4 gga = make_float4(0.f, 0.f, 0.f, 0.f), gbe = gga, gts[2] = {gga, gga}, gtf[2] = {gga, gga};
-  if constexpr (!LNC) {
-    if (gnp) {
-      gga = *reinterpret_cast<const float4*>(g.gn_gamma + ncol);
-      gbe = *reinterpret_cast<const float4*>(g.gn_beta + ncol);
-      if (g.gn_temb) {
-#pragma unroll
-        for (int bi = 0; bi < 2; ++bi) {
-          const float* tp = g.gn_temb + (size_t)min(b0 + bi, g.B - 1) * g.gn_ldtemb + g.gn_temb_off + ncol;
-          gts[bi] = *reinterpret_cast<const float4*>(tp);
-          gtf[bi] = *reinterpret_cast<const float4*>(tp + g.N);
-        }
-      }
-    }
-  }
 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -580,20 +557,13 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
         rs2[k] = make_float2(0.f, 0.f);
         if (g.rowstats) rs2[k] = make_float2(sum16_dpp(ps), sum16_dpp(pq));
       }
-      if (gnp) {
-        if constexpr (!LNC) {
 #pragma unroll
-          for (int k = 0; k < NIT; ++k) keep[mt][k] = vv[k];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const int m = mrow0 + k * RPI + rsub;
-          if (m < g.M) {
-            if (of) out_f4(of + (size_t)m * g.ldo_f32 + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
-            if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
-            if (g.rowstats && cq == 0) *reinterpret_cast<float2*>(g.rowstats + ((size_t)m * (g.N >> 6) + (ncol >> 6)) * 2) = rs2[k];
-          }
+      for (int k = 0; k < NIT; ++k) {
+        const int m = mrow0 + k * RPI + rsub;
+        if (m < g.M) {
+          if (of) out_f4(of + (size_t)m * g.ldo_f32 + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
+          if (oo) out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
+          if (g.rowstats && cq == 0) *reinterpret_cast<float2*>(g.rowstats + ((size_t)m * (g.N >> 6) + (ncol >> 6)) * 2) = rs2[k];
         }
       }
     }
@@ -610,110 +580,13 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
     }
     if (rsub == 0 && (cq & 3) == 0 && mw0 < g.M) {
       const int blk = ncol >> 4, nblk = g.N >> 4;
-      // GroupNorm in the producer: every contribution also counts itself in the bits above the fixed-point value
-      const unsigned long long one = gnp ? (unsigned long long)GN_ARRIVAL : 0ull;
       unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
-      atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE) + one);
-      atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE) + one);
+      atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
+      atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
       if (mB < g.M && mB < mw0 + WM) {
-        atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE) + one);
-        atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE) + one);
+        atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
+        atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
       }
-    }
-  }
-  if constexpr (!LNC) {
-    if (gnp) {
-      // ---- GroupNorm in the PRODUCER (resnet.py:600-612: norm2, time scale / shift, SiLU on conv1's result).  The grid is
-      // one round of co-resident workgroups (the host checked: gemm_gn_fits), so a workgroup can wait for the others inside the
-      // kernel.  No counter and no fence: every statistics atomic above carries GN_ARRIVAL = 2^54 on top of its fixed-point
-      // value (|value| < 2^53), so a slot holds  contributions * 2^54 + sum  and the number of contributions a (batch item,
-      // 16-channel block) will receive is known in closed form.  A lane polls the slots of ITS group past the non-coherent caches
-      // (agent-scope atomic loads) until both moments are complete -- the poll that sees the last contribution also returns
-      // the finished sums: ~two memory round trips after the atomics, against ~four for arrive-counter + barrier + re-read
-      // (measured: that version cost more than the gn_apply launch it saved).  The fp32 tensor is never written or re-read.
-      // The spin is bounded: a grid that is NOT co-resident shows up as a fault count, not as a hang.
-      const int Cg = g.N / g.gn_groups, nbk = Cg >> 4, nblk = g.N >> 4;
-      const int grp = ncol / Cg;
-      const bool two = mB < g.M && mB < mw0 + WM;            // (wave-uniform) this wave's rows straddle two batch items
-      const float gam[4] = {gga.x, gga.y, gga.z, gga.w}, bet[4] = {gbe.x, gbe.y, gbe.z, gbe.w};
-      float sc[2][4], sh[2][4];
-#pragma unroll
-      for (int bi = 0; bi < 2; ++bi) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { sc[bi][e] = 0.f; sh[bi][e] = 0.f; }
-        if (bi == 1 && !two) continue;
-        const int b = b0 + bi;
-        // contributions per slot of batch item b: one per wave tile (WM rows, both K halves) that starts inside the item, plus
-        // the one tile that starts before it and reaches into it (unless the item starts on a tile boundary)
-        const long long lo = (long long)b * g.Tout, hi = lo + g.Tout;
-        const long long expect = 2 * ((hi + WM - 1) / WM - (lo + WM - 1) / WM + ((b > 0 && lo % WM != 0) ? 1 : 0));
-        const long long* p = g.stats + ((size_t)b * nblk + (size_t)grp * nbk) * 2;
-        // one lane per 16-channel block of the wave tile polls (four per wave: every poll is an uncached request to the memory
-        // side, and with all 64 lanes of all waves polling the requests starved the very atomics they were waiting for);
-        // mean / rstd reach the other lanes of the block by shuffle
-        float mean_f = 0.f, r = 0.f;
-        if (rsub == 0 && (cq & 3) == 0) {
-        long long rs_[4], rq_[4];
-        int spins = 0;
-        while (true) {
-          bool all = true;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            rs_[j] = 0; rq_[j] = 0;
-            if (j < nbk) {
-              rs_[j] = __hip_atomic_load(p + 2 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              rq_[j] = __hip_atomic_load(p + 2 * j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              const long long cs = (rs_[j] + (GN_ARRIVAL >> 1)) >> 54, cq2 = (rq_[j] + (GN_ARRIVAL >> 1)) >> 54;
-              all = all && cs >= expect && cq2 >= expect;       // (== expect: the caller clears the slots before every launch)
-              rs_[j] -= cs * GN_ARRIVAL; rq_[j] -= cq2 * GN_ARRIVAL;
-            }
-          }
-          if (all) break;
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > GN_SPIN_LIMIT) { atomicAdd(g.gn_fault, 1u); break; }
-        }
-        double vs[4], vq[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { vs[j] = (double)rs_[j] * (1.0 / GN_SUM_SCALE); vq[j] = (double)rq_[j] * (1.0 / GN_SQ_SCALE); }
-        // the same arithmetic, in the same order, as gn_apply_kernel (misc.hip): the two paths agree bit for bit
-        const double ds = (vs[0] + vs[2]) + (vs[1] + vs[3]), dq = (vq[0] + vq[2]) + (vq[1] + vq[3]);
-        const float inv_nf = 1.0f / ((float)g.Tout * (float)Cg);
-        const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)g.Tout * (double)Cg));
-        const double mean = ds * inv_n;
-        double var = dq * inv_n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float ve = (float)var + g.gn_eps;
-        r = rsqrtf(ve);
-        r = r * (1.5f - 0.5f * ve * r * r);
-        mean_f = (float)mean;
-        }
-        mean_f = __shfl(mean_f, cq & ~3);
-        r = __shfl(r, cq & ~3);
-        const float ts[4] = {gts[bi].x, gts[bi].y, gts[bi].z, gts[bi].w}, tf[4] = {gtf[bi].x, gtf[bi].y, gtf[bi].z, gtf[bi].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sc[bi][e] = r * gam[e];
-          sh[bi][e] = bet[e] - mean_f * sc[bi][e];
-          if (g.gn_temb) {
-            const float s1 = 1.0f + ts[e];
-            sc[bi][e] *= s1;
-            sh[bi][e] = sh[bi][e] * s1 + tf[e];
-          }
-        }
-      }
-#pragma unroll
-      for (int mt = 0; mt < KM; ++mt)
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-          const int m = mw0 + mt * 32 + kg * 16 + k * RPI + rsub;
-          if (m < g.M) {
-            const int bi = m < mB ? 0 : 1;
-            const float4 w = keep[mt][k];
-            float y0 = w.x * sc[bi][0] + sh[bi][0], y1 = w.y * sc[bi][1] + sh[bi][1], y2 = w.z * sc[bi][2] + sh[bi][2], y3 = w.w * sc[bi][3] + sh[bi][3];
-            if (g.gn_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-            out_op4<TM>(oo + (size_t)m * g.ldo_op + ncol, y0, y1, y2, y3);
-          }
-        }
     }
   }
 #if NS2VC_GEMM_TRACE
@@ -740,7 +613,7 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 //     then all eight waves add the pair while they transpose rows out -- every wave stores, nothing idles.
 // ---------------------------------------------------------------------------
 template <typename TM, int BM, int BN, int STAGES, bool LNC>
-__global__ __launch_bounds__(512, 4) void gemm4_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
@@ -968,20 +841,22 @@ void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force
 // Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
 // The compiled set is exactly what this function can return plus the tiles the kernel tests force:
 //   gemm4: {128, 64} x 128, ring {2, 3};   gemm2: 64x128 ring {2, 3}, 128x128 ring 2, 64x64 ring {2, 3, 4}.
-static bool pick_tile(const GemmArgs& g, int opsz, int& bm, int& bn, int& st) {
-  const int bke = 128 / opsz;
+template <typename TM>
+static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
+  const int bke = 128 / (int)sizeof(TM);
   const int nk = g.K / bke;
+  int bm, bn, st;
   const bool n128 = (g.N % 128) == 0;
   if (g_force_bm) {   // test / tuning hook (ns2vc_debug_set_gemm_tile)
     bm = g_force_bm; bn = g_force_bn; st = g_force_st ? g_force_st : 3;
-    if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return false;
+    if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return hipErrorInvalidValue;
   } else {
     // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01d_bufferdma.txt).
     // The 8-wave K-split kernel wins everywhere except the narrowest GEGLU; 128-row tiles pay off once K is long
     // (>= 12 tiles) or N is wide, and only while the grid still covers the chip (M >= ~7000 rows).
     const bool big_m = g.M >= 7000;
     if (g.geglu) {
-      if (!n128) return false;
+      if (!n128) return hipErrorInvalidValue;
       if (g.N >= 2048) { bm = 128; bn = 128; st = 12; }
       else { bm = 64; bn = 128; st = 2; }
     } else if (n128 && g.N <= 512) {
@@ -996,14 +871,6 @@ static bool pick_tile(const GemmArgs& g, int opsz, int& bm, int& bn, int& st) {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
   }
-  return true;
-}
-
-template <typename TM>
-static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
-  int bm, bn, st;
-  if (!pick_tile(g, (int)sizeof(TM), bm, bn, st)) return hipErrorInvalidValue;
-  if (g.gn_fault && ((st != 12 && st != 13) || 2 * (g.Tout / (bm / 2) + 2) > GN_MAX_ARRIVALS)) return hipErrorInvalidValue;   // GroupNorm in the producer: 8-wave kernel only
   if (st == 12 || st == 13) {   // 8-wave K-split kernel, ring depth st - 10
     if (bn != 128) return hipErrorInvalidValue;
 #define NS2VC_CASE4(BM_, ST_) if (bm == BM_ && st == 10 + ST_) return launch_cfg4<TM, BM_, 128, ST_>(g, s)
@@ -1019,51 +886,8 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
   return hipErrorInvalidValue;
 }
 
-static bool gn_geom_ok(const GemmArgs& g) {
-  if (g.geglu || g.ln_stats || g.rowstats || g.Tout < 64) return false;
-  if (g.gn_groups <= 0 || g.N % g.gn_groups) return false;
-  const int cg = g.N / g.gn_groups;
-  if ((cg & 15) || cg > 64) return false;
-  if ((g.gn_ldtemb & 3) || (g.gn_temb_off & 3)) return false;
-  return true;
-}
-static bool gn_args_ok(const GemmArgs& g) {
-  return gn_geom_ok(g) && g.stats && !g.out_f32 && g.out_op && g.gn_gamma && g.gn_beta;
-}
-
-// GroupNorm in the producer needs every workgroup of the launch on the chip at once (in-kernel grid barrier): workgroups go
-// round-robin over the 8 XCDs, so the bound is per XCD
-template <typename TM> static int gemm4_blocks_per_cu(int bm, int st) {
-  int n = 0;
-#define NS2VC_OCC4(BM_, ST_)                                                                                                      \
-  if (bm == BM_ && st == 10 + ST_)                                                                                                \
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm4_kernel<TM, BM_, 128, ST_, false>, 512, gemm4_lds_bytes(BM_, 128, ST_)) != hipSuccess) n = 0
-  NS2VC_OCC4(128, 2); NS2VC_OCC4(128, 3); NS2VC_OCC4(64, 2); NS2VC_OCC4(64, 3);
-#undef NS2VC_OCC4
-  return n;
-}
-bool gemm_gn_fits(const GemmArgs& g, int prec) {      // (geometry only: callable before the workspace exists)
-  if (!gn_geom_ok(g)) return false;
-  int bm, bn, st;
-  if (!pick_tile(g, (int)operand_bytes(prec), bm, bn, st) || (st != 12 && st != 13) || bn != 128) return false;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  int per_cu = 0;
-  switch (prec) {
-    case PREC_BF16: per_cu = gemm4_blocks_per_cu<bf16_t>(bm, st); break;
-    case PREC_F16: per_cu = gemm4_blocks_per_cu<f16_t>(bm, st); break;
-    case PREC_F32: per_cu = gemm4_blocks_per_cu<float>(bm, st); break;
-    default: return false;
-  }
-  if (2 * (g.Tout / (bm / 2) + 2) > GN_MAX_ARRIVALS) return false;
-  const long nb = (long)(g.N / bn) * ((g.M + bm - 1) / bm);
-  const int xcds = cus >= 64 ? 8 : 1;
-  return per_cu > 0 && (nb + xcds - 1) / xcds <= (long)per_cu * (cus / xcds);
-}
-
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.N % 64 != 0 || g.M <= 0) return hipErrorInvalidValue;
-  if (g.gn_fault && !gn_args_ok(g)) return hipErrorInvalidValue;
   const int bke = prec == PREC_F32 ? 32 : 64;
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return hipErrorInvalidValue;
   if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return hipErrorInvalidValue;

@@ -235,14 +235,6 @@ class Engine:
         check(self.lib.ns2vc_unet_ln_ratio(self.h, C.byref(r)), "ln_ratio")
         return float(r.value)
 
-    def sync_faults(self) -> int:
-        """workgroups whose in-kernel grid barrier timed out since the last call (plan option "gn_producer"; synchronises).
-        0 on a healthy run -- anything else means the affected forwards are wrong (GPU shared with another process):
-        switch the option off."""
-        n = C.c_uint()
-        check(self.lib.ns2vc_unet_sync_faults(self.h, C.byref(n)), "sync_faults")
-        return int(n.value)
-
     def prepare(self, B: int, T: int, Lp: int) -> None:
         check(self.lib.ns2vc_unet_prepare(self.h, B, T, Lp), "ns2vc_unet_prepare")
         self.shape = (B, T, Lp)

@@ -136,82 +136,6 @@ def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, g
     return out, ref, out_op
 
 
-def _gn_silu_ref(h, B, T, G, eps, gamma, beta, temb):
-    """float64 GroupNorm over (T, C/G) per batch item, optional (1 + scale) / shift per (b, c), SiLU"""
-    C_ = h.shape[1]
-    x = h.reshape(B, T, G, C_ // G)
-    mean = x.mean(axis=(1, 3), keepdims=True)
-    var = x.var(axis=(1, 3), keepdims=True)
-    y = ((x - mean) / np.sqrt(var + eps)).reshape(B, T, C_) * gamma + beta
-    if temb is not None:
-        y = y * (1.0 + temb[:, None, :C_]) + temb[:, None, C_:]
-    return silu(y).reshape(B * T, C_)
-
-
-@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("case", [
-    # B, T, cin, N, tile, temb
-    (3, 300, 128, 128, (64, 128, 13), True),        # rows of a wave straddle batch items
-    (2, 256, 128, 256, (128, 128, 13), True),
-    (4, 75, 256, 384, (64, 128, 12), False),        # 48-channel groups: three 16-channel blocks each
-    (2, 130, 128, 512, (0, 0, 0), True),            # launcher's own tile choice
-], ids=["straddle", "tile128", "groups48", "auto"])
-def test_gemm_groupnorm_in_producer(case, prec, diag):
-    """conv1 + norm2 + time scale/shift + SiLU in ONE launch (ns2vc_gemm_args.gn_fault: the launch waits for the whole grid's
-    statistics) vs float64, and the wait never times out"""
-    from ns2vc_amd._lib import GemmArgs, check
-    from ns2vc_amd.engine import DevBuf, sync
-    B, T, cin, N, tile, with_temb = case
-    lib = _lib()
-    rng = np.random.default_rng(zlib.crc32(repr(case).encode()) + prec)
-    G, eps, M, K = 8, 1e-5, B * T, 3 * cin
-    a0 = rnd(rng.standard_normal((B, T, cin)), prec)
-    W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
-    bias = rng.standard_normal(N).astype(np.float32)
-    gamma = (1.0 + 0.3 * rng.standard_normal(N)).astype(np.float32)
-    beta = (0.3 * rng.standard_normal(N)).astype(np.float32)
-    ldt, off = 2 * N + 8, 4
-    temb = (0.5 * rng.standard_normal((B, ldt))).astype(np.float32)
-    h = gather_rows(a0.astype(np.float64), B, T, T, 3, 0).reshape(M, K) @ W.astype(np.float64).T + bias
-    ref = _gn_silu_ref(h, B, T, G, eps, gamma, beta, temb[:, off:off + 2 * N].astype(np.float64) if with_temb else None)
-
-    d_a0, d_w, d_bias, d_gam, d_bet, d_temb = OpBuf(a0, prec), _pack(W, prec), _dev(bias), _dev(gamma), _dev(beta), _dev(temb)
-    d_stats = DevBuf(B * (N // 16) * 2 * 8)
-    d_stats.upload(np.zeros(B * (N // 16) * 2, dtype=np.int64))
-    d_sync = DevBuf(16)
-    d_sync.upload(np.zeros(4, dtype=np.uint32))
-    d_oop = OpBuf(np.full((M, N), np.nan, dtype=np.float32), prec)
-    g = GemmArgs()
-    g.a0 = d_a0.ptr; g.lda0 = cin; g.c0 = cin
-    g.B, g.Tin, g.Tout, g.M = B, T, T, M
-    g.taps, g.tmode = 3, 0
-    g.w = d_w.value; g.K = K; g.N = N
-    g.bias = d_bias.ptr
-    g.out_op = d_oop.ptr; g.ldo_op = N
-    g.stats = d_stats.ptr
-    g.gn_fault = d_sync.ptr
-    g.gn_gamma = d_gam.ptr; g.gn_beta = d_bet.ptr
-    if with_temb:
-        g.gn_temb = d_temb.ptr; g.gn_ldtemb = ldt; g.gn_temb_off = off
-    g.gn_groups, g.gn_silu, g.gn_eps = G, 1, eps
-    check(lib.ns2vc_debug_set_gemm_tile(*tile), "set tile")
-    try:
-        for rep in range(2):        # (the statistics slots are cleared before every launch: they also count arrivals)
-            d_stats.upload(np.zeros(B * (N // 16) * 2, dtype=np.int64))
-            check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
-            sync()
-    finally:
-        lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
-    out = d_oop.read((M, N))
-    sy = d_sync.to_numpy((4,), dtype=np.uint32)
-    lib.ns2vc_dev_free(d_w)
-    assert sy[0] == 0, f"the in-kernel wait timed out {sy[0]} times"
-    assert np.isfinite(out).all()
-    err = rel_l2(out, ref)
-    diag(f"gemm+GroupNorm in producer {case} prec={PREC_IDS[prec]}: rel_l2={err:.3e}")
-    assert err < 3 * eps16(prec) + 2e-5, err
-
-
 GEMM_CASES = [
     # name, B, Tin, Tout, c0, c1, N, taps, tmode, bias, res, geglu, dual
     ("linear_plain", 2, 75, 75, 128, 0, 128, 1, 0, 1, 0, 0, 0),
