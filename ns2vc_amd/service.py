@@ -67,7 +67,7 @@ class GroupedConverter:
             refer = torch.stack([segments[i].refer.to(dev, torch.float32) for i in idx])
             content, prompt, mask = self.pre.infer(c, refer, torch.full((len(idx),), T, device=dev), torch.full((len(idx),), Lp, device=dev))
             # x_T per SEGMENT (seeded by its position in the input), so a segment's result does not depend on its group
-            noise = torch.stack([torch.randn((100, T), generator=torch.Generator().manual_seed(self.seed + i)) for i in idx]).to(dev)
+            noise = torch.stack([torch.randn((self.den.cfg.latent_channels, T), generator=torch.Generator().manual_seed(self.seed + i)) for i in idx]).to(dev)
             return {"content": content, "prompt": prompt, "prompt_mask": mask, "noise": noise}
 
         def post_fn(latent, idx):
