@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NS2VC_ABI_VERSION 2
+#define NS2VC_ABI_VERSION 3
 #define NS2VC_MAX_LEVELS 8
 #define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
 
@@ -83,10 +83,16 @@ int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int bufle
  *                    ln_linear and fold_ff; default 1) vs the GEGLU GEMM + the folded GEMM
  * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF / NS2VC_FUSE_FFN set the defaults at ns2vc_unet_create. */
 int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value);
-/* LayerNorm-by-linearity health: the largest |mean| / std over every LayerNorm input row seen since the last call
+/* LayerNorm-by-linearity health: the largest |mean| / std over every LayerNorm input row seen since the last read-out
  * (or since prepare).  The 16-bit modes round the raw row before centring, so their error on a row grows ~linearly
- * with this ratio (1 at ratio <~ 1; use "ln_linear" 0 when it is >> 10).  Synchronises the device; resets the maximum. */
-int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio);
+ * with this ratio (1 at ratio <~ 1; use "ln_linear" 0 when it is >> 10); in fp32 the variance E[x^2] - mean^2 loses
+ * ~ratio^2 ulps.  The read-and-reset is enqueued on `stream` (the stream the evaluations ran on), never on the legacy
+ * stream:  ns2vc_unet_ln_ratio      = enqueue + synchronise THAT stream + return the value;
+ *          ns2vc_unet_ln_ratio_post = enqueue only (no host wait);
+ *          ns2vc_unet_ln_ratio_poll = non-blocking: *out_ready = 1 and the value of the last post once it has completed. */
+int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio, void* stream);
+int ns2vc_unet_ln_ratio_post(ns2vc_unet* h, void* stream);
+int ns2vc_unet_ln_ratio_poll(ns2vc_unet* h, float* out_ratio, int* out_ready);
 
 /* Allocate workspace and build the launch plan for a (batch, frames, prompt frames) shape. */
 int ns2vc_unet_prepare(ns2vc_unet* h, int B, int T, int Lp);
@@ -119,6 +125,16 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host);
 /* x (B, latent_channels, T): x_T in, sample out.  use_graph != 0 replays one captured
  * hipGraph per step (no host sync inside the loop). */
 int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* stream);
+/* The same loop in parts (ns2vc_sampler_run = begin + steps(all) + end), so that a second engine can take over in
+ * mid-loop.  Use: MIXED PRECISION -- the last evaluations of a loop dominate the error of the sampled latent (the final
+ * second-order update of DPM-Solver++(2M), dpm_solver.py:796-831, extrapolates over a large log-SNR step), so a 16-bit
+ * engine runs steps [0, N-k) and an fp32 engine, prepared for the same shape / condition / table, runs the last k:
+ *   begin(h16, x_T); steps(h16, N-k); handoff(h32, h16); steps(h32, k); end(h32, x_out).
+ * handoff copies the fp32 solver state (x_e, x_bar, d1, m_prev, loop position) on `stream`. */
+int ns2vc_sampler_begin(ns2vc_unet* h, const float* x_T_bct, void* stream);
+int ns2vc_sampler_steps(ns2vc_unet* h, int n_steps, int use_graph, void* stream);
+int ns2vc_sampler_end(ns2vc_unet* h, float* x_out_bct, void* stream);
+int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream);
 
 /* ---- introspection for tests / profiling -------------------------------------------- */
 int ns2vc_unet_set_debug(ns2vc_unet* h, int enable);  /* keep a copy of every block output; drops the plan: call before prepare() */

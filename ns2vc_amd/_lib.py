@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
 NCOEF = 12
 MAX_LEVELS = 8
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Ns2vcError(RuntimeError):
@@ -116,9 +116,15 @@ PROTOTYPES = {
     "ns2vc_unet_forward": (_I, [_P, _P, _P, _P, _P]),
     "ns2vc_sampler_load": (_I, [_P, _I, C.POINTER(C.c_float)]),
     "ns2vc_sampler_run": (_I, [_P, _P, _I, _P]),
+    "ns2vc_sampler_begin": (_I, [_P, _P, _P]),
+    "ns2vc_sampler_steps": (_I, [_P, _I, _I, _P]),
+    "ns2vc_sampler_end": (_I, [_P, _P, _P]),
+    "ns2vc_sampler_handoff": (_I, [_P, _P, _P]),
     "ns2vc_unet_set_debug": (_I, [_P, _I]),
     "ns2vc_unet_set_option": (_I, [_P, C.c_char_p, _I]),
-    "ns2vc_unet_ln_ratio": (_I, [_P, C.POINTER(C.c_float)]),
+    "ns2vc_unet_ln_ratio": (_I, [_P, C.POINTER(C.c_float), _P]),
+    "ns2vc_unet_ln_ratio_post": (_I, [_P, _P]),
+    "ns2vc_unet_ln_ratio_poll": (_I, [_P, C.POINTER(C.c_float), C.POINTER(_I)]),
     "ns2vc_unet_num_taps": (_I, [_P]),
     "ns2vc_unet_tap_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I), C.POINTER(_I)]),
     "ns2vc_unet_tap_read": (_I, [_P, _I, _P]),

@@ -162,7 +162,12 @@ struct ns2vc_unet {
   float* temb_table = nullptr;   // [kMaxSteps][time_embed_dim]: the timestep MLP of every row of the solver table (sampling loop only)
   bool temb_table_valid = false;
   int steps = 0;
+  int next_step = -1;            // sampling loop position (host mirror of step_dev + 1); -1 = no loop begun
   bool use_step_table = false;
+  // LayerNorm-health read-out (ns2vc_unet_ln_ratio*): snapshot slot in the arena, pinned host mailbox, completion event
+  unsigned* ln_mail = nullptr;
+  hipEvent_t ln_event = nullptr;
+  bool ln_posted = false;
 
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t step_graph = nullptr;
@@ -170,6 +175,8 @@ struct ns2vc_unet {
   ~ns2vc_unet() {
     if (step_graph) (void)hipGraphExecDestroy(step_graph);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (ln_event) (void)hipEventDestroy(ln_event);
+    if (ln_mail) (void)hipHostFree(ln_mail);
     if (arena) (void)hipFree(arena);
     if (coef_dev) (void)hipFree(coef_dev);
     if (temb_table) (void)hipFree(temb_table);
@@ -1130,6 +1137,8 @@ void drop_plan(ns2vc_unet* h) {
   if (h->arena) { (void)hipDeviceSynchronize(); (void)hipFree(h->arena); h->arena = nullptr; }
   h->cond_ops.clear(); h->fwd_ops.clear(); h->taps.clear();
   h->arena_bytes = h->arena_used = 0;
+  h->next_step = -1;           // the solver state lived in the arena
+  h->ln_posted = false;
 }
 
 }  // namespace
@@ -1275,14 +1284,45 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   return 0;
 }
 
-int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio) {
+// The maximum lives in the arena and is raised by the consumers' atomicMax on whatever stream the forward runs on, so the
+// read-and-reset is a kernel + an async copy ON THAT STREAM (a host-side memset on the legacy stream raced with the
+// non-blocking streams the engine is driven on, and a device-wide synchronize stalled the overlapped pipeline).
+int ns2vc_unet_ln_ratio_post(ns2vc_unet* h, void* stream) {
   if (check_ready(h, true)) return 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (!h->ln_mail) {
+    HIPCHK(hipHostMalloc((void**)&h->ln_mail, 64, hipHostMallocDefault));
+    h->ln_mail[0] = 0;
+  }
+  if (!h->ln_event) HIPCHK(hipEventCreateWithFlags(&h->ln_event, hipEventDisableTiming));
+  HIPCHK(launch_snapshot_u32(h->ln_health, h->ln_health + 16, s));
+  HIPCHK(hipMemcpyAsync(h->ln_mail, h->ln_health + 16, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(h->ln_event, s));
+  h->ln_posted = true;
+  return 0;
+}
+
+int ns2vc_unet_ln_ratio_poll(ns2vc_unet* h, float* out_ratio, int* out_ready) {
+  if (!h || !out_ratio || !out_ready) return fail("null argument");
+  *out_ready = 0;
+  *out_ratio = 0.f;
+  if (!h->ln_posted) return 0;
+  if (bind_device(h)) return 1;
+  const hipError_t q = hipEventQuery(h->ln_event);
+  if (q == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+  if (q != hipSuccess) return fail("hipEventQuery failed: %s", hipGetErrorString(q));
+  memcpy(out_ratio, h->ln_mail, sizeof(float));
+  *out_ready = 1;
+  h->ln_posted = false;
+  return 0;
+}
+
+int ns2vc_unet_ln_ratio(ns2vc_unet* h, float* out_ratio, void* stream) {
   if (!out_ratio) return fail("null argument");
-  unsigned bits = 0;
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(&bits, h->ln_health, sizeof(bits), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemset(h->ln_health, 0, sizeof(bits)));
-  memcpy(out_ratio, &bits, sizeof(float));
+  if (ns2vc_unet_ln_ratio_post(h, stream)) return 1;
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  memcpy(out_ratio, h->ln_mail, sizeof(float));
+  h->ln_posted = false;
   return 0;
 }
 
@@ -1370,6 +1410,7 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
   HIPCHK(hipMemcpy(h->coef_dev, coef_host, (size_t)steps * NS2VC_NCOEF * sizeof(float), hipMemcpyHostToDevice));
   h->steps = steps;
   h->temb_table_valid = false;
+  h->next_step = -1;
   return 0;
 }
 
@@ -1380,13 +1421,31 @@ static int run_step(ns2vc_unet* h, hipStream_t s) {
   return 0;
 }
 
-int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* stream) {
+// The loop in three parts, so that a caller can hand the solver state to a second engine in mid-loop (mixed precision:
+// ns2vc_sampler_handoff): begin = state from x_T, steps = the next n evaluations + updates, end = layout change back.
+int ns2vc_sampler_begin(ns2vc_unet* h, const float* x_T_bct, void* stream) {
   if (check_ready(h, true)) return 1;
-  if (!x_inout_bct) return fail("null tensor");
+  if (!x_T_bct) return fail("null tensor");
   if (!h->coef_dev || h->steps <= 0) return fail("no solver table loaded (call ns2vc_sampler_load)");
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
   const size_t n = (size_t)h->B * h->T * h->CP;
+  HIPCHK(launch_nct_to_btc(x_T_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
+  HIPCHK(launch_copy16(h->xe, h->xbar, n * sizeof(float), s));
+  HIPCHK(launch_zero(h->d1, n * sizeof(float), s));
+  HIPCHK(launch_zero(h->mprev, n * sizeof(float), s));
+  HIPCHK(launch_fill_i32(h->step_dev, -1, s));      // the first launch of every step advances it (gn_stats.clear)
+  h->next_step = 0;
+  return 0;
+}
+
+int ns2vc_sampler_steps(ns2vc_unet* h, int n_steps, int use_graph, void* stream) {
+  if (check_ready(h, true)) return 1;
+  if (!h->coef_dev || h->steps <= 0) return fail("no solver table loaded (call ns2vc_sampler_load)");
+  if (h->next_step < 0) return fail("no sampling loop in progress (call ns2vc_sampler_begin or ns2vc_sampler_handoff)");
+  if (n_steps < 0 || h->next_step + n_steps > h->steps) return fail("steps %d..%d outside the loaded table of %d", h->next_step, h->next_step + n_steps, h->steps);
+  hipStream_t s = (hipStream_t)stream;
+  const auto& c = h->cfg;
   h->use_step_table = true;
   if (!h->temb_table_valid) {      // new table or new weights: timestep MLP of every table row (column 0 = t), no prompt term
     const int E = c.block_out_channels[0] * 4;
@@ -1395,7 +1454,7 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
                              h->prec, h->steps, c.block_out_channels[0], E, s));
     h->temb_table_valid = true;
   }
-  if (use_graph && !h->step_graph) {
+  if (use_graph && !h->step_graph && n_steps > 0) {
     if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
@@ -1407,17 +1466,51 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) { h->step_graph = nullptr; return fail("hipGraphInstantiate: %s", hipGetErrorString(e)); }
   }
-  HIPCHK(launch_nct_to_btc(x_inout_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
-  HIPCHK(launch_copy16(h->xe, h->xbar, n * sizeof(float), s));
-  HIPCHK(launch_zero(h->d1, n * sizeof(float), s));
-  HIPCHK(launch_zero(h->mprev, n * sizeof(float), s));
-  HIPCHK(launch_fill_i32(h->step_dev, -1, s));      // the first launch of every step advances it (gn_stats.clear)
-  for (int i = 0; i < h->steps; ++i) {
+  for (int i = 0; i < n_steps; ++i) {
     if (use_graph) HIPCHK(hipGraphLaunch(h->step_graph, s));
     else if (run_step(h, s)) return 1;
   }
-  HIPCHK(launch_btc_to_nct(h->xe, h->CP, c.latent_channels, h->T, h->B, x_inout_bct, s));
+  h->next_step += n_steps;
   return 0;
+}
+
+int ns2vc_sampler_end(ns2vc_unet* h, float* x_out_bct, void* stream) {
+  if (check_ready(h, true)) return 1;
+  if (!x_out_bct) return fail("null tensor");
+  if (h->next_step < 0) return fail("no sampling loop in progress");
+  const auto& c = h->cfg;
+  HIPCHK(launch_btc_to_nct(h->xe, h->CP, c.latent_channels, h->T, h->B, x_out_bct, (hipStream_t)stream));
+  h->next_step = -1;
+  return 0;
+}
+
+// Solver state of `src` (x_e, x_bar, d1, m_prev, loop position) -> `dst`, which continues the SAME table from there: the
+// engines may differ in precision (the state is fp32 in every mode; dst's operand copy of x_e is rebuilt in its own type).
+// Both must be prepared for the same (B, T) and hold the same solver table and condition.
+int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream) {
+  if (check_ready(dst, true) || check_ready(src, true)) return 1;
+  if (dst == src) return fail("handoff to the same engine");
+  if (dst->B != src->B || dst->T != src->T || dst->CP != src->CP) return fail("handoff between different shapes");
+  if (dst->device != src->device) return fail("handoff between engines on different devices");
+  if (src->next_step < 0) return fail("source engine has no sampling loop in progress");
+  if (!dst->coef_dev || dst->steps != src->steps) return fail("destination engine must hold the same solver table (%d vs %d steps)", dst->steps, src->steps);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)src->B * src->T * src->CP;
+  HIPCHK(launch_copy16(src->xe, dst->xe, n * sizeof(float), s));
+  HIPCHK(launch_copy16(src->xbar, dst->xbar, n * sizeof(float), s));
+  HIPCHK(launch_copy16(src->d1, dst->d1, n * sizeof(float), s));
+  HIPCHK(launch_copy16(src->mprev, dst->mprev, n * sizeof(float), s));
+  HIPCHK(launch_cast_op(dst->xe, n, dst->xe_op, dst->prec, s));
+  HIPCHK(launch_fill_i32(dst->step_dev, src->next_step - 1, s));
+  dst->next_step = src->next_step;
+  src->next_step = -1;
+  return 0;
+}
+
+int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* stream) {
+  if (ns2vc_sampler_begin(h, x_inout_bct, stream)) return 1;
+  if (ns2vc_sampler_steps(h, h->steps, use_graph, stream)) return 1;
+  return ns2vc_sampler_end(h, x_inout_bct, stream);
 }
 
 int ns2vc_unet_num_taps(ns2vc_unet* h) { return h ? (int)h->taps.size() : 0; }

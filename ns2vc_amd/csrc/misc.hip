@@ -548,6 +548,8 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
   }
 }
 __global__ void fill_i32_kernel(int* p, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *p = v; }
+// read-and-reset of a device maximum (LayerNorm health, ns2vc_unet_ln_ratio*): stream-ordered with the launches that raise it
+__global__ void snapshot_u32_kernel(unsigned* src, unsigned* dst) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = atomicExch(src, 0u); }
 
 // ---------------------------------------------------------------------------
 // launchers
@@ -730,6 +732,10 @@ hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s
 }
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s) {
   hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, p, v);
+  return hipGetLastError();
+}
+hipError_t launch_snapshot_u32(unsigned* src, unsigned* dst, hipStream_t s) {
+  hipLaunchKernelGGL(snapshot_u32_kernel, dim3(1), dim3(64), 0, s, src, dst);
   return hipGetLastError();
 }
 

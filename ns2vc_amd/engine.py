@@ -228,12 +228,23 @@ class Engine:
         check(self.lib.ns2vc_unet_set_option(self.h, name.encode(), int(value)), f"set_option({name})")
         self.shape = None
 
-    def ln_ratio(self) -> float:
-        """max |mean| / std over all LayerNorm input rows since the last call (synchronises).  The 16-bit modes' error on a
-        LayerNorm row grows with it under the default "ln_linear" plan; see ``Denoiser`` for the automatic guard."""
+    def ln_ratio(self, stream=None) -> float:
+        """max |mean| / std over all LayerNorm input rows since the last read-out.  The read-and-reset is enqueued on
+        ``stream`` (pass the stream the evaluations ran on) and only THAT stream is synchronised.  The 16-bit modes' error
+        on a LayerNorm row grows with it under the default "ln_linear" plan; see ``Denoiser`` for the automatic guard."""
         r = C.c_float()
-        check(self.lib.ns2vc_unet_ln_ratio(self.h, C.byref(r)), "ln_ratio")
+        check(self.lib.ns2vc_unet_ln_ratio(self.h, C.byref(r), _stream_ptr(stream)), "ln_ratio")
         return float(r.value)
+
+    def ln_ratio_post(self, stream=None) -> None:
+        """enqueue the read-and-reset on ``stream`` without waiting; collect it with ``ln_ratio_poll``"""
+        check(self.lib.ns2vc_unet_ln_ratio_post(self.h, _stream_ptr(stream)), "ln_ratio_post")
+
+    def ln_ratio_poll(self) -> Optional[float]:
+        """value of the last ``ln_ratio_post`` if it has completed (non-blocking), else None"""
+        r, ok = C.c_float(), C.c_int()
+        check(self.lib.ns2vc_unet_ln_ratio_poll(self.h, C.byref(r), C.byref(ok)), "ln_ratio_poll")
+        return float(r.value) if ok.value else None
 
     def prepare(self, B: int, T: int, Lp: int) -> None:
         check(self.lib.ns2vc_unet_prepare(self.h, B, T, Lp), "ns2vc_unet_prepare")
@@ -278,9 +289,26 @@ class Engine:
         self.table = table
         return table
 
-    def sample(self, x_inout, use_graph: bool = True, stream=None) -> None:
-        """x_inout (B,100,T): x_T in, sample out (in place).  NFE == steps of the loaded table."""
-        check(self.lib.ns2vc_sampler_run(self.h, _ptr(x_inout), int(use_graph), _stream_ptr(stream)), "sampler_run")
+    def sample(self, x_inout, use_graph: bool = True, stream=None, tail: Optional["Engine"] = None, tail_steps: int = 0) -> None:
+        """x_inout (B,100,T): x_T in, sample out (in place).  NFE == steps of the loaded table.
+
+        ``tail`` / ``tail_steps``: mixed precision -- this engine runs the first ``steps - tail_steps`` evaluations, then the
+        solver state is handed to ``tail`` (normally an fp32 engine prepared for the same shape, condition and table),
+        which runs the last ``tail_steps``.  The error of a sampled latent is dominated by the last evaluations
+        (DPM-Solver++(2M)'s final second-order update extrapolates over a large log-SNR step, dpm_solver.py:796-831):
+        two fp32 evaluations at the end take a 50-step fp16 loop from 1.7e-3 to ~2e-4 of the reference."""
+        if tail is None or tail_steps <= 0:
+            check(self.lib.ns2vc_sampler_run(self.h, _ptr(x_inout), int(use_graph), _stream_ptr(stream)), "sampler_run")
+            return
+        if self.table is None or tail.table is None or tail.table.steps != self.table.steps:
+            raise Ns2vcError("mixed-precision sampling: both engines need the same solver table loaded")
+        n, k = self.table.steps, min(int(tail_steps), self.table.steps)
+        sp = _stream_ptr(stream)
+        check(self.lib.ns2vc_sampler_begin(self.h, _ptr(x_inout), sp), "sampler_begin")
+        check(self.lib.ns2vc_sampler_steps(self.h, n - k, int(use_graph), sp), "sampler_steps")
+        check(self.lib.ns2vc_sampler_handoff(tail.h, self.h, sp), "sampler_handoff")
+        check(self.lib.ns2vc_sampler_steps(tail.h, k, int(use_graph), sp), "sampler_steps(tail)")
+        check(self.lib.ns2vc_sampler_end(tail.h, _ptr(x_inout), sp), "sampler_end")
 
     # -- profiling --------------------------------------------------------------------
     def op_info(self, which: int = 0) -> List[Tuple[str, int, float, float]]:

@@ -18,41 +18,93 @@ from .schedule import linear_betas
 from .spec import UNetConfig
 
 
+# default number of trailing fp32 evaluations of a 16-bit sampling loop, per solver (``Denoiser(tail_fp32=None)``):
+# DPM-Solver++(2M) takes its LAST update at second order over the largest log-SNR step of the schedule (no lower_order_final
+# for steps >= 10, dpm_solver.py:1198-1201), which amplifies the rounding noise of the last two evaluations ~2.7x (50 steps:
+# fp16 1.7e-3 on the sampled latent, with the last two evaluations in fp32 ~2e-4); UniPC-bh2 ends at first order and keeps
+# the single-evaluation noise (8.6e-4 at 20 steps), so it stays pure 16-bit unless asked.
+DEFAULT_TAIL_FP32 = {"dpmsolver++": 2, "unipc": 0}
+# LayerNorm-by-linearity guard thresholds on max |mean|/std (see Denoiser): 16-bit modes lose ~ratio * 2^-11 on a row,
+# fp32 loses ~ratio^2 * 2^-24 in the variance E[x^2] - mean^2
+LN_GUARD_DEFAULT = {"fp16": 8.0, "bf16": 8.0, "fp32": 32.0}
+
+
 class Denoiser:
     """``precision``: "fp16" (default: 16-bit MFMA operands, 8e-4 vs the reference fp32 path -- inside the 1e-3 parity
     bar), "fp32" (exact-fp32 MFMA, 1e-6) or "bf16" (same speed as fp16, 6.5e-3; kept for range-critical checkpoints).
 
+    ``tail_fp32``: evaluations at the END of every sampling loop that run on a second, fp32 engine (the solver state is
+    handed over on the device, ``Engine.sample(tail=...)``).  None = ``DEFAULT_TAIL_FP32[solver]`` for the 16-bit
+    precisions (2 for DPM-Solver++, 0 for UniPC), 0 = never.  The fp32 engine (weights + workspace) is built on first use.
+
     ``ln_guard``: LayerNorm by linearity (the default plan) lets the 16-bit modes round a LayerNorm's RAW input before
-    centring, so their error on a row grows with |mean| / std of that row.  After the FIRST evaluation with a new set
-    of weights the engine's measured maximum of that ratio is read once (one host sync); above ``ln_guard`` the plan is
-    switched to explicit LayerNorm passes (``ln_linear`` 0: ~4 % slower, immune) and the evaluation is repeated.
-    ``None`` disables the check."""
+    centring, so their error on a row grows with |mean| / std of that row (and the fp32 variance E[x^2] - mean^2 with its
+    square).  The engine records the maximum of that ratio.  It is read after the FIRST evaluation with a new shape /
+    set of weights (one wait on the denoiser's stream; above the threshold the plan is switched to explicit LayerNorm
+    passes, ``ln_linear`` 0: ~4 % slower, immune, and the evaluation is repeated) and, because the ratio also depends on
+    the content, the prompt and the timestep, after EVERY later call without blocking: the read-out is enqueued behind
+    the call and collected at the start of the next one (``ln_ratio_seen`` = running maximum); a late excess switches
+    the plan for all following calls and warns that the previous result was computed above the threshold.
+    ``None`` disables the check; a float sets the threshold (default 8 for the 16-bit modes, 32 for fp32)."""
 
     def __init__(self, state: Dict[str, object], cfg: UNetConfig = UNetConfig(), precision: str = DEFAULT_PRECISION,
-                 betas: Optional[np.ndarray] = None, ln_guard: Optional[float] = 8.0):
+                 betas: Optional[np.ndarray] = None, ln_guard: Optional[float] = -1.0, tail_fp32: Optional[int] = None):
         self.cfg = cfg
+        self.precision = {"f32": "fp32", "f16": "fp16"}.get(precision, precision)
         self.engine = Engine(cfg, precision=precision)
         self.engine.load_state_dict(state)
+        self._state = state
         self.betas = linear_betas() if betas is None else np.asarray(betas, dtype=np.float32)
         self._shape = None
         self._table_key = None
-        self.ln_guard = ln_guard if precision not in ("fp32", "f32") else None
+        self.ln_guard = LN_GUARD_DEFAULT[self.precision] if (ln_guard is not None and ln_guard < 0) else ln_guard
         self.ln_ratio_seen: Optional[float] = None
         self._ln_checked = False
+        self._ln_pending = False
+        self.tail_fp32 = tail_fp32
+        self.tail_engine: Optional[Engine] = None
+        self._tail_shape = None
+        self._tail_table_key = None
 
-    def _guard(self, redo):
-        """first-call health check of the LayerNorm-by-linearity plan (see the class docstring)"""
-        if self._ln_checked or self.ln_guard is None:
-            return None
-        self._ln_checked = True
-        self.ln_ratio_seen = self.engine.ln_ratio()
-        if self.ln_ratio_seen <= self.ln_guard:
-            return None
-        warnings.warn(f"LayerNorm inputs with |mean|/std up to {self.ln_ratio_seen:.1f} (> {self.ln_guard}): switching the "
-                      f"{self.engine.precision} engine to explicit LayerNorm passes (ln_linear=0)")
+    # ---- LayerNorm-by-linearity guard ---------------------------------------------------------------------------------
+    def _note_ratio(self, r: float) -> bool:
+        self.ln_ratio_seen = r if self.ln_ratio_seen is None else max(self.ln_ratio_seen, r)
+        return self.ln_guard is not None and r > self.ln_guard
+
+    def _switch_plan(self, r: float, late: bool) -> None:
+        warnings.warn(f"LayerNorm inputs with |mean|/std up to {r:.1f} (> {self.ln_guard}): switching the "
+                      f"{self.engine.precision} engine to explicit LayerNorm passes (ln_linear=0)" +
+                      ("; the PREVIOUS result was computed above the threshold" if late else ""))
         self.engine.set_option("ln_linear", False)
         self._shape = None
-        return redo()
+        self._ln_checked = True          # the explicit plan does not depend on the ratio
+        self.ln_guard = None
+
+    def _guard_before(self) -> None:
+        """collect the read-out enqueued behind the previous call (non-blocking)"""
+        if self.ln_guard is None or not self._ln_pending:
+            return
+        r = self.engine.ln_ratio_poll()
+        if r is None:
+            return
+        self._ln_pending = False
+        if self._note_ratio(r):
+            self._switch_plan(r, late=True)
+
+    def _guard_after(self, stream, redo):
+        if self.ln_guard is None:
+            return None
+        if not self._ln_checked:         # first call on this plan: wait for the value, repeat the call if it is too large
+            self._ln_checked = True
+            r = self.engine.ln_ratio(stream)
+            if self._note_ratio(r):
+                self._switch_plan(r, late=False)
+                return redo()
+            return None
+        if not self._ln_pending:         # later calls: enqueue, collect next time
+            self.engine.ln_ratio_post(stream)
+            self._ln_pending = True
+        return None
 
     def _prepare(self, B: int, T: int, Lp: int) -> None:
         if self._shape != (B, T, Lp):
@@ -60,6 +112,8 @@ class Denoiser:
             torch.cuda.synchronize()
             self.engine.prepare(B, T, Lp)
             self._shape = (B, T, Lp)
+            self._ln_checked = False                # a new shape is a new set of rows: check synchronously once
+            self._ln_pending = False
 
     def _table(self, solver: str, steps: int, order: int) -> None:
         key = (solver, steps, order)
@@ -67,36 +121,66 @@ class Denoiser:
             self.engine.load_sampler(solver, steps, self.betas, order)
             self._table_key = key
 
+    def _tail(self, solver: str, steps: int, order: int, n_tail: int) -> Optional[Engine]:
+        """the fp32 engine that finishes a 16-bit loop, prepared for the current shape and table"""
+        if n_tail <= 0 or self.precision == "fp32":
+            return None
+        if self.tail_engine is None:
+            self.tail_engine = Engine(self.cfg, precision="fp32")
+            self.tail_engine.load_state_dict(self._state)
+        if self._tail_shape != self._shape:
+            import torch
+            torch.cuda.synchronize()
+            self.tail_engine.prepare(*self._shape)
+            self._tail_shape = self._shape
+        key = (solver, steps, order)
+        if self._tail_table_key != key:
+            self.tail_engine.load_sampler(solver, steps, self.betas, order)
+            self._tail_table_key = key
+        return self.tail_engine
+
     def denoise(self, x, t, content, prompt, prompt_mask=None):
         """One evaluation: x (B,100,T), t (B,), content (B,256,T), prompt (B,Lp,256), mask (B,Lp) bool -> x0_pred."""
         import torch
         B, _, T = x.shape
+        self._guard_before()
         self._prepare(B, T, prompt.shape[1])
         s = torch.cuda.current_stream(x.device)
         mask = None if prompt_mask is None else prompt_mask.to(torch.uint8).contiguous()
         self.engine.set_condition(content.float().contiguous(), prompt.float().contiguous(), mask, stream=s)
         out = torch.empty_like(x, dtype=torch.float32)
         self.engine.forward(x.float().contiguous(), t.float().contiguous(), out, stream=s)
-        redone = self._guard(lambda: self.denoise(x, t, content, prompt, prompt_mask))
+        redone = self._guard_after(s, lambda: self.denoise(x, t, content, prompt, prompt_mask))
         return out if redone is None else redone
 
     def sample(self, content, prompt, prompt_mask=None, noise=None, solver: str = "unipc", steps: int = 20, order: int = 2,
-               use_graph: bool = True, generator=None):
+               use_graph: bool = True, generator=None, tail_fp32: Optional[int] = None):
         """content (B,256,T), prompt (B,Lp,256), mask (B,Lp) bool; ``noise`` (B,100,T) = x_T (drawn with
-        torch.randn like model.py:635 if None).  Returns the sampled latent (B,100,T) fp32."""
+        torch.randn like model.py:635 if None).  Returns the sampled latent (B,100,T) fp32.
+        ``tail_fp32`` overrides the instance's setting for this call (see the class docstring)."""
         import torch
         B, _, T = content.shape
         dev = content.device
+        self._guard_before()
         self._prepare(B, T, prompt.shape[1])
         self._table(solver, steps, order)
+        n_tail = tail_fp32 if tail_fp32 is not None else self.tail_fp32
+        if n_tail is None:
+            n_tail = DEFAULT_TAIL_FP32.get(solver, 0) if self.precision != "fp32" else 0
+        n_tail = max(0, min(int(n_tail), steps))
+        tail = self._tail(solver, steps, order, n_tail)
         if noise is None:
             noise = torch.randn((B, self.cfg.latent_channels, T), device=dev, generator=generator)
         x = noise.to(device=dev, dtype=torch.float32).contiguous().clone()
         s = torch.cuda.current_stream(dev)
         mask = None if prompt_mask is None else prompt_mask.to(device=dev, dtype=torch.uint8).contiguous()
-        self.engine.set_condition(content.float().contiguous(), prompt.float().contiguous(), mask, stream=s)
-        self.engine.sample(x, use_graph=use_graph, stream=s)
-        redone = self._guard(lambda: self.sample(content, prompt, prompt_mask, noise, solver, steps, order, use_graph))
+        c32, p32 = content.float().contiguous(), prompt.float().contiguous()
+        self.engine.set_condition(c32, p32, mask, stream=s)
+        if tail is not None:
+            tail.set_condition(c32, p32, mask, stream=s)
+        self.engine.sample(x, use_graph=use_graph, stream=s, tail=tail, tail_steps=n_tail if tail is not None else 0)
+        redone = self._guard_after(s, lambda: self.sample(content, prompt, prompt_mask, noise, solver, steps, order, use_graph,
+                                                          tail_fp32=tail_fp32))
         return x if redone is None else redone
 
     def sample_sharded(self, content, prompt, prompt_mask, noise, **kw):

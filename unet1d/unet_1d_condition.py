@@ -8,11 +8,14 @@ Boundary kept:
   * ``forward(sample, timestep, encoder_hidden_states, ..., encoder_attention_mask=,
     return_dict=)`` -> object with ``.sample`` (``:743-757, 1034-1037``).
 
-The inference forward is NOT PyTorch: it hands device pointers to libns2vc_hip.so;
-without a GPU / with CPU tensors it raises (there is no CPU inference path).  TRAINING
-(autograd recording: ``model.py:720`` under ``Trainer.train``) is the one case routed to
-plain PyTorch ops (``unet1d/torch_path.py``) so that ``train.py`` stays drop-in; the
-counters ``engine_calls`` / ``autograd_calls`` tell which path ran.  The fast path for sampling
+The inference forward on GPU tensors is NOT PyTorch: it hands device pointers to
+libns2vc_hip.so (a missing library is an error, never a silent fallback).  Two cases are
+routed to plain PyTorch ops on this module's own parameters (``unet1d/torch_path.py``,
+product code, never ``oracle/``): TRAINING (autograd recording: ``model.py:720`` under
+``Trainer.train``), so that ``train.py`` stays drop-in, and inference on CPU tensors
+(``infer.py --device cpu``, BASELINE config 1 "plumbing, no GPU"), which warns once that
+it is the slow path.  The counters ``engine_calls`` / ``autograd_calls`` / ``cpu_calls``
+tell which path ran.  The fast path for sampling
 is ``ns2vc_amd.pipeline.Denoiser`` (captured loop, condition hoisted once).  Here the
 reference API concatenates x and content into a NEW ``sample`` tensor on every solver
 step (``model.py:409``), so the content half of conv_in is redone per call, but the
@@ -27,6 +30,7 @@ default fp32, the reference's arithmetic).
 from __future__ import annotations
 
 import os
+import warnings
 from dataclasses import dataclass
 from typing import Any, Dict, Optional, Tuple, Union
 
@@ -101,27 +105,48 @@ class UNet1DConditionModel(nn.Module):
         self._engine = None
         self._engine_key = None
         self._engine_shape = None
-        self._plist = None              # flat parameter list (the key walk is per call: keep it a list comprehension)
         self._prompt_key = None         # ((data_ptr, _version, shape) of prompt and mask) the engine's prompt half was built from
         self._prompt_hold = None        # ... and the tensors themselves: while they live their storage cannot be re-used
         self.prompt_hoists = 0          # how often the prompt half of the condition was (re)computed: tests / diagnostics
         self.engine_calls = 0           # forwards served by the HIP engine (inference)
         self.autograd_calls = 0         # forwards served by unet1d/torch_path.py (training: autograd was recording)
+        self.cpu_calls = 0              # no_grad forwards on CPU tensors, served by unet1d/torch_path.py (plumbing path)
         self._torch_path = None
+        self._warned = set()
+        # LayerNorm-by-linearity guard of the engine (ns2vc_amd.pipeline.Denoiser has the same one): threshold on the
+        # engine's measured max |mean|/std of the LayerNorm rows; None disables.  Checked on the first call of a shape
+        # (one wait on the current stream; above it the plan switches to explicit LayerNorm passes and the call is
+        # redone), afterwards without blocking (enqueued behind a call, collected at the next one).
+        self.ln_guard: Optional[float] = 32.0 if self.engine_precision in ("fp32", "f32") else 8.0
+        self.ln_ratio_seen: Optional[float] = None
+        self._ln_checked = False
+        self._ln_pending = False
 
     # ---------------------------------------------------------------------------------
     def _weights_key(self):
-        if self._plist is None or len(self._plist) != len(self._parameters_flat()):
-            self._plist = self._parameters_flat()
-        return (self.engine_precision, tuple([(p.data_ptr(), p._version) for p in self._plist]))
-
-    def _parameters_flat(self):
-        return list(self.parameters())
+        # walks the live parameters on every call (4.13 vs 3.97 ms per call measured: tools/dropin_overhead.py): a rebound
+        # parameter (m.conv_in.weight = nn.Parameter(...), parametrize, weight_norm) changes data_ptr, an in-place update
+        # (optimizer step, .copy_) changes _version -- either reloads the engine's packed weights
+        return (self.engine_precision, tuple([(p.data_ptr(), p._version) for p in self.parameters()]))
 
     def _apply(self, fn, *a, **kw):      # .to() / .cuda() / .half() may replace parameter storage
-        self._plist = None
         self._prompt_key = self._prompt_hold = None
         return super()._apply(fn, *a, **kw)
+
+    def _warn_once(self, tag: str, msg: str) -> None:
+        if tag not in self._warned:
+            self._warned.add(tag)
+            warnings.warn(msg)
+
+    def _run_torch_path(self, sample, timestep, encoder_hidden_states, encoder_attention_mask):
+        if self._torch_path is None:
+            from .torch_path import TorchDenoiser
+            self._torch_path = TorchDenoiser(self, self.cfg)
+        Bq = sample.shape[0]
+        tt = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)], device=sample.device)
+        tt = tt.to(sample.device).reshape(-1).expand(Bq)
+        mask_b = None if encoder_attention_mask is None else encoder_attention_mask.to(sample.device).reshape(Bq, -1).bool()
+        return self._torch_path(sample, tt, encoder_hidden_states, mask_b)
 
     def _get_engine(self):
         from ns2vc_amd.engine import Engine
@@ -133,7 +158,40 @@ class UNet1DConditionModel(nn.Module):
             self._engine_key = key
             self._engine_shape = None
             self._prompt_key = self._prompt_hold = None
+            self._ln_checked = self._ln_pending = False
         return self._engine
+
+    # ---- LayerNorm-by-linearity guard (same policy as ns2vc_amd.pipeline.Denoiser) ------------------------------------
+    def _ln_excess(self, eng, r: float, late: bool) -> bool:
+        self.ln_ratio_seen = r if self.ln_ratio_seen is None else max(self.ln_ratio_seen, r)
+        if self.ln_guard is None or r <= self.ln_guard:
+            return False
+        warnings.warn(f"LayerNorm inputs with |mean|/std up to {r:.1f} (> {self.ln_guard}): switching the {eng.precision} engine to "
+                      f"explicit LayerNorm passes (ln_linear=0)" + ("; the PREVIOUS result was computed above the threshold" if late else ""))
+        eng.set_option("ln_linear", False)
+        self._engine_shape = None
+        self._prompt_key = self._prompt_hold = None
+        self.ln_guard = None
+        return True
+
+    def _ln_guard_before(self, eng) -> None:
+        if self.ln_guard is None or not self._ln_pending:
+            return
+        r = eng.ln_ratio_poll()
+        if r is not None:
+            self._ln_pending = False
+            self._ln_excess(eng, r, late=True)
+
+    def _ln_guard_after(self, eng, stream) -> bool:
+        if self.ln_guard is None:
+            return False
+        if not self._ln_checked:
+            self._ln_checked = True
+            return self._ln_excess(eng, eng.ln_ratio(stream), late=False)
+        if not self._ln_pending:
+            eng.ln_ratio_post(stream)
+            self._ln_pending = True
+        return False
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], encoder_hidden_states: torch.Tensor,
                 class_labels=None, timestep_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
@@ -148,19 +206,20 @@ class UNet1DConditionModel(nn.Module):
         if torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in self.parameters())):
             # TRAINING: autograd is recording (model.py:720).  Plain PyTorch ops on this module's parameters; never taken
             # under torch.no_grad(), i.e. never by NaturalSpeech2.sample / Svc.infer / the benchmarks.
-            if self._torch_path is None:
-                from .torch_path import TorchDenoiser
-                self._torch_path = TorchDenoiser(self, cfg)
-            Bq = sample.shape[0]
-            tt = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)], device=sample.device)
-            tt = tt.to(sample.device).reshape(-1).expand(Bq)
-            mask_b = None if encoder_attention_mask is None else encoder_attention_mask.to(sample.device).reshape(Bq, -1).bool()
-            out = self._torch_path(sample, tt, encoder_hidden_states, mask_b)
+            if not self.training:        # an eval / benchmark call that forgot torch.no_grad() would silently miss the engine
+                self._warn_once("autograd-eval", "UNet1DConditionModel: autograd is recording while the module is in eval() mode -- this call runs "
+                                "the PyTorch training path (unet1d/torch_path.py), not the HIP engine; wrap inference in torch.no_grad()")
+            out = self._run_torch_path(sample, timestep, encoder_hidden_states, encoder_attention_mask)
             self.autograd_calls += 1
             return UNet1DConditionOutput(sample=out) if return_dict else (out,)
         if not sample.is_cuda:
-            raise RuntimeError("UNet1DConditionModel (HIP engine) needs CUDA/ROCm tensors for inference: there is no CPU inference path "
-                               "(autograd / training calls use PyTorch ops: unet1d/torch_path.py)")
+            # BASELINE config 1 / `infer.py --device cpu` (inference/infer_tool.py:119-135): plumbing on the host through the
+            # module's own PyTorch forward (product code, the same one training uses; never oracle/).  Slow by construction.
+            self._warn_once("cpu", "UNet1DConditionModel: CPU tensors -- running the PyTorch path (unet1d/torch_path.py), NOT the HIP engine; "
+                            "this is the slow plumbing path (move the module and its inputs to a ROCm device for the engine)")
+            out = self._run_torch_path(sample.float(), timestep, encoder_hidden_states.float(), encoder_attention_mask).to(sample.dtype)
+            self.cpu_calls += 1
+            return UNet1DConditionOutput(sample=out) if return_dict else (out,)
         B, Cin, T = sample.shape
         if Cin != cfg.in_channels:
             raise RuntimeError(f"expected {cfg.in_channels} input channels, got {Cin}")
@@ -180,17 +239,22 @@ class UNet1DConditionModel(nn.Module):
             mask = encoder_attention_mask.to(device=dev).reshape(B, Lp).to(torch.uint8).contiguous()
         with torch.cuda.device(dev):     # engine creation / weights / workspace / launches all bind to the tensors' device
             eng = self._get_engine()
+            self._ln_guard_before(eng)           # (may drop the plan: before the shape check)
             if self._engine_shape != (B, T, Lp):
                 torch.cuda.synchronize(dev)
                 eng.prepare(B, T, Lp)
                 self._engine_shape = (B, T, Lp)
                 self._prompt_key = self._prompt_hold = None
+                self._ln_checked = self._ln_pending = False
             out = torch.empty((B, cfg.out_channels, T), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev)
 
             ehs = encoder_hidden_states
-            pkey = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), tuple(ehs.stride()), ehs.dtype, stream.cuda_stream)
-            if pkey != self._prompt_key:
+            # Inference tensors (torch.inference_mode()) carry no version counter: they cannot be keyed, so the prompt half is
+            # re-hoisted on every call.  (In-place edits made through `.data` do not bump _version either: callers that
+            # rewrite a prompt that way must pass a new tensor.)
+            pkey = None if ehs.is_inference() else (ehs.data_ptr(), ehs._version, tuple(ehs.shape), tuple(ehs.stride()), ehs.dtype, stream.cuda_stream)
+            if pkey is None or pkey != self._prompt_key:
                 eng.set_prompt(prompt, mask, stream=stream)
                 self._prompt_key = pkey
                 self._prompt_hold = ehs          # alive => its address cannot be handed to another tensor while it is the key
@@ -200,6 +264,8 @@ class UNet1DConditionModel(nn.Module):
             eng.set_content(content, stream=stream)
             eng.forward(x, ts, out, stream=stream)
             self.engine_calls += 1
+            if self._ln_guard_after(eng, stream):      # first call of this plan found LayerNorm rows above the threshold: redo on the explicit plan
+                return self.forward(sample, timestep, encoder_hidden_states, encoder_attention_mask=encoder_attention_mask, return_dict=return_dict)
         out = out.to(sample.dtype)
         if not return_dict:
             return (out,)
