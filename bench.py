@@ -21,9 +21,13 @@ or plainly as `python bench.py --gpus N` -- then this process spawns the N ranks
 (127.0.0.1 rendezvous) and fails loudly if fewer than N devices are visible.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
-  roofline      dominant kernel family (implicit GEMM) vs the dense MFMA peak, timed live with HIP events
-  parity        rel-L2 of the timed precision's predicted latent vs the oracle AT THE BENCH SHAPE (B=32)
+  roofline      dominant kernel family (implicit GEMM: gemm4 + fused feed-forward + row chains) vs the dense MFMA peak;
+                `achieved` = the family's share of the TIMED loop, `isolated` = its launches timed back to back with HIP events
+  parity        rel-L2 of the timed precision's predicted latent vs the oracle AT THE BENCH SHAPE (B=32), and
+                `sampled_latent`: the timed solver's output (captured loop, B=32) vs oracle.sampler_ref on the first utterances
   fp32_parity_mode   the same job and roofline in the exact-fp32 precision
+  other_configs BASELINE configs 2 and 5 (default and --attn-fp8) timed the same way, with parity against the fp32 engine
+  strong_scaling     BASELINE config 4's global batch (256) split over the N ranks
   cpu_baseline  the oracle on the host cores: all cores (P processes x T threads) and one process, at B=32
 """
 from __future__ import annotations
@@ -64,6 +68,11 @@ def parse():
                     "costs parity, see DESIGN.md section 4)")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-baseline / parity legs")
     ap.add_argument("--skip-fp32", action="store_true", help="skip the fp32_parity_mode block")
+    ap.add_argument("--skip-others", action="store_true", help="skip the other_configs block (BASELINE configs 2 and 5)")
+    ap.add_argument("--skip-strong", action="store_true", help="skip the strong_scaling block (global batch 256 split over the ranks)")
+    ap.add_argument("--tail-fp32", type=int, default=0, help="last evaluations of the timed loop on a second, fp32 engine (mixed precision; "
+                    "0 = the headline's pure 16-bit loop)")
+    ap.add_argument("--strong-batch", type=int, default=256, help="global batch of the strong_scaling block (BASELINE config 4: 256)")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the baseline legs")
     ap.add_argument("--ops", default="", help="write the per-launch table (name, kind, ms, GFLOP, MB) to this file")
     ap.add_argument("--detail", action="store_true", help="print the per-kernel-family table to stderr")
@@ -119,9 +128,11 @@ def cpu_worker(seconds: float, threads: int, T: int, Lp: int, B: int = 4):
     print(json.dumps({"samples": n, "seconds": time.perf_counter() - t0}), flush=True)
 
 
-def cpu_baseline(T: int, Lp: int, B: int, budget_s: float):
+def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
     """(1) one process at the bench batch (thread count = best of a short probe), whose output is also the parity
-    reference; (2) all cores: P processes x that thread count, started together, samples/s summed."""
+    reference; (2) all cores: P processes x that thread count, started together, samples/s summed; (3) `sampler` =
+    (solver, steps, items): oracle.sampler_ref on the first `items` utterances of the same inputs = the reference of
+    parity.sampled_latent."""
     import torch
     from oracle import unet_ref
     cores = _host_cores()
@@ -177,13 +188,29 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float):
                     pass
     use = agg if agg and "sample_steps_per_s" in agg and agg["sample_steps_per_s"] > single["sample_steps_per_s"] else single
     used_cores = nproc * th if use is agg else th
+    # ---- the sampled latent of the timed solver on the first utterances (the oracle treats utterances independently)
+    samp = None
+    if sampler is not None:
+        from oracle import sampler_ref
+        solver, steps, nb = sampler
+        nb = max(1, min(nb, B))
+        torch.set_num_threads(th)
+        tc, tp, tm = content[:nb], prompt[:nb], mask[:nb]
+
+        def x0(xx, tt):
+            return unet_ref.denoiser(P, cfg, xx, tc, tp, tm, tt)
+        t0 = time.perf_counter()
+        betas = sampler_ref.linear_betas(1000)
+        ys = (sampler_ref.unipc_bh2(x0, betas, x[:nb].clone(), steps) if solver == "unipc" else
+              sampler_ref.dpm_solver_pp_2m(x0, betas, x[:nb].clone(), steps, 2 if steps >= 2 else 1))
+        samp = {"y": ys.numpy(), "items": nb, "seconds": time.perf_counter() - t0}
     out = {"value": use["sample_steps_per_s"] / B, "unit": f"denoiser-steps/s (batch {B})", "cores": used_cores, "host_cores": cores, "kind": "port",
            "sample_steps_per_s": use["sample_steps_per_s"],
            "sample": (f"oracle UNet forward (torch CPU fp32) at T={T}, Lp={Lp}: " +
                       (f"{nproc} processes x {th} threads x batch 4 for {agg['seconds']:.0f} s, samples/s summed" if use is agg else
                        f"one process, {th} threads, batch {B}, {n1} forwards in {dt:.1f} s")),
            "single_process": single, "all_cores": agg}
-    return out, (x.numpy(), content.numpy(), prompt.numpy(), mask.numpy(), t_par.numpy(), y_ref.numpy())
+    return out, (x.numpy(), content.numpy(), prompt.numpy(), mask.numpy(), t_par.numpy(), y_ref.numpy()), samp
 
 
 # ------------------------------------------------------------------------------------------------
@@ -230,15 +257,28 @@ def family_table(eng, stream, ops_path=""):
 
 
 def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
+    """Dominant kernel family = implicit GEMM (gemm4_kernel + the fused feed-forward ffn_kernel + rowchain_kernel).
+    `achieved` is what the family reaches INSIDE the timed loop: its algorithmic FLOP / (step time x the family's share of the
+    step), the share taken from the per-launch HIP-event timings (rocprofv3 cannot run inside bench.py; its kernel-trace
+    figure for the same command is stamped as `rocprof` when profiles/ holds one for this shape and precision).  `isolated`
+    is the same family with every launch repeated 8x back to back between one event pair (L2-warm, no neighbours): an upper
+    bound on the kernels themselves, ~8 % above the in-loop figure."""
     peak = MFMA_PEAK_TFLOPS[precision]
     g = fam.get("implicit_gemm", {"launches": 1, "ms": 1.0, "flops": 0.0, "bytes": 0.0})
-    gemm_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-    # HBM bytes per launch of the same family: rocprofv3 --pmc cannot run inside bench.py, so they come from the committed PMC
-    # passes of this very command (profiles/rNN_pmc_hbm_traffic.json: FETCH_SIZE x2-corrected + WRITE_SIZE), stamped with the
-    # commit they were measured at; only quoted for the workload / precision they were measured on
-    traffic = traffic_src = traffic_commit = None
+    iso_tflops = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
+    total_iso_ms = sum(v["ms"] for v in fam.values())
+    share = g["ms"] / total_iso_ms if total_iso_ms > 0 else 0.0
+    loop_ms = step_ms * share
+    gemm_tflops = g["flops"] / (loop_ms * 1e-3) / 1e12 if loop_ms > 0 else 0.0
+    # HBM bytes per launch of the same family and the rocprofv3 kernel-trace time of the family: rocprofv3 cannot run inside
+    # bench.py, so both come from the committed passes of this very command (profiles/rNN_pmc_hbm_traffic.json: FETCH_SIZE
+    # x2-corrected + WRITE_SIZE; profiles/rNN_family_times.json), stamped with the commit they were measured at and quoted
+    # only for the workload / precision they were measured on
+    traffic = traffic_src = traffic_commit = traffic_cmd = None
+    rocprof = None
     pdir = os.path.join(ROOT, "profiles")
-    for fn in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_hbm_traffic.json")), reverse=True) if os.path.isdir(pdir) else []:
+    names = sorted(os.listdir(pdir), reverse=True) if os.path.isdir(pdir) else []
+    for fn in (f for f in names if f.endswith("_pmc_hbm_traffic.json")):
         try:
             with open(os.path.join(pdir, fn)) as fh:
                 tj = json.load(fh)
@@ -248,20 +288,39 @@ def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
             traffic = tj["families"]["implicit_gemm"]["hbm_mb_per_launch"] * 1e6
             traffic_src = f"profiles/{fn} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bytes per launch)"
             traffic_commit = tj.get("commit")
+            traffic_cmd = tj.get("source")
+            break
+    for fn in (f for f in names if f.endswith("_family_times.json")):
+        try:
+            with open(os.path.join(pdir, fn)) as fh:
+                fj = json.load(fh)
+        except Exception:
+            continue
+        if fj.get("precision") == precision and tuple(fj.get("shape", ())) == tuple(shape) and fj.get("families", {}).get("implicit_gemm"):
+            fm = fj["families"]["implicit_gemm"]["ms_per_step"]
+            rocprof = {"family_ms_per_step": fm, "tflops": g["flops"] / (fm * 1e-3) / 1e12 if fm > 0 else 0.0,
+                       "frac": (g["flops"] / (fm * 1e-3) / 1e12 / peak) if fm > 0 else 0.0, "step_ms_under_rocprof": fj.get("step_ms"),
+                       "source": f"profiles/{fn}", "command": fj.get("source"), "measured_at": fj.get("commit")}
             break
     return {
-        "bound": "mfma", "kernel": "gemm4_kernel / gemm2_kernel (implicit GEMM: conv1d k3/k1 + linear)",
-        "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": traffic,
-        "traffic_source": traffic_src, "traffic_measured_at": traffic_commit,
+        "bound": "mfma", "kernel": "implicit-GEMM family: gemm4_kernel (conv1d k3/k1 + linear) + ffn_kernel (fused feed-forward) + rowchain_kernel (token-local linear chains)",
+        "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
+        "achieved_method": "family FLOP / (timed ms_per_step x the family's share of the per-launch HIP-event times)",
+        "family_share_of_step": share, "family_ms_in_loop": loop_ms,
+        "isolated": {"tflops": iso_tflops, "frac": iso_tflops / peak, "ms_per_step": g["ms"],
+                     "method": "every launch 8x back to back between one HIP event pair on the launch stream (L2-warm)"},
+        "rocprof": rocprof,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_command": traffic_cmd, "traffic_measured_at": traffic_commit,
         "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
-        "launches_per_step": g["launches"], "avg_launch_us": g["ms"] * 1e3 / max(g["launches"], 1),
+        "launches_per_step": g["launches"], "avg_launch_us": loop_ms * 1e3 / max(g["launches"], 1),
         "algorithmic_gflop_per_launch": g["flops"] / 1e9 / max(g["launches"], 1),
-        "algorithmic_hbm_gbs": g["bytes"] / (g["ms"] * 1e-3) / 1e9 if g["ms"] > 0 else 0.0,
+        "algorithmic_hbm_gbs": g["bytes"] / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0,
         "whole_step": {"algorithmic_tflop_per_step": gflop_sample * B / 1e3, "ms_per_step": step_ms,
                        "achieved_tflops": gflop_sample * B / 1e3 / (step_ms * 1e-3), "frac_of_mfma_peak": gflop_sample * B / 1e3 / (step_ms * 1e-3) / peak},
-        "families": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 4),
-                         "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
-                         "algorithmic_gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)} for k, v in fam.items()},
+        "families": {k: {"launches": v["launches"], "ms_per_step_isolated": round(v["ms"], 4),
+                         "ms_per_step_in_loop": round(step_ms * v["ms"] / total_iso_ms, 4) if total_iso_ms > 0 else None,
+                         "tflops_isolated": (v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0),
+                         "algorithmic_gbs_isolated": (v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0)} for k, v in fam.items()},
     }
 
 
@@ -306,19 +365,20 @@ def main():
     use_graph = not a.no_graph
     stream = torch.cuda.Stream(device=dev)
 
-    def build(precision):
+    def build(precision, B_=None, T_=None, solver_=None, K_=None, attn_fp8=None):
+        B_, T_, solver_, K_ = B_ or B, T_ or T, solver_ or solver, K_ or K
         eng = E.Engine(cfg, precision=precision)
-        if a.attn_fp8 and precision != "fp32":
+        if (a.attn_fp8 if attn_fp8 is None else attn_fp8) and precision != "fp32":
             eng.set_option("attn_fp8", True)
         eng.load_state_dict(W)
-        eng.prepare(B, T, Lp)
-        eng.load_sampler(solver, K, order=order)
+        eng.prepare(B_, T_, Lp)
+        eng.load_sampler(solver_, K_, order=2 if K_ >= 2 else 1)
         return eng
 
-    noise_np, content_np, prompt_np = bench_inputs(f"bench.r{rank}", B, T, Lp)
-    content, prompt, noise = (torch.from_numpy(v).to(dev) for v in (content_np, prompt_np, noise_np))
-    mask = torch.ones((B, Lp), dtype=torch.uint8, device=dev)
-    x = torch.empty_like(noise)
+    def dev_inputs(tag, B_, T_):
+        n_np, c_np, p_np = bench_inputs(tag, B_, T_, Lp)
+        c, p_, n = (torch.from_numpy(v).to(dev) for v in (c_np, p_np, n_np))
+        return {"noise": n, "content": c, "prompt": p_, "mask": torch.ones((B_, Lp), dtype=torch.uint8, device=dev), "x": torch.empty_like(n)}
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -326,16 +386,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_jobs(eng, warmup_steps, reps, with_gather):
-        """`reps` timed jobs of exactly K steps, each bracketed by barrier + synchronize; returns per-job wall seconds
-        (MAX over ranks), GPU-event ms of the last job and the all-gather seconds of the last job"""
+    def timed_jobs(eng, io, K_, warmup_steps, reps, with_gather, tail=None, tail_steps=0, n_total=None):
+        """`reps` timed jobs of exactly K_ steps, each bracketed by barrier + synchronize; returns per-job wall seconds
+        (MAX over ranks), GPU-event ms of the last job and the all-gather seconds of the last job.  With `tail`, the last
+        `tail_steps` evaluations run on that (fp32) engine: both engines' condition hoisting is inside the timed job."""
+        x = io["x"]
+
         def job():
-            x.copy_(noise)                                   # x_T
-            eng.set_condition(content, prompt, mask, stream=stream)
-            eng.sample(x, use_graph=use_graph, stream=stream)
+            x.copy_(io["noise"])                             # x_T
+            eng.set_condition(io["content"], io["prompt"], io["mask"], stream=stream)
+            if tail is not None:
+                tail.set_condition(io["content"], io["prompt"], io["mask"], stream=stream)
+            eng.sample(x, use_graph=use_graph, stream=stream, tail=tail, tail_steps=tail_steps)
         walls, gpu_ms, t_gather = [], 0.0, 0.0
         with torch.cuda.stream(stream):
-            for _ in range(max(1, math.ceil(warmup_steps / max(K, 1)))):
+            for _ in range(max(1, math.ceil(warmup_steps / max(K_, 1)))):
                 job()
             stream.synchronize()
             for _ in range(reps):
@@ -348,10 +413,10 @@ def main():
                 if with_gather:
                     stream.synchronize()
                     tg = time.perf_counter()
-                    full = gather_latents(x, B * world)
+                    full = gather_latents(x, n_total)
                     torch.cuda.synchronize(dev)
                     t_gather = time.perf_counter() - tg
-                    assert full.shape[0] == B * world
+                    assert full.shape[0] == n_total
                 stream.synchronize()
                 barrier()
                 wall = time.perf_counter() - t0
@@ -363,29 +428,58 @@ def main():
                 gpu_ms = ev0.elapsed_ms(ev1)
         return walls, gpu_ms, t_gather
 
+    def rel_l2_dev(y, ref):
+        return float((y.double() - ref.double()).norm() / ref.double().norm())
+
+    io = dev_inputs(f"bench.r{rank}", B, T)
+    x = io["x"]
     eng = build(a.precision)
+    tail_eng = build("fp32") if (a.tail_fp32 > 0 and a.precision != "fp32") else None
     launches, workspace_gb = eng.launches()[0], eng.workspace_bytes() / 1e9
     reps = max(1, a.reps)
-    walls, gpu_ms, t_gather = timed_jobs(eng, a.warmup, reps, world > 1)
+    walls, gpu_ms, t_gather = timed_jobs(eng, io, K, a.warmup, reps, world > 1, tail_eng, a.tail_fp32, B * world)
     wall = statistics.median(walls)
     finite = bool(torch.isfinite(x).all().item())
+    x_timed = x.clone()
     # the timed (captured-graph) loop must return exactly what the same loop launched eagerly returns
     loop_check = None
     if use_graph:
         with torch.cuda.stream(stream):
-            x_graph = x.clone()
-            x.copy_(noise)
-            eng.set_condition(content, prompt, mask, stream=stream)
-            eng.sample(x, use_graph=False, stream=stream)
+            x.copy_(io["noise"])
+            eng.set_condition(io["content"], io["prompt"], io["mask"], stream=stream)
+            if tail_eng is not None:
+                tail_eng.set_condition(io["content"], io["prompt"], io["mask"], stream=stream)
+            eng.sample(x, use_graph=False, stream=stream, tail=tail_eng, tail_steps=a.tail_fp32)
             stream.synchronize()
-            loop_check = {"graph_loop_equals_eager_loop": bool(torch.equal(x, x_graph)), "steps": K}
+            loop_check = {"graph_loop_equals_eager_loop": bool(torch.equal(x, x_timed)), "steps": K}
     per_rank_ms = [wall * 1e3 / K]
+    gather_ms = 0.0
     if world > 1:
         mine = torch.tensor([statistics.median(walls) * 1e3 / K, t_gather * 1e3], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank_ms = [float(v[0]) for v in allr]
         gather_ms = max(float(v[1]) for v in allr)
+
+    # ---- strong scaling: BASELINE config 4's global batch split over the ranks (every rank takes part; rank 0 reports)
+    strong = None
+    if not a.skip_strong:
+        from ns2vc_amd.dist import shard_range
+        GB = a.strong_batch
+        lo, hi = shard_range(GB, rank, world)
+        try:
+            es = build(a.precision, B_=hi - lo)
+            ios = dev_inputs(f"strong.r{rank}", hi - lo, T)
+            ws, _, tg = timed_jobs(es, ios, K, K, min(reps, 3), world > 1, None, 0, GB)
+            es.close()
+            del ios
+            wm = statistics.median(ws)
+            strong = {"global_batch": GB, "per_rank_batch": hi - lo, "n_gpus": world, "steps": K, "solver": solver, "ms_per_step": wm * 1e3 / K,
+                      "value": K / wm, "unit": f"denoiser-steps/s at global batch {GB} (strong scaling: the batch is split over the ranks)",
+                      "sample_steps_per_s": GB * K / wm, "jobs_ms": [w * 1e3 for w in ws], "all_gather_ms": tg * 1e3 if world > 1 else 0.0,
+                      "scaling": "strong"}
+        except Exception as ex:                                # never take the headline down
+            strong = {"error": repr(ex)}
 
     if rank == 0:
         gflop_sample = PUBLISHED_GFLOP.get((T, Lp), algorithmic_gflop_per_sample_step(T, Lp))
@@ -395,10 +489,10 @@ def main():
 
         # ---- CPU baseline (oracle on the host cores) + parity of the timed precision at the bench shape
         cpu = parity = None
-        ref = None
+        ref = samp = None
         if world == 1 and not a.skip_cpu:
             try:
-                cpu, ref = cpu_baseline(T, Lp, B, a.cpu_budget)
+                cpu, ref, samp = cpu_baseline(T, Lp, B, a.cpu_budget, sampler=(solver, K, 4 if K <= 20 else 2))
             except Exception as ex:                      # the baseline leg must never take the GPU number down
                 cpu = {"value": None, "unit": f"denoiser-steps/s (batch {B})", "cores": _host_cores(), "kind": "port", "sample": f"failed: {ex!r}"}
 
@@ -416,20 +510,106 @@ def main():
                     "reference": "oracle/unet_ref.py (pinned bit-exact to the reference by tests/golden), one UNet forward, per-item timesteps 40..960"}
         if ref is not None:
             parity = parity_of(eng, a.precision)
+            if samp is not None:                       # the TIMED loop's output (same inputs: bench.r0) on the utterances the oracle sampled
+                nb = samp["items"]
+                ys = x_timed[:nb].cpu().numpy().astype(np.float64)
+                parity["sampled_latent"] = {
+                    "rel_l2_vs_oracle": float(np.linalg.norm(ys - samp["y"]) / np.linalg.norm(samp["y"])), "items": nb, "of_batch": B,
+                    "solver": solver, "steps": K, "tail_fp32": a.tail_fp32, "oracle_seconds": round(samp["seconds"], 1),
+                    "reference": f"oracle/sampler_ref.py (pinned to the reference's own samplers by tests/golden) on utterances 0..{nb - 1} of the timed batch, identical noise"}
 
         # ---- the exact-fp32 precision: same job, same roofline definition (peak = 157.3 TFLOP/s fp32 MFMA)
         fp32_block = None
+        e32 = None
         if world == 1 and a.precision != "fp32" and not a.skip_fp32:
             eng.close()
             e32 = build("fp32")
-            w32, _, _ = timed_jobs(e32, K, min(reps, 3), False)
+            w32, _, _ = timed_jobs(e32, io, K, K, min(reps, 3), False)
+            x32 = x.clone()
             ms32 = statistics.median(w32) * 1e3 / K
             fam32 = family_table(e32, stream)
             fp32_block = {"dtype": "fp32", "ms_per_step": ms32, "value": K / statistics.median(w32), "jobs_ms": [w * 1e3 for w in w32],
-                          "roofline": roofline_block(fam32, "fp32", ms32, gflop_sample, B, (B, T, Lp))}
+                          "roofline": roofline_block(fam32, "fp32", ms32, gflop_sample, B, (B, T, Lp)),
+                          "sampled_latent_vs_timed_precision": rel_l2_dev(x_timed, x32)}
             if ref is not None:
                 fp32_block["parity"] = parity_of(e32, "fp32")
+            # the mixed-precision loop at the headline shape: the last two evaluations on this fp32 engine
+            if a.tail_fp32 == 0:
+                try:
+                    em = build(a.precision)
+                    wmx, _, _ = timed_jobs(em, io, K, K, min(reps, 3), False, e32, 2)
+                    fp32_block["mixed_precision_tail2"] = {
+                        "what": f"{a.precision} for the first {K - 2} evaluations, fp32 for the last 2 (ns2vc_sampler_handoff); both engines' set_condition inside the job",
+                        "ms_per_step": statistics.median(wmx) * 1e3 / K, "value": K / statistics.median(wmx),
+                        "sampled_latent_vs_fp32_loop": rel_l2_dev(x, x32), "pure_16bit_vs_fp32_loop": rel_l2_dev(x_timed, x32)}
+                    if samp is not None:
+                        ys = x[:samp["items"]].cpu().numpy().astype(np.float64)
+                        fp32_block["mixed_precision_tail2"]["sampled_latent_vs_oracle"] = float(np.linalg.norm(ys - samp["y"]) / np.linalg.norm(samp["y"]))
+                    em.close()
+                except Exception as ex:
+                    fp32_block["mixed_precision_tail2"] = {"error": repr(ex)}
             e32.close()
+
+        # ---- BASELINE configs 2 and 5, timed the same way (one GPU): parity against the exact-fp32 engine at the same shape
+        others = None
+        if world == 1 and not a.skip_others:
+            others = []
+            try:
+                eng.close()
+            except Exception:
+                pass
+            specs = [("configs[1]: 10 s utterance, 50-step DPM-Solver, batch 8", 10.0, 8, "dpmsolver++", 50, False),
+                     ("configs[4] shape, 16-bit attention: 30 s utterance, 50-step DPM-Solver, batch 8", 30.0, 8, "dpmsolver++", 50, False),
+                     ("configs[4] as stated (fp8 MFMA attention path): 30 s utterance, 50-step DPM-Solver, batch 8", 30.0, 8, "dpmsolver++", 50, True)]
+            ref32 = {}
+            for name, secs, B2, solver2, K2, fp8 in specs:
+                try:
+                    T2 = frames_for_seconds(secs)
+                    io2 = dev_inputs(f"other.{secs:g}", B2, T2)
+                    if (T2, B2) not in ref32:          # exact-fp32 engine: the forward and the whole loop as references
+                        r32 = build("fp32", B_=B2, T_=T2, solver_=solver2, K_=K2)
+                        t_par = torch.linspace(40.0, 960.0, B2, device=dev)
+                        y32 = torch.empty_like(io2["noise"])
+                        with torch.cuda.stream(stream):
+                            r32.set_condition(io2["content"], io2["prompt"], io2["mask"], stream=stream)
+                            r32.forward(io2["noise"], t_par, y32, stream=stream)
+                            io2["x"].copy_(io2["noise"])
+                            r32.sample(io2["x"], use_graph=use_graph, stream=stream)
+                            stream.synchronize()
+                        ref32[(T2, B2)] = (r32, t_par, y32, io2["x"].clone())
+                    r32, t_par, y32, s32 = ref32[(T2, B2)]
+                    e2 = build(a.precision, B_=B2, T_=T2, solver_=solver2, K_=K2, attn_fp8=fp8)
+                    tail2 = 2 if a.precision != "fp32" else 0
+                    w2, _, _ = timed_jobs(e2, io2, K2, K2, 3, False, r32 if tail2 else None, tail2)
+                    s_mixed = io2["x"].clone()
+                    w2p, _, _ = timed_jobs(e2, io2, K2, K2, 3, False)
+                    s_pure = io2["x"].clone()
+                    y2 = torch.empty_like(io2["noise"])
+                    with torch.cuda.stream(stream):
+                        e2.set_condition(io2["content"], io2["prompt"], io2["mask"], stream=stream)
+                        e2.forward(io2["noise"], t_par, y2, stream=stream)
+                        stream.synchronize()
+                    g2 = PUBLISHED_GFLOP.get((T2, Lp), algorithmic_gflop_per_sample_step(T2, Lp))
+                    ms2, ms2p = statistics.median(w2) * 1e3 / K2, statistics.median(w2p) * 1e3 / K2
+                    fam2 = family_table(e2, stream)
+                    others.append({
+                        "config": name, "workload": f"{secs:g} s (T={T2}), batch {B2}, Lp={Lp}, {K2}-step {solver2} order 2, captured loop, {a.precision} operands"
+                                                    + (", PV of every attention on v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3)" if fp8 else "")
+                                                    + (f", last {tail2} evaluations on the fp32 engine" if tail2 else ""),
+                        "dtype": a.precision + ("+fp8 PV" if fp8 else ""), "tail_fp32": tail2, "ms_per_step": ms2, "value": K2 / statistics.median(w2),
+                        "unit": f"denoiser-steps/s (batch {B2}, whole job)", "sample_steps_per_s": B2 * K2 / statistics.median(w2),
+                        "rtf": statistics.median(w2) / (B2 * secs), "jobs_ms": [w * 1e3 for w in w2],
+                        "pure_16bit_loop": {"ms_per_step": ms2p, "value": K2 / statistics.median(w2p)},
+                        "parity": {"reference": "the exact-fp32 engine at the same shape and inputs (itself 1e-6 from the oracle: tests/test_engine_gpu.py, fp32_parity_mode)",
+                                   "forward_rel_l2": rel_l2_dev(y2, y32), "sampled_latent_rel_l2": rel_l2_dev(s_mixed, s32),
+                                   "sampled_latent_rel_l2_pure_16bit": rel_l2_dev(s_pure, s32), "tolerance": 1e-3},
+                        "roofline": roofline_block(fam2, a.precision, ms2p, g2, B2, (B2, T2, Lp)),
+                        "launches_per_step": e2.launches()[0]})
+                    e2.close()
+                except Exception as ex:
+                    others.append({"config": name, "error": repr(ex)})
+            for r32, *_ in ref32.values():
+                r32.close()
 
         value = world * K / wall
         out = {
@@ -437,18 +617,20 @@ def main():
             "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded hash inputs, procedural weights of the production UNet1DConditionModel)",
             "config": {"workload": f"{a.seconds:g} s utterance (T={T} Vocos frames), batch {B}/GPU, prompt Lp={Lp}, {K}-step {solver} order {order}, "
-                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision} MFMA operands{' + fp8 PV in attention' if a.attn_fp8 else ''}; timed job = set_condition + {K} steps"
+                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision} MFMA operands{' + fp8 PV in attention' if a.attn_fp8 else ''}"
+                                   f"{f' + last {a.tail_fp32} evaluations fp32' if a.tail_fp32 else ''}; timed job = set_condition + {K} steps"
                                    + (" + all-gather of latents" if world > 1 else ""),
                        "global_batch": B * world, "frames": T, "prompt_frames": Lp, "solver": solver, "parallelism": f"dp{world}"},
             "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,
                        "max_ms_per_step": max(walls) * 1e3 / K},
             "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
             "launches_per_step": launches, "workspace_gb": workspace_gb, "device": E.device_info(),
-            "rccl_ranks": world if world > 1 else 0, "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "parity": parity, "fp32_parity_mode": fp32_block, "cpu_baseline": cpu,
+            "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
+            "roofline": roof, "parity": parity, "fp32_parity_mode": fp32_block, "other_configs": others, "strong_scaling": strong, "cpu_baseline": cpu,
         }
         if world > 1:
             out["all_gather_ms"] = gather_ms
+            out["all_gather_bytes"] = int(B * world * cfg.latent_channels * T * 4)     # what every rank receives: the finished latents of the global batch
             out["spawned_by"] = "bench.py" if os.environ.get("NS2VC_BENCH_SPAWNED") else "launcher"
         if cpu and cpu.get("value"):
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -116,19 +116,29 @@ template <> __device__ __forceinline__ f16_t op_from_float<f16_t>(float x) { f16
 //     by the MFMA is exact too);
 //   * V^T carries a row of ones, so the PV MFMA also accumulates the denominator (of the SAME rounded probabilities
 //     that build the numerator): no per-score add, no separate running sum.
-// P8 (16-bit operand types only): the PV product runs on the fp8 MFMA (v_mfma_f32_32x32x16_fp8_fp8, OCP e4m3 on gfx950): V^T is
-// staged in LDS as fp8 (converted while staging), the probabilities are packed to fp8 instead of the 16-bit type; QK^T, the
-// softmax state and all accumulators are unchanged.  BASELINE config 5 names an fp8 attention path; see DESIGN section 4 for
-// why it is an option and not the default (the kernel is VALU-bound 3 : 1, and 3 mantissa bits in P cost the parity bar).
+// P8 (16-bit operand types only; BASELINE config 5's "fp8 MFMA attention path"): the PV product runs on the fp8-RATE matrix
+// instruction of gfx950, v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64 = one whole key tile per instruction, OCP e4m3 operands, unit
+// E8M0 scales; twice the bf16 rate -- the non-scaled v_mfma_f32_32x32x16_fp8_fp8 of round 2 runs at the bf16 rate,
+// MI355X_MICROARCH.md "Matrix cores").  V^T is staged in LDS as fp8 (converted while staging), the probabilities are packed to
+// fp8 instead of the 16-bit type; QK^T (K = head dim: 16..64), the softmax state and all accumulators are unchanged.
+// Operand slots: the instruction contracts over 64 k-slots, lane half `hi` supplying slots 32*hi .. 32*hi+31 of its A row / B
+// column (8 VGPRs, 4 slots each).  The contraction index is a dummy, so the keys are PERMUTED to where the score MFMA left
+// them: after S^T = K Q^T lane (q, hi) holds the keys  k2*32 + 8*g + 4*hi + i  (k2 = 32-key sub-tile, g = 0..3, i = 0..3) in
+// s[k2][4*g + i]; key -> slot 32*hi + (16*k2 + 4*g + i), i.e. P's register v = 4*k2 + g is pack(s[k2][4g .. 4g+3]) with no
+// data movement at all, and V^T rows are stored with the same key -> slot map (vpos8).  See DESIGN section 4 for why it stays an
+// option (the kernel is VALU-bound, fp8 shortens only the matrix time; 3 mantissa bits in P cost the parity bar).
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
   int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
   v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
   return (uint32_t)v;
 }
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+// slot of key (0..63) inside a 64-slot V^T row of the fp8 path
+__device__ __forceinline__ int vpos8(int key) { return ((key & 4) << 3) | ((key & 32) >> 1) | ((key & 24) >> 1) | (key & 3); }
 template <typename TM, int HD, int KEYS, bool P8>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   op_mode_init<TM>();
-  static_assert(!P8 || sizeof(TM) == 2, "the fp8 PV path exists for the 16-bit operand types");
+  static_assert(!P8 || (sizeof(TM) == 2 && KEYS == 64), "the fp8 PV path: 16-bit operand types, one 64-key tile per f8f6f4 MFMA");
   constexpr int NSUB = KEYS / 32;         // 32-key sub-tiles per K/V tile (2 or 4): per-tile bookkeeping, barrier and waits amortise over them
   constexpr int SZ = AMma<TM>::SZ;
   constexpr int EPC = 16 / SZ;            // elements per 16-B fragment chunk
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   for (int i = tid; i < 2 * KEYS; i += 256) {      // K aux element 0 = 1 for every key row, V^T row HD = ones, both stages
     const int st = i / KEYS, key = i - st * KEYS;
     *reinterpret_cast<TM*>(smem + st * STAGE + key * KROWB + HD * SZ) = op_from_float<TM>(1.0f);
-    if constexpr (P8) *reinterpret_cast<uint8_t*>(smem + st * STAGE + KBYTES + HD * VROWB + key) = (uint8_t)pack_fp8x4(1.0f, 0.f, 0.f, 0.f);
+    if constexpr (P8) *reinterpret_cast<uint8_t*>(smem + st * STAGE + KBYTES + HD * VROWB + key) = (uint8_t)0x38;     // e4m3 1.0; all 64 slots of the row
     else *reinterpret_cast<TM*>(smem + st * STAGE + KBYTES + HD * VROWB + key * SZ) = op_from_float<TM>(1.0f);
   }
 
@@ -241,15 +251,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
         }
         {
           const int key = u % KEYS, pc = u / KEYS;
-          const int pos = (key & ~31) + AMma<TM>::vpos(key & 31);
-          if constexpr (P8) {       // eight 16-bit values of one key -> eight fp8 bytes down the V^T column
+          if constexpr (P8) {       // eight 16-bit values of one key -> eight fp8 bytes down the V^T column, at the key's k-slot
             const u32x4_t w = vraw[i];
             const uint32_t b0 = pack_fp8x4(Op16<TM>::lo(w.x), Op16<TM>::hi(w.x), Op16<TM>::lo(w.y), Op16<TM>::hi(w.y));
             const uint32_t b1 = pack_fp8x4(Op16<TM>::lo(w.z), Op16<TM>::hi(w.z), Op16<TM>::lo(w.w), Op16<TM>::hi(w.w));
-            uint8_t* vp = reinterpret_cast<uint8_t*>(Vs + (pc * EPC) * VROWB + pos);
+            uint8_t* vp = reinterpret_cast<uint8_t*>(Vs + (pc * EPC) * VROWB + vpos8(key));
 #pragma unroll
             for (int j = 0; j < 4; ++j) { vp[j * VROWB] = (uint8_t)(b0 >> (8 * j)); vp[(4 + j) * VROWB] = (uint8_t)(b1 >> (8 * j)); }
           } else {
+            const int pos = (key & ~31) + AMma<TM>::vpos(key & 31);
             vt_scatter<TM>(Vs + (pc * EPC) * VROWB + pos * SZ, VROWB, vraw[i]);
           }
         }
@@ -320,19 +330,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
     // ---- [O^T ; l][d][q] += sum_key [V^T ; 1][d][key] * P^T[key][q]
     if constexpr (P8) {
+      // the lane's 32 probabilities of this tile = its 32 k-slots, already in slot order: register v = 4*k2 + g
+      i32x8_t pf;
 #pragma unroll
-      for (int k2 = 0; k2 < NSUB; ++k2) {
+      for (int v = 0; v < 8; ++v)
+        pf[v] = (int)pack_fp8x4(s[v >> 2][4 * (v & 3) + 0], s[v >> 2][4 * (v & 3) + 1], s[v >> 2][4 * (v & 3) + 2], s[v >> 2][4 * (v & 3) + 3]);
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {             // 16 keys per fp8 MFMA: this lane half's 8 probabilities = 8 bytes
-          const uint32_t p0 = pack_fp8x4(s[k2][8 * sl + 0], s[k2][8 * sl + 1], s[k2][8 * sl + 2], s[k2][8 * sl + 3]);
-          const uint32_t p1 = pack_fp8x4(s[k2][8 * sl + 4], s[k2][8 * sl + 5], s[k2][8 * sl + 6], s[k2][8 * sl + 7]);
-          const long pf = (long)(((unsigned long long)p1 << 32) | p0);
-#pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const long vf = *reinterpret_cast<const long*>(Vs + (d * 32 + l31) * VROWB + k2 * 32 + sl * 16 + hi * 8);
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf, pf, o[d], 0, 0, 0);
-          }
-        }
+      for (int d = 0; d < DT; ++d) {
+        const char* vr = Vs + (d * 32 + l31) * VROWB + hi * 32;
+        const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(vr), v1 = *reinterpret_cast<const u32x4_t*>(vr + 16);
+        const i32x8_t vf = {(int)v0.x, (int)v0.y, (int)v0.z, (int)v0.w, (int)v1.x, (int)v1.y, (int)v1.z, (int)v1.w};
+        // cbsz = blgp = 0: both operands OCP e4m3; scales 0x7f = 2^0 in every E8M0 byte
+        o[d] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pf, o[d], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
       }
     } else {
 #pragma unroll

@@ -2,7 +2,7 @@
 # same-box A/B of HIP runtime switches that act on the kernel-to-kernel path of a captured graph (210 dependent launches per step).
 # Every run is under its own `timeout`: ROC_SYSTEM_SCOPE_SIGNAL=0 hangs the process on this image (it cost a 15-minute GPU call)
 run() {
-  env "$@" timeout 120 python bench.py --skip-cpu --skip-fp32 --steps 20 --warmup 3 2>> gpurun_out/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],4), round(d['timing']['min_ms_per_step'],4), d['loop_check']['graph_loop_equals_eager_loop'])"
+  env "$@" timeout 120 python bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 3 2>> gpurun_out/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],4), round(d['timing']['min_ms_per_step'],4), d['loop_check']['graph_loop_equals_eager_loop'])"
 }
 for i in 1 2; do
   run X=0
