@@ -612,8 +612,21 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 //   * the two K halves meet in the epilogue: both stage their accumulators in LDS (32-row slabs, re-using the ring),
 //     then all eight waves add the pair while they transpose rows out -- every wave stores, nothing idles.
 // ---------------------------------------------------------------------------
+// Ablation build (make DEFS=-DNS2VC_GEMM_ABLATE=1 into a variant library, tools/gemm_sweep.py --ablate4): the K loop with one of
+// its parts removed, to see what bounds it.  flags: 2 = loads only (no fragment reads, no MFMAs), 4 = no steady-state DMA
+// (reads + MFMAs on whatever the ring holds), 8 = no fragment reads (MFMAs on registers read once), 16 = no MFMAs (DMA + reads)
+#ifndef NS2VC_GEMM_ABLATE
+#define NS2VC_GEMM_ABLATE 0
+#endif
+#if NS2VC_GEMM_ABLATE
+#define NS2VC_G4_FLAGS_PARAM , const int flags
+#define NS2VC_G4_FLAG(b) ((flags & (b)) != 0)
+#else
+#define NS2VC_G4_FLAGS_PARAM
+#define NS2VC_G4_FLAG(b) false
+#endif
 template <typename TM, int BM, int BN, int STAGES, bool LNC>
-__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FLAGS_PARAM) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
@@ -755,6 +768,9 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int sw = (l31 >> 1) & 7;
   int stage = 0;
+#if NS2VC_GEMM_ABLATE
+  u32x4_t abl_a[2][MT], abl_b[2][NT];
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int after = min(STAGES - 2, nk - 1 - kt);
     if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
@@ -764,13 +780,14 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
     __builtin_amdgcn_s_barrier();
     if (kt == 0) NS2VC_STAMP(3);
     auto refill = [&]() __attribute__((always_inline)) {
-      if (kt + STAGES - 1 < nk) {
+      if (kt + STAGES - 1 < nk && !NS2VC_G4_FLAG(4)) {
         int st2 = stage + STAGES - 1;
         if (st2 >= STAGES) st2 -= STAGES;
         issue_tile(st2);
       }
     };
     auto multiply = [&]() __attribute__((always_inline)) {
+      if (NS2VC_G4_FLAG(2)) return;
       const char* As = smem + stage * STAGE;
       const char* Bs = As + BM * TROW;
       const char* ap = As + (wm * WM + l31) * TROW;
@@ -779,10 +796,35 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g) {
       for (int kk = 0; kk < 2; ++kk) {
         const int coff = ((2 * (2 * kg + kk) + hi) ^ sw) * 16;       // this K half's two 32-B k-slabs
         u32x4_t af[MT], bf[NT];
+#if NS2VC_GEMM_ABLATE
+        if (NS2VC_G4_FLAG(8) && kt > 0) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
+          for (int i = 0; i < MT; ++i) af[i] = abl_a[kk][i];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
+          for (int j = 0; j < NT; ++j) bf[j] = abl_b[kk][j];
+        } else
+#endif
+        {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
+        }
+#if NS2VC_GEMM_ABLATE
+        if (kt == 0) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) abl_a[kk][i] = af[i];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) abl_b[kk][j] = bf[j];
+        }
+        if (NS2VC_G4_FLAG(16)) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bf[j]));
+          continue;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -830,8 +872,13 @@ static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
 template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
+#if NS2VC_GEMM_ABLATE
+  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+#else
   if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
   else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+#endif
   return hipGetLastError();
 }
 

@@ -27,6 +27,11 @@ ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 10
           (128, 128, 2 | 256), (128, 128, 2 | 512), (128, 128, 2 | 1024)]
 
 
+# gemm4_kernel ablations (variant library built with DEFS=-DNS2VC_GEMM_ABLATE=1): flags 2 = DMA only, 4 = no steady-state DMA,
+# 8 = no fragment reads, 16 = no MFMAs; 4|8 = MFMAs only, 4|16 = fragment reads only
+ABLATE4 = [(bm, 128, 13 | (f << 8)) for bm in (64, 128) for f in (0, 2, 4, 8, 16, 4 | 8, 4 | 16)]
+
+
 def shapes(B=32, T=938):
     Ts = [T, (T + 1) // 2, ((T + 1) // 2 + 1) // 2, (((T + 1) // 2 + 1) // 2 + 1) // 2]
     Cs = [128, 256, 384, 512]
@@ -50,10 +55,13 @@ def main():
     ap.add_argument("--prec", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--ablate", action="store_true", help="time the ABLATE list (K rotation / loads-only / compute-only variants)")
+    ap.add_argument("--ablate4", action="store_true", help="time the ABLATE4 list (gemm4_kernel with parts of its K loop removed; needs the NS2VC_GEMM_ABLATE build)")
     a = ap.parse_args()
     global CONFIGS
     if a.ablate:
         CONFIGS = ABLATE
+    if a.ablate4:
+        CONFIGS = ABLATE4
     prec = {"fp32": 0, "bf16": 1, "fp16": 2}[a.prec]
     esz = 4 if prec == 0 else 2
     lib = _lib.load()
