@@ -507,3 +507,38 @@ def test_grouped_converter_plan_groups_equal_shapes():
     assert sorted(i for g_ in groups for i in g_) == list(range(len(segs)))
     for g_ in groups:
         assert len({(lengths[i], rlens[i]) for i in g_}) == 1 and len(g_) <= 3
+
+
+def test_vocos_decoder_restatement_shapes_keys_and_inverse_stft():
+    """ns2vc_amd/vocoder.py (the back end `vocos.decode`, model.py:689-691; parity UNPINNED: the vocos package and its
+    checkpoint are not available offline): parameter names / shapes of the published `charactr/vocos-mel-24khz` decoder, the
+    output length the reference's slicing relies on ((T - 1) * 256 samples), and the spectrum head + inverse STFT against an
+    independent numpy overlap-add."""
+    from ns2vc_amd.vocoder import VocosDecoder
+    torch.manual_seed(0)
+    m = VocosDecoder().eval()
+    sd = m.state_dict()
+    assert sd["backbone.embed.weight"].shape == (512, 100, 7) and sd["head.out.weight"].shape == (1026, 512) and sd["head.istft.window"].shape == (1024,)
+    for i in range(8):
+        assert sd[f"backbone.convnext.{i}.dwconv.weight"].shape == (512, 1, 7) and sd[f"backbone.convnext.{i}.pwconv1.weight"].shape == (1536, 512)
+        assert sd[f"backbone.convnext.{i}.pwconv2.weight"].shape == (512, 1536) and sd[f"backbone.convnext.{i}.gamma"].shape == (512,)
+    assert len(sd) == 4 + 8 * 9 + 2 + 2 + 1 and sum(v.numel() for k, v in sd.items() if k != "head.istft.window") == 13_531_650
+    m.load_vocos_state_dict({**sd, "feature_extractor.mel_spec.mel_scale.fb": torch.zeros(513, 100)})       # encoder-side buffers are ignored
+    B, T = 2, 41
+    mel = torch.randn(B, 100, T)
+    audio = m.decode(mel)
+    assert audio.shape == (B, (T - 1) * 256) and bool(torch.isfinite(audio).all())
+    # spectrum head + inverse STFT vs numpy: irfft of every frame, Hann window, overlap-add, window-envelope normalisation, centre trim
+    h = torch.randn(B, T, 512)
+    got = m.head(h).numpy()
+    o = (h @ m.head.out.weight.T + m.head.out.bias).numpy().astype(np.float64).transpose(0, 2, 1)
+    mag, ph = np.minimum(np.exp(o[:, :513]), 1e2), o[:, 513:]
+    spec = mag * (np.cos(ph) + 1j * np.sin(ph))
+    win = np.hanning(1025)[:1024]                                   # periodic Hann = torch.hann_window(1024)
+    n = 1024 + 256 * (T - 1)
+    want = np.zeros((B, n)); env = np.zeros(n)
+    for t in range(T):
+        want[:, 256 * t: 256 * t + 1024] += np.fft.irfft(spec[:, :, t], n=1024, axis=-1) * win
+        env[256 * t: 256 * t + 1024] += win ** 2
+    want = (want / np.maximum(env, 1e-11))[:, 512: n - 512]
+    assert got.shape == want.shape and rel_l2(got, want) < 1e-4
