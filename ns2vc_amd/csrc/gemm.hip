@@ -35,7 +35,6 @@
 // attention), GroupNorm / LayerNorm partial statistics of the result.
 #include "common.h"
 #include "mma.h"
-#include <cstdlib>
 
 namespace ns2vc {
 
@@ -626,15 +625,7 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #define NS2VC_G4_FLAGS_PARAM
 #define NS2VC_G4_FLAG(b) false
 #endif
-// PF (fragment prefetch across the barrier, round 3).  The ablation runs of the K loop (profiles/r03_gemm_ablate4.txt: DMA only,
-// fragment reads only, MFMAs only each cost 650-790 cycles per 64 x 128 x 64 tile against 1200 for all three, with the MFMA
-// pipe needing 256) showed an iteration to be a CHAIN of latencies -- barrier, DMA issue, an LDS round trip, MFMAs, a second
-// LDS round trip, MFMAs -- that two lock-stepped waves per SIMD cannot hide.  With PF the fragments of tile i+1 are read
-// into a second register set right after the barrier that makes tile i+1 visible, and the MFMAs of that iteration run on
-// tile i's fragments, read one iteration earlier: both LDS round trips leave the critical path (+24..32 VGPRs), and since
-// a tile's ring slot is free as soon as every wave holds its fragments the ring carries one more tile in flight (all STAGES
-// tiles are issued up front, tile i+STAGES is issued in iteration i).
-template <typename TM, int BM, int BN, int STAGES, bool LNC, bool PF>
+template <typename TM, int BM, int BN, int STAGES, bool LNC>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FLAGS_PARAM) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
@@ -769,73 +760,13 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
 
   const int nk = g.K / BKE;
   NS2VC_STAMP(1);
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int sw = (l31 >> 1) & 7;
-  if constexpr (PF) {
-    // ---- pipelined K loop: registers hold tile i while the ring holds tiles i+1 .. i+STAGES
-#pragma unroll
-    for (int s = 0; s < STAGES; ++s)
-      if (s < nk) issue_tile(s);
-    NS2VC_STAMP(2);
-    const char* const ap0 = smem + (wm * WM + l31) * TROW;
-    const char* const bp0 = smem + BM * TROW + (wn * WN + l31) * TROW;
-    const int coff0 = ((2 * (2 * kg + 0) + hi) ^ sw) * 16, coff1 = ((2 * (2 * kg + 1) + hi) ^ sw) * 16;
-    u32x4_t fa[2][MT], fb[2][NT], ga[2][MT], gb[2][NT];
-    auto read_frags = [&](u32x4_t (&a)[2][MT], u32x4_t (&b)[2][NT], int stg) __attribute__((always_inline)) {
-      const char* ap = ap0 + stg * STAGE;
-      const char* bp = bp0 + stg * STAGE;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) { a[0][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff0); a[1][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff1); }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) { b[0][j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff0); b[1][j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff1); }
-    };
-    auto mma_frags = [&](const u32x4_t (&a)[2][MT], const u32x4_t (&b)[2][NT]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], a[kk][i], b[kk][j]);
-    };
-    // tile t has landed when at most LPT x (tiles issued after it) pieces are still in flight
-    auto wait_landed = [&](int after) __attribute__((always_inline)) {
-      if (STAGES >= 5 && after >= 4) wait_vmcnt<4 * LPT>();
-      else if (STAGES >= 4 && after >= 3) wait_vmcnt<3 * LPT>();
-      else if (STAGES >= 3 && after >= 2) wait_vmcnt<2 * LPT>();
-      else if (after >= 1) wait_vmcnt<LPT>();
-      else wait_vmcnt<0>();
-    };
-    static_assert(LPT * (STAGES - 1) < 60, "vmcnt range");
-    // tile 0 -> registers
-    wait_landed(min(STAGES - 1, nk - 1));
-    __builtin_amdgcn_s_barrier();
-    NS2VC_STAMP(3);
-    read_frags(fa, fb, 0);
-    int stg_next = 1;                       // ring slot of tile i+1
-    int stg_free = 0;                       // ring slot of tile i (free once every wave holds its fragments)
-    // one iteration: [tile i+1 visible, slot of tile i free] -> DMA tile i+STAGES -> fragment reads of tile i+1 -> MFMAs of tile i
-    auto iteration = [&](int i, u32x4_t (&ca)[2][MT], u32x4_t (&cb)[2][NT], u32x4_t (&na)[2][MT], u32x4_t (&nb)[2][NT]) __attribute__((always_inline)) {
-      const bool more = i + 1 < nk;
-      if (more) wait_landed(min(STAGES - 2, nk - 2 - i));      // tile i+1; issued after it so far: i+2 .. i+STAGES-1
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // my fragments of tile i are in registers
-      if (more) __builtin_amdgcn_s_barrier();                   // ... and so are everyone else's: slot of tile i is free, tile i+1 visible
-      if (i + STAGES < nk) issue_tile(stg_free);
-      if (more) read_frags(na, nb, stg_next);
-      mma_frags(ca, cb);
-      if (++stg_next == STAGES) stg_next = 0;
-      if (++stg_free == STAGES) stg_free = 0;
-    };
-    int i = 0;
-    for (; i + 1 < nk; i += 2) {
-      iteration(i, fa, fb, ga, gb);
-      iteration(i + 1, ga, gb, fa, fb);
-    }
-    if (i < nk) iteration(i, fa, fb, ga, gb);
-  } else {
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
     if (s < nk) issue_tile(s);
   NS2VC_STAMP(2);
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int sw = (l31 >> 1) & 7;
   int stage = 0;
 #if NS2VC_GEMM_ABLATE
   u32x4_t abl_a[2][MT], abl_b[2][NT];
@@ -908,7 +839,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
     if (++stage == STAGES) stage = 0;
   }
 
-  }
   gemm4_epilogue<TM, BM, LNC>(g, acc, smem, m0, n0, tid, tr, lnraw);
 }
 
@@ -923,7 +853,6 @@ static constexpr size_t gemm_lds_bytes(int bm, int bn, int stages) {
 }
 
 static int g_gemm_flags = 0;
-static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
 template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
@@ -940,28 +869,20 @@ static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
   const size_t epi = (size_t)8 * 32 * (bn / 2 + 4) * 4;
   return ring > epi ? ring : epi;
 }
-// fragment prefetch across the barrier (gemm4_kernel PF): default on; NS2VC_GEMM_PF=0 or ns2vc_debug_set_gemm_tile(..., stages | 1 << 8)
-// select the round-2 loop (kept for A/B and as the tested reference)
-// policy (same-box A/B, profiles/r03_gemm_pf.txt): 0 = never, 1 = every tile, 2 = 64-row tiles only (128 x 128 tiles need
-// 150-170 VGPRs with the second fragment set and lose their second workgroup per CU: wide-N GEMMs 30-45 % slower),
-// 3 = as 2 with ring 2 for the 64-row tiles of the big-M levels
-static int g_gemm_pf = getenv("NS2VC_GEMM_PF") ? atoi(getenv("NS2VC_GEMM_PF")) : 2;
 template <typename TM, int BM, int BN, int STAGES>
 static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
-  const bool forced = g_force_bm != 0;      // tests / sweeps pick the loop with flag bit 0 of `stages`
-  const bool pf = forced ? !(g_gemm_flags & 1) : (g_gemm_pf == 1 || (g_gemm_pf >= 2 && BM == 64));
 #if NS2VC_GEMM_ABLATE
-#define NS2VC_L4(LNC_, PF_) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, LNC_, PF_>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags)
+  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
 #else
-#define NS2VC_L4(LNC_, PF_) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, LNC_, PF_>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g)
+  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
 #endif
-  if (g.ln_stats) { if (pf) NS2VC_L4(true, true); else NS2VC_L4(true, false); }
-  else { if (pf) NS2VC_L4(false, true); else NS2VC_L4(false, false); }
-#undef NS2VC_L4
   return hipGetLastError();
 }
 
+static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
 void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
 // Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
@@ -997,12 +918,10 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
   }
-  if (!g_force_bm && g_gemm_pf == 3 && st == 13 && bm == 64 && g.M >= 7000) st = 12;
-  if (st >= 12 && st <= 15) {   // 8-wave K-split kernel, ring depth st - 10
+  if (st == 12 || st == 13) {   // 8-wave K-split kernel, ring depth st - 10
     if (bn != 128) return hipErrorInvalidValue;
 #define NS2VC_CASE4(BM_, ST_) if (bm == BM_ && st == 10 + ST_) return launch_cfg4<TM, BM_, 128, ST_>(g, s)
     NS2VC_CASE4(128, 2); NS2VC_CASE4(128, 3); NS2VC_CASE4(64, 2); NS2VC_CASE4(64, 3);
-    NS2VC_CASE4(128, 4); NS2VC_CASE4(64, 4); NS2VC_CASE4(64, 5);      // deeper rings (stages 14 / 15): long-K GEMMs that own a CU anyway
 #undef NS2VC_CASE4
     return hipErrorInvalidValue;
   }
@@ -1053,15 +972,12 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
   } while (0)
 #define NS2VC_SET4(TM, BM, ST)                                                                                  \
   do {                                                                                                          \
-    hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false, false>, gemm4_lds_bytes(BM, 128, ST));          \
-    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true, false>, gemm4_lds_bytes(BM, 128, ST)); \
-    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, false, true>, gemm4_lds_bytes(BM, 128, ST)); \
-    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true, true>, gemm4_lds_bytes(BM, 128, ST));  \
+    hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false>, gemm4_lds_bytes(BM, 128, ST));                 \
+    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true>, gemm4_lds_bytes(BM, 128, ST));        \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 template <typename TM> static hipError_t init_typed() {
   NS2VC_SET4(TM, 128, 2); NS2VC_SET4(TM, 128, 3); NS2VC_SET4(TM, 64, 2); NS2VC_SET4(TM, 64, 3);
-  NS2VC_SET4(TM, 128, 4); NS2VC_SET4(TM, 64, 4); NS2VC_SET4(TM, 64, 5);
   NS2VC_SET(TM, 128, 128, 2);
   NS2VC_SET(TM, 64, 128, 2); NS2VC_SET(TM, 64, 128, 3);
   NS2VC_SET(TM, 64, 64, 2); NS2VC_SET(TM, 64, 64, 3); NS2VC_SET(TM, 64, 64, 4);

@@ -530,8 +530,9 @@ def test_vocos_decoder_restatement_shapes_keys_and_inverse_stft():
     assert audio.shape == (B, (T - 1) * 256) and bool(torch.isfinite(audio).all())
     # spectrum head + inverse STFT vs numpy: irfft of every frame, Hann window, overlap-add, window-envelope normalisation, centre trim
     h = torch.randn(B, T, 512)
-    got = m.head(h).numpy()
-    o = (h @ m.head.out.weight.T + m.head.out.bias).numpy().astype(np.float64).transpose(0, 2, 1)
+    with torch.no_grad():
+        got = m.head(h).numpy()
+        o = (h @ m.head.out.weight.T + m.head.out.bias).numpy().astype(np.float64).transpose(0, 2, 1)
     mag, ph = np.minimum(np.exp(o[:, :513]), 1e2), o[:, 513:]
     spec = mag * (np.cos(ph) + 1j * np.sin(ph))
     win = np.hanning(1025)[:1024]                                   # periodic Hann = torch.hann_window(1024)

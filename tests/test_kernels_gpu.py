@@ -172,11 +172,9 @@ def test_gemm_cases(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(128, 128, 13), (64, 128, 13), (128, 128, 13 | 256), (64, 128, 13 | 256), (64, 128, 15)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(128, 128, 13), (64, 128, 13)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_cases_ksplit_kernel(tile, prec, diag):
-    """Every feature case (taps, stride 2, upsample, concat, residual, GEGLU, dual outputs) through the 8-wave K-split kernel:
-    the pipelined K loop (fragment prefetch across the barrier, the default) and, with flag bit 8 of `stages` (| 256), the
-    round-2 loop; stages 14 / 15 = ring depth 4 / 5."""
+    """Every feature case (taps, stride 2, upsample, concat, residual, GEGLU, dual outputs) through the 8-wave K-split kernel."""
     for name, *args in GEMM_CASES:
         if args[5] % 128:
             continue
@@ -192,10 +190,7 @@ def test_gemm_cases_ksplit_kernel(tile, prec, diag):
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("tile", [(128, 128, 2), (64, 128, 2), (64, 128, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4),
                                   # stages 12 / 13 = the 8-wave K-split kernel (gemm4_kernel) with ring depth 2 / 3
-                                  (128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13),
-                                  # | 256: the same kernels with the round-2 (non-pipelined) K loop; 14 / 15: ring depth 4 / 5
-                                  (128, 128, 12 | 256), (128, 128, 13 | 256), (64, 128, 12 | 256), (64, 128, 13 | 256),
-                                  (128, 128, 14), (64, 128, 14), (64, 128, 15)],
+                                  (128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13)],
                          ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_every_tile(tile, prec, diag):
     rng = np.random.default_rng(tile[0] * 1000 + tile[1])
@@ -204,8 +199,8 @@ def test_gemm_every_tile(tile, prec, diag):
     e = rel_l2(out, ref)
     diag(f"gemm tile={tile} prec={prec} rel_l2={e:.3e}")
     assert e < TOL[prec]
-    # K of exactly 1 .. 7 tiles exercises the pipeline prologue / tail waits of every ring depth
-    for kk in (1, 2, 3, 4, 5, 6, 7):
+    # K of exactly 1, 2 and 3 tiles exercises the pipeline prologue / tail waits
+    for kk in (1, 2, 3):
         out, ref, _ = run_gemm(rng, prec, 2, 90, 90, (64 if prec else 32) * kk, 0, 128, 1, 0, 1, 0, 0, 0, tile=tile)
         e = rel_l2(out, ref)
         diag(f"gemm tile={tile} prec={prec} ktiles={kk} rel_l2={e:.3e}")

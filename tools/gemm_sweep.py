@@ -23,9 +23,6 @@ from ns2vc_amd.engine import DevBuf, Event, Stream  # noqa: E402
 # (BM, BN, stages | flags << 8); stages 2..4 = LDS-DMA ring depth of the 4-wave kernel (gemm2_kernel), 12 / 13 = the 8-wave
 # K-split kernel (gemm4_kernel) with ring 2 / 3; flags (gemm2 only): 1 = K rotation, 2 = loads only, 4 = no steady-state loads
 CONFIGS = [(128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13), (128, 128, 2), (64, 128, 2), (64, 128, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
-# gemm4_kernel: pipelined K loop (default) vs the round-2 loop (flag 1 = | 256), ring depths 2 .. 5 (stages 12 .. 15)
-PFCFG = [(128, 128, 12 | 256), (128, 128, 12), (128, 128, 13 | 256), (128, 128, 13), (128, 128, 14), (64, 128, 12 | 256), (64, 128, 12), (64, 128, 13 | 256), (64, 128, 13),
-         (64, 128, 14), (64, 128, 15)]
 ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 1024), (64, 128, 3 | 512), (64, 64, 2 | 256), (64, 64, 2 | 512), (64, 64, 2 | 1024),
           (128, 128, 2 | 256), (128, 128, 2 | 512), (128, 128, 2 | 1024)]
 
@@ -58,7 +55,6 @@ def main():
     ap.add_argument("--prec", default="fp16", choices=["fp16", "bf16", "fp32"])
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--ablate", action="store_true", help="time the ABLATE list (K rotation / loads-only / compute-only variants)")
-    ap.add_argument("--pf", action="store_true", help="time the PFCFG list (pipelined vs round-2 K loop of gemm4_kernel, ring depths 2 .. 5)")
     ap.add_argument("--ablate4", action="store_true", help="time the ABLATE4 list (gemm4_kernel with parts of its K loop removed; needs the NS2VC_GEMM_ABLATE build)")
     a = ap.parse_args()
     global CONFIGS
@@ -66,8 +62,6 @@ def main():
         CONFIGS = ABLATE
     if a.ablate4:
         CONFIGS = ABLATE4
-    if a.pf:
-        CONFIGS = PFCFG
     prec = {"fp32": 0, "bf16": 1, "fp16": 2}[a.prec]
     esz = 4 if prec == 0 else 2
     lib = _lib.load()
