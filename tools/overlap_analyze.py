@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""usage: overlap_analyze.py kernel_trace.csv -- how much of the PyTorch stages' kernel time (front end, vocoder: every kernel
-that is not ns2vc::*) ran while a denoiser kernel was also in flight, from a rocprofv3 --kernel-trace CSV of tools/overlap_run.py.
-Only the LAST 60 % of the trace is analysed (the warm-up batch and the setup are in front)."""
+"""usage: overlap_analyze.py kernel_trace.csv run.json -- how much of the PyTorch stages' kernel time (front end, vocoder: every
+kernel that is not ns2vc::*) ran while a denoiser kernel was also in flight, from a rocprofv3 --kernel-trace CSV of
+tools/overlap_run.py.  Only the timed batches are analysed: the last (ms_per_batch x batches) of the trace, as run.json reports them
+(the warm-up batch and the setup are in front)."""
 import csv
 import json
 import sys
@@ -10,7 +11,9 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "ns2vc::" in r["Kernel_Name"]))
 rows.sort()
-t_lo = rows[0][0] + int(0.4 * (rows[-1][1] - rows[0][0]))
+run = json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+t_hi = max(r[1] for r in rows)
+t_lo = t_hi - int(run["ms_per_batch"] * run["batches"] * 1e6 * 1.01)
 rows = [r for r in rows if r[0] >= t_lo]
 den = [(s, e) for s, e, d in rows if d]
 oth = [(s, e) for s, e, d in rows if not d]
