@@ -81,8 +81,6 @@ int ns2vc_unet_num_missing_weights(ns2vc_unet* h, char* first_missing, int bufle
  *   "fold_ff"   1|0  ff.net.2 folded into proj_out at pack time (default 1) vs two launches
  *   "fuse_ffn"  1|0  GEGLU feed-forward + proj_out in ONE launch where eligible (16-bit precisions, dim <= 256; needs
  *                    ln_linear and fold_ff; default 1) vs the GEGLU GEMM + the folded GEMM
- *   "fuse_conv_gn" 1|0  every resnet's conv1 + norm2 + SiLU in ONE launch where eligible (16-bit precisions, T_level <= 1024;
- *                    default 1) vs the implicit GEMM + gn_apply (also "fuse_ffn_pre", "fuse_rows", "fuse_rows_gn", "attn_fp8")
  * The environment variables NS2VC_LN_LINEAR / NS2VC_FOLD_FF / NS2VC_FUSE_FFN set the defaults at ns2vc_unet_create. */
 int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value);
 /* LayerNorm-by-linearity health: the largest |mean| / std over every LayerNorm input row seen since the last read-out
@@ -261,25 +259,6 @@ typedef struct ns2vc_rowchain_args {
 /* w1 [dim][dim], w2 [n2][dim]: fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
 int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int n2, int precision, void** out_stream_dev);
 int ns2vc_k_rowchain(const ns2vc_rowchain_args* a, int precision, void* stream);
-/* conv1 (k = 3, stride 1) of a ResnetBlock + GroupNorm(norm2) + time scale / shift + SiLU in one launch (csrc/convgn.hip;
- * resnet.py:600-631), 16-bit precisions:  out_op = act( GN(conv(a) + bias) * (1 + temb[b][off + n]) + temb[b][off + N + n] ).
- * A workgroup owns all T frames of one batch item for lcm(32, N / G) output channels, so the statistics never leave it and the
- * fp32 convolution result is never written.  a: operand rows [B*T][lda] (already act(norm1(x))); wpack from ns2vc_pack_convgn;
- * needs cin % 64 == 0, (N / G) % 16 == 0 and ceil(T / 256) * lcm(32, N / G) / 32 <= 6 (e.g. T <= 1024 at N / G = 16 | 32). */
-typedef struct ns2vc_convgn_args {
-  const void* a; int32_t lda, cin;
-  const void* wpack;
-  const float* bias; const float* gamma; const float* beta; float eps; int32_t G;
-  const float* temb; int32_t ldtemb, temb_off;   /* optional per-(batch item, channel) scale | shift rows, or NULL */
-  int32_t silu;
-  void* out_op; int32_t ldo;                      /* operand-typed [B*T][ldo] */
-  int32_t B, T, N;
-  float* dbg_conv;                                /* tests: fp32 [B*T][N] convolution result (+ bias) before the normalisation, or NULL */
-  float* dbg_stats;                               /* tests: fp32 [B][N/16][2] (mean, rstd) of every 16-channel block's group, or NULL */
-} ns2vc_convgn_args;
-/* rows [N][3*cin] fp32 host, K = tap * cin + c (the order every conv weight is packed in) -> device fragment stream */
-int ns2vc_pack_convgn(const float* rows_host, int N, int cin, int G, int precision, void** out_dev);
-int ns2vc_k_convgn(const ns2vc_convgn_args* a, int precision, void* stream);
 int ns2vc_debug_set_attn_keys(int keys); /* tests / tuning: 128 selects the 128-key K/V tile kernels (16-bit precisions, hd 16 / 32); 0 or 64 = the default 64-key tiles */
 int ns2vc_debug_set_rowchain_tokens(int nt); /* tests: force 64-token (1) / 128-token (2, dim 128 only) workgroups; 0 = heuristic */
 

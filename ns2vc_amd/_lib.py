@@ -81,19 +81,6 @@ class RowchainArgs(C.Structure):
     ]
 
 
-class ConvGnArgs(C.Structure):
-    _fields_ = [
-        ("a", C.c_void_p), ("lda", C.c_int32), ("cin", C.c_int32),
-        ("wpack", C.c_void_p),
-        ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("G", C.c_int32),
-        ("temb", C.c_void_p), ("ldtemb", C.c_int32), ("temb_off", C.c_int32),
-        ("silu", C.c_int32),
-        ("out_op", C.c_void_p), ("ldo", C.c_int32),
-        ("B", C.c_int32), ("T", C.c_int32), ("N", C.c_int32),
-        ("dbg_conv", C.c_void_p), ("dbg_stats", C.c_void_p),
-    ]
-
-
 class AttnArgs(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
@@ -169,8 +156,6 @@ PROTOTYPES = {
     "ns2vc_pack_rowchain": (_I, [_P, _P, _I, _I, _I, _PP]),
     "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),
     "ns2vc_debug_set_rowchain_tokens": (_I, [_I]),
-    "ns2vc_pack_convgn": (_I, [_P, _I, _I, _I, _I, _PP]),
-    "ns2vc_k_convgn": (_I, [C.POINTER(ConvGnArgs), _I, _P]),
     "ns2vc_debug_set_attn_keys": (_I, [_I]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),

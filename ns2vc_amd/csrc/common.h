@@ -236,8 +236,6 @@ hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipS
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride,
                              const float* w1t, const float* b1, const float* w2t, const float* b2,
                              const float* aug, float* emb, void* emb_act_op, int prec, int B, int tdim, int edim, hipStream_t s);
-hipError_t launch_convgn(const ::ns2vc_convgn_args& a, int prec, hipStream_t s);                // convgn.hip
-bool convgn_eligible(int cin, int N, int G, int T, int prec);
 hipError_t launch_rowchain(const ::ns2vc_rowchain_args& a, int prec, hipStream_t s);            // rowchain.hip
 bool rowchain_eligible(int dim, int n2, int T, int prec);
 hipError_t init_rowchain_attributes();

@@ -24,7 +24,6 @@ using namespace ns2vc;
 namespace ns2vc {
 hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
 hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out);   // rowchain.hip
-hipError_t pack_convgn_stream(const float* rows, int N, int cin, int G, int prec, std::vector<unsigned short>& out);   // convgn.hip
 void set_ffn_trace(unsigned long long* p);
 }
 
@@ -68,7 +67,6 @@ struct ResnetW {
   bool shortcut = false;
   float *n1g = nullptr, *n1b = nullptr, *n2g = nullptr, *n2b = nullptr;
   PackedW conv1, conv2, sc;
-  void* conv1_gn = nullptr;   // conv1 as the fragment stream of the fused conv1 + norm2 + SiLU kernel (convgn.hip; 16-bit precisions)
 };
 struct AttnW {
   std::string prefix;
@@ -146,7 +144,6 @@ struct ns2vc_unet {
   bool attn_fp8 = false;     // PV product of every attention on the fp8 MFMA (16-bit precisions; BASELINE config 5's fp8 path; costs parity)
   bool fuse_ffn_pre = true;  // attn2.to_out + residual computed inside the fused feed-forward kernel
   bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
-  bool fuse_conv_gn = true;  // every resnet's conv1 + norm2 (+ time scale / shift) + SiLU in one launch where eligible (convgn.hip)
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -476,19 +473,6 @@ int pack_all(ns2vc_unet* h) {
       r.n1g = P.vec(r.prefix + ".norm1.weight"); r.n1b = P.vec(r.prefix + ".norm1.bias");
       r.n2g = P.vec(r.prefix + ".norm2.weight"); r.n2b = P.vec(r.prefix + ".norm2.bias");
       r.conv1 = P.conv(r.prefix + ".conv1");
-      r.conv1_gn = nullptr;
-      if (h->prec != PREC_F32 && convgn_eligible(r.cin, r.cout, c.norm_num_groups, 64, h->prec)) {
-        const HostTensor& w1 = P.T(r.prefix + ".conv1.weight");
-        if (P.err) return 1;
-        std::vector<unsigned short> st;
-        if (pack_convgn_stream(P.conv_rows(w1, 0, r.cin, r.cin).data(), r.cout, r.cin, c.norm_num_groups, h->prec, st) != hipSuccess)
-          return fail("conv1 + GroupNorm stream packing failed for %s", r.prefix.c_str());
-        void* dev = nullptr;
-        if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
-        h->weight_allocs.push_back(dev);
-        if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
-        r.conv1_gn = dev;
-      }
       if (r.shortcut) {   // conv2 and the 1x1 shortcut share one GEMM: K = 3*cout + cin, biases summed
         const HostTensor& w2 = P.T(r.prefix + ".conv2.weight");
         const HostTensor& ws = P.T(r.prefix + ".conv_shortcut.weight");
@@ -744,27 +728,12 @@ struct Planner {
     const int cin = c0 + c1;
     // ---- conv1(act(norm1(x)))
     groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
-    if (h->fuse_conv_gn && r.conv1_gn && convgn_eligible(cin, r.cout, G, Tl, prec)) {
-      // conv1 + norm2 * (1 + scale) + shift + SiLU in ONE launch: a workgroup owns (batch item, whole groups), so the fp32
-      // h and the gn_apply launch do not exist (convgn.hip)
-      ns2vc_convgn_args c;
-      memset(&c, 0, sizeof(c));
-      c.a = xn; c.lda = cin; c.cin = cin; c.wpack = r.conv1_gn; c.bias = r.conv1.bias;
-      c.gamma = r.n2g; c.beta = r.n2b; c.eps = 1e-5f; c.G = G;
-      c.temb = h->temb; c.ldtemb = h->temb_all.N; c.temb_off = r.temb_off; c.silu = 1;
-      c.out_op = hn; c.ldo = r.cout; c.B = B; c.T = Tl; c.N = r.cout;
-      const int pr = prec;
-      const double M = (double)B * Tl;
-      add(r.prefix + ".conv1+norm2", [=](hipStream_t s) { return launch_convgn(c, pr, s); }, 1, 2.0 * M * r.cout * 3.0 * cin,
-          M * cin * opsz + 3.0 * cin * r.cout * opsz + M * r.cout * opsz);
-    } else {
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
     g.stats = new_stats(h1, Tl, r.cout);
     gemm(r.prefix + ".conv1", g);
     // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut
     groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
-    }
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3;
     if (r.shortcut) {      // out = conv2(hn) + conv_shortcut(x): the 1x1 conv rides along as a second K segment
@@ -1231,7 +1200,6 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_CONV_GN")) h->fuse_conv_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
@@ -1311,8 +1279,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
-  else if (!strcmp(name, "fuse_conv_gn")) opt = &h->fuse_conv_gn;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_conv_gn, attn_fp8)", name);
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, attn_fp8)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1722,23 +1689,6 @@ int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int
   HIPCHK(hipMalloc(&d, st.size() * 2));
   HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
   *out_stream_dev = d;
-  return 0;
-}
-int ns2vc_pack_convgn(const float* rows_host, int N, int cin, int G, int precision, void** out_dev) {
-  if (!rows_host || !out_dev) return fail("null argument");
-  std::vector<unsigned short> st;
-  if (pack_convgn_stream(rows_host, N, cin, G, precision, st) != hipSuccess)
-    return fail("convgn: needs a 16-bit precision, cin %% 64 == 0, (N / G) %% 16 == 0 and lcm(32, N / G) <= 96 dividing N");
-  void* d = nullptr;
-  HIPCHK(hipMalloc(&d, st.size() * 2));
-  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
-  *out_dev = d;
-  return 0;
-}
-int ns2vc_k_convgn(const ns2vc_convgn_args* a, int precision, void* stream) {
-  if (!a) return fail("null args");
-  hipError_t e = launch_convgn(*a, precision, (hipStream_t)stream);
-  if (e != hipSuccess) return fail("launch_convgn: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_debug_set_attn_keys(int keys) {
