@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)     # internal: one all-core baseline worker
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-frames", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-pin", default="", help=argparse.SUPPRESS)                  # internal: "lo-hi" core range of one all-core worker
     return ap.parse_args()
 
 
@@ -167,7 +168,9 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(secs), "--cpu-threads", str(th), "--cpu-frames", str(T),
                "--prompt-frames", str(Lp)]
         env = dict(os.environ, OMP_NUM_THREADS=str(th), MKL_NUM_THREADS=str(th), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-        procs = [subprocess.Popen(cmd, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(nproc)]
+        # every worker is pinned to its own `th` cores (unpinned, 16 x 16 threads ran SLOWER than one process in rounds 1-2)
+        procs = [subprocess.Popen(cmd + ["--cpu-pin", f"{i * th}-{(i + 1) * th}"], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for i in range(nproc)]
         try:
             for p in procs:
                 line = p.stdout.readline()
@@ -177,7 +180,7 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
                 p.stdin.write("go\n"); p.stdin.flush()
             outs = [json.loads(p.stdout.readline()) for p in procs]
             agg = {"sample_steps_per_s": sum(o["samples"] / o["seconds"] for o in outs), "processes": nproc, "threads_per_process": th,
-                   "batch_per_process": 4, "seconds": secs}
+                   "batch_per_process": 4, "seconds": secs, "pinned": "each process on its own disjoint cores (sched_setaffinity)"}
         except Exception as ex:
             agg = {"error": repr(ex)}
         finally:
@@ -328,6 +331,13 @@ def main():
     a = parse()
     T_frames = int(math.floor(24000 * a.seconds / 256)) + 1
     if a.cpu_worker > 0:
+        if a.cpu_pin:                                   # one all-core worker on its own disjoint set of cores (before torch starts its thread pool)
+            try:
+                lo, hi = (int(v) for v in a.cpu_pin.split("-"))
+                avail = sorted(os.sched_getaffinity(0))
+                os.sched_setaffinity(0, set(avail[lo:hi]))
+            except Exception:
+                pass
         cpu_worker(a.cpu_worker, a.cpu_threads or 8, a.cpu_frames or T_frames, a.prompt_frames)
         return
     if "RANK" not in os.environ and a.gpus > 1:

@@ -22,9 +22,8 @@ from ns2vc_amd.engine import DevBuf, Event, Stream  # noqa: E402
 
 # (BM, BN, stages | flags << 8); stages 2..4 = LDS-DMA ring depth of the 4-wave kernel (gemm2_kernel), 12 / 13 = the 8-wave
 # K-split kernel (gemm4_kernel) with ring 2 / 3; flags (gemm2 only): 1 = K rotation, 2 = loads only, 4 = no steady-state loads
-CONFIGS = [(128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13), (128, 128, 2), (64, 128, 2), (64, 128, 3), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
-ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 1024), (64, 128, 3 | 512), (64, 64, 2 | 256), (64, 64, 2 | 512), (64, 64, 2 | 1024),
-          (128, 128, 2 | 256), (128, 128, 2 | 512), (128, 128, 2 | 1024)]
+CONFIGS = [(128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13), (64, 128, 2), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
+ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 1024), (64, 64, 2 | 256), (64, 64, 2 | 512), (64, 64, 2 | 1024)]
 
 
 # gemm4_kernel ablations (variant library built with DEFS=-DNS2VC_GEMM_ABLATE=1): flags 2 = DMA only, 4 = no steady-state DMA,
