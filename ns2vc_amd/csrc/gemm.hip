@@ -625,13 +625,33 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #define NS2VC_G4_FLAGS_PARAM
 #define NS2VC_G4_FLAG(b) false
 #endif
-template <typename TM, int BM, int BN, int STAGES, bool LNC>
-__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FLAGS_PARAM) {
+// SPEC (r3): loader / consumer wave specialisation.  profiles/r03_gemm_ablate4.txt: the DMA stream alone and the reads + MFMAs
+// alone each take about half of the full loop's time -- they do not overlap, because every wave issues its DMA pieces (an
+// LDS-DMA instruction holds the issuing wave until the CU's load path has taken its 1 KB: ~117 cycles per piece and wave) and
+// only then its MFMAs, all eight waves in the same phase behind the per-tile barrier.  A second workgroup on the CU interleaves
+// the phases by itself; the coarse levels (M = 3776 / 7520 rows: 118-354 tiles for 256 CUs) have none.  SPEC splits the roles:
+//   1: waves 0-3 issue ALL DMA pieces and never multiply, waves 4-7 multiply the whole K tile and never load (512 threads)
+//   2: 8 loader waves (the count the L2 -> LDS path needs for its 64 B/clk) + 8 consumer waves with the K split (1024 threads)
+//   3: 8 loader waves + 4 consumer waves (768 threads)
+// Loaders that have no role in the 8-wave epilogue leave after the K loop (s_barrier counts live waves only); the others bring
+// zero accumulators, so the epilogue is unchanged.
+template <int SPEC> struct G4Waves {
+  static constexpr int NL = SPEC == 0 ? 8 : SPEC == 1 ? 4 : 8;       // waves that issue DMA
+  static constexpr int NC = SPEC == 0 ? 8 : SPEC == 2 ? 8 : 4;       // waves that multiply
+  static constexpr int NW = SPEC == 0 ? 8 : NL + NC;
+};
+template <typename TM, int BM, int BN, int STAGES, bool LNC, int SPEC = 0>
+__global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const GemmArgs g NS2VC_G4_FLAGS_PARAM) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;
   constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
-  constexpr int LA = BM / 64, LB = BN / 64, LPT = LA + LB;     // 16-B DMA pieces per thread per tile (64 rows per pass)
+  constexpr int NL = G4Waves<SPEC>::NL, NC = G4Waves<SPEC>::NC, NW = G4Waves<SPEC>::NW;
+  constexpr int EOFF = NW - 8;                                  // first wave with a role in the 8-wave epilogue
+  constexpr int LTH = NL * 64;                                  // threads that issue DMA
+  constexpr int RPP = LTH / 8;                                  // tile rows per DMA pass (8 threads = one 128-B row)
+  constexpr int PASSB = RPP * TROW;
+  constexpr int LA = BM / RPP, LB = BN / RPP, LPT = LA + LB;    // 16-B DMA pieces per loading thread per tile
   constexpr int STAGE = (BM + BN) * TROW;
   static_assert(BN == 128 && NT == 2, "wave tile is (BM/2) x 64");
   static_assert(LPT * (STAGES - 1) < 60, "vmcnt range");
@@ -640,8 +660,11 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave >> 2, wq = wave & 3;         // K half, wave tile
+  const int ewave = wave - EOFF;                   // role in the epilogue (< 0: none)
+  const int kg = (ewave >> 2) & 1, wq = ewave & 3; // K half, wave tile
   const int wm = wq >> 1, wn = wq & 1;
+  const bool loader = SPEC == 0 || wave < NL;
+  const bool consumer = SPEC == 0 || wave >= NW - NC;
   const unsigned lds0 = (unsigned)(size_t)smem;
   unsigned long long* tr = NS2VC_TRACE_PTR();
   NS2VC_STAMP(0);
@@ -659,13 +682,13 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
   }
   const int m0 = tm * BM, n0 = tn * BN;
   LnRaw lnraw;                         // LayerNorm-by-linearity consumer: pairs of the lane's epilogue row, in flight during the K loop
-  if constexpr (LNC) ln_row_load(g, m0 + wm * (BM / 2) + (lane >> 4) * 32 + kg * 16 + (lane & 15), lane < 16 * (BM / 64), lnraw);
+  if constexpr (LNC) if (ewave >= 0) ln_row_load(g, m0 + wm * (BM / 2) + (lane >> 4) * 32 + kg * 16 + (lane & 15), lane < 16 * (BM / 64), lnraw);
 
   // ---- DMA coordinates: piece j of this thread = tile row j*64 + tid/8, physical 16-B chunk tid%8.
   // Everything per-lane is a 32-bit byte offset computed ONCE (per piece, tap and source tensor); the K position of a
   // tile is a scalar added by the hardware (buffer addressing), rows in the zero padding / past M are out-of-range
   // offsets that the DMA turns into zeros.  The K loop carries no address arithmetic.
-  const int prow = tid >> 3, pchunk = tid & 7;
+  const int prow = (tid & (LTH - 1)) >> 3, pchunk = tid & 7;
   const int Ctot = g.c0 + g.c1;
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
@@ -677,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
   const bool plain = g.taps == 1 && g.tmode == TMODE_SAME && g.c1 == 0 && g.c2 == 0;   // a linear: source row == output row
 #pragma unroll
   for (int j = 0; j < LA; ++j) {
-    const int m = m0 + j * 64 + prow;
+    const int m = m0 + j * RPP + prow;
     const bool mok = m < g.M;
     if (plain) {          // (wave-uniform) skips the integer division and six of the seven offsets: most launches are linears
       p0t0[j] = mok ? (unsigned)m * (unsigned)g.lda0 * SZB + acolb : DMA_OOB;
@@ -699,7 +722,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
   }
   unsigned vw[LB];
 #pragma unroll
-  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * 64 + prow) * (unsigned)g.K) * SZB + acolb;
+  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * RPP + prow) * (unsigned)g.K) * SZB + acolb;
   const unsigned long long rowsA = (unsigned long long)g.B * g.Tin;
   const i32x4_t rA0 = make_rsrc(g.a0, rowsA * g.lda0 * SZB);
   const i32x4_t rA1 = make_rsrc(g.c1 ? g.a1 : g.a0, rowsA * (g.c1 ? g.lda1 : g.lda0) * SZB);
@@ -710,41 +733,42 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
   int is_tap = 0, is_cc = 0, is_k = 0;
   const int K1 = g.taps * Ctot;
   auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+    if (!loader) return;
     const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
     // every branch below is wave-uniform: one fixed descriptor and one fixed offset register per DMA instruction
     if (is_k >= K1) {
       const unsigned so = (unsigned)(is_k - K1) * SZB;
 #pragma unroll
-      for (int j = 0; j < LA; ++j) blds16(rA2, p2c[j], so, sbase + j * 8192);
+      for (int j = 0; j < LA; ++j) blds16(rA2, p2c[j], so, sbase + j * PASSB);
     } else if (is_cc < g.c0) {
       const unsigned so = (unsigned)is_cc * SZB;
       if (is_tap == 0) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) blds16(rA0, p0t0[j], so, sbase + j * 8192);
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t0[j], so, sbase + j * PASSB);
       } else if (is_tap == 1) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) blds16(rA0, p0t1[j], so, sbase + j * 8192);
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t1[j], so, sbase + j * PASSB);
       } else {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) blds16(rA0, p0t2[j], so, sbase + j * 8192);
+        for (int j = 0; j < LA; ++j) blds16(rA0, p0t2[j], so, sbase + j * PASSB);
       }
     } else {
       const unsigned so = (unsigned)(is_cc - g.c0) * SZB;
       if (is_tap == 0) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) blds16(rA1, p1t0[j], so, sbase + j * 8192);
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t0[j], so, sbase + j * PASSB);
       } else if (is_tap == 1) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) blds16(rA1, p1t1[j], so, sbase + j * 8192);
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t1[j], so, sbase + j * PASSB);
       } else {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) blds16(rA1, p1t2[j], so, sbase + j * 8192);
+        for (int j = 0; j < LA; ++j) blds16(rA1, p1t2[j], so, sbase + j * PASSB);
       }
     }
     const unsigned bbase = sbase + BM * TROW;
     const unsigned soffW = (unsigned)is_k * SZB;
 #pragma unroll
-    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * 8192);
+    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * PASSB);
     is_k += BKE;
     is_cc += BKE;
     if (is_cc >= Ctot) { is_cc = 0; ++is_tap; }
@@ -769,7 +793,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
   const int sw = (l31 >> 1) & 7;
   int stage = 0;
 #if NS2VC_GEMM_ABLATE
-  u32x4_t abl_a[2][MT], abl_b[2][NT];
+  u32x4_t abl_a[4][MT], abl_b[4][NT];
 #endif
   for (int kt = 0; kt < nk; ++kt) {
     const int after = min(STAGES - 2, nk - 1 - kt);
@@ -788,13 +812,14 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
     };
     auto multiply = [&]() __attribute__((always_inline)) {
       if (NS2VC_G4_FLAG(2)) return;
+      if (!consumer) return;
       const char* As = smem + stage * STAGE;
       const char* Bs = As + BM * TROW;
       const char* ap = As + (wm * WM + l31) * TROW;
       const char* bp = Bs + (wn * WN + l31) * TROW;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int coff = ((2 * (2 * kg + kk) + hi) ^ sw) * 16;       // this K half's two 32-B k-slabs
+      for (int kk = 0; kk < (NC == 8 ? 2 : 4); ++kk) {
+        const int coff = ((2 * ((NC == 8 ? 2 * kg : 0) + kk) + hi) ^ sw) * 16;     // this K half's two 32-B k-slabs (4 consumer waves: all four)
         u32x4_t af[MT], bf[NT];
 #if NS2VC_GEMM_ABLATE
         if (NS2VC_G4_FLAG(8) && kt > 0) {
@@ -839,7 +864,8 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs g NS2VC_G4_FL
     if (++stage == STAGES) stage = 0;
   }
 
-  gemm4_epilogue<TM, BM, LNC>(g, acc, smem, m0, n0, tid, tr, lnraw);
+  if (SPEC != 0 && ewave < 0) return;             // loaders beyond the epilogue's eight waves
+  gemm4_epilogue<TM, BM, LNC>(g, acc, smem, m0, n0, tid - EOFF * 64, tr, lnraw);
 }
 
 // ---------------------------------------------------------------------------
@@ -869,20 +895,21 @@ static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
   const size_t epi = (size_t)8 * 32 * (bn / 2 + 4) * 4;
   return ring > epi ? ring : epi;
 }
-template <typename TM, int BM, int BN, int STAGES>
+template <typename TM, int BM, int BN, int STAGES, int SPEC = 0>
 static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
   const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
 #if NS2VC_GEMM_ABLATE
-  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
-  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
 #else
-  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
-  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false>), dim3(nb), dim3(512), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g);
 #endif
   return hipGetLastError();
 }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
+static int g_spec = getenv("NS2VC_GEMM_SPEC") ? atoi(getenv("NS2VC_GEMM_SPEC")) : 1;   // A/B hook: 0 = round-2 tile choice
 void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
 // Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
@@ -910,13 +937,25 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
       // narrow outputs: every conv and the to_out / proj / ff-out linears (and all LayerNorm-statistics producers)
       bn = 128; st = 13;
       bm = (big_m && nk >= 12) ? 128 : 64;
+      // loader / consumer waves where the tile was 64 rows anyway, and instead of the 128-row tiles of the coarse levels (one
+      // workgroup per CU either way); the 128-row tiles of levels 0-1 stay (per-launch table in profiles/r03_gemm_spec.txt)
+      if (g_spec && nk >= 4 && (bm == 64 || g.M < 12000)) { bm = 64; st = 23; }
       if (g.M >= 12000 && g.N > 128 && nk <= 2) { bm = 128; st = 12; }     // level-0 q|k|v: short K, wide-ish N
     } else if (n128) {
       bn = 128;
-      if (g.M >= 12000) { bm = 128; st = 12; } else { bm = 64; st = 13; }
+      if (g.M >= 12000) { bm = 128; st = 12; } else { bm = 64; st = (g_spec && nk >= 4) ? 23 : 13; }
     } else {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
+  }
+  if (st >= 22 && st <= 44) {   // loader / consumer specialised kernels: st = 10 * (1 + SPEC) + ring depth
+    if (bn != 128) return hipErrorInvalidValue;
+#define NS2VC_CASE4S(BM_, ST_, SP_) if (bm == BM_ && st == 10 * (1 + SP_) + ST_) return launch_cfg4<TM, BM_, 128, ST_, SP_>(g, s)
+    // compiled: 4 + 4 waves, ring 3.  Measured and not kept (profiles/r03_gemm_spec.txt): 8 + 8 and 8 + 4 waves (no faster at one
+    // workgroup per CU, slower at two: 1024 / 768 threads), ring 2 (+11 % in the captured step) and ring 4 (one workgroup per CU)
+    NS2VC_CASE4S(128, 3, 1); NS2VC_CASE4S(64, 3, 1);
+#undef NS2VC_CASE4S
+    return hipErrorInvalidValue;
   }
   if (st == 12 || st == 13) {   // 8-wave K-split kernel, ring depth st - 10
     if (bn != 128) return hipErrorInvalidValue;
@@ -975,8 +1014,15 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
     if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true>, gemm4_lds_bytes(BM, 128, ST));        \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
+#define NS2VC_SET4S(TM, BM, ST, SP)                                                                             \
+  do {                                                                                                          \
+    hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false, SP>, gemm4_lds_bytes(BM, 128, ST));             \
+    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true, SP>, gemm4_lds_bytes(BM, 128, ST));    \
+    if (e != hipSuccess) return e;                                                                              \
+  } while (0)
 template <typename TM> static hipError_t init_typed() {
   NS2VC_SET4(TM, 128, 2); NS2VC_SET4(TM, 128, 3); NS2VC_SET4(TM, 64, 2); NS2VC_SET4(TM, 64, 3);
+  NS2VC_SET4S(TM, 128, 3, 1); NS2VC_SET4S(TM, 64, 3, 1);
   NS2VC_SET(TM, 64, 128, 2);
   NS2VC_SET(TM, 64, 64, 2); NS2VC_SET(TM, 64, 64, 3); NS2VC_SET(TM, 64, 64, 4);
   return hipSuccess;

@@ -172,7 +172,7 @@ def test_gemm_cases(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(128, 128, 13), (64, 128, 13)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(128, 128, 13), (64, 128, 13), (128, 128, 23), (64, 128, 23)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_cases_ksplit_kernel(tile, prec, diag):
     """Every feature case (taps, stride 2, upsample, concat, residual, GEGLU, dual outputs) through the 8-wave K-split kernel."""
     for name, *args in GEMM_CASES:
@@ -190,7 +190,9 @@ def test_gemm_cases_ksplit_kernel(tile, prec, diag):
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("tile", [(64, 128, 2), (64, 64, 2), (64, 64, 3), (64, 64, 4),
                                   # stages 12 / 13 = the 8-wave K-split kernel (gemm4_kernel) with ring depth 2 / 3
-                                  (128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13)],
+                                  (128, 128, 12), (128, 128, 13), (64, 128, 12), (64, 128, 13),
+                                  # stage 23 = the same kernel with loader / consumer wave specialisation (4 + 4 waves), ring 3
+                                  (128, 128, 23), (64, 128, 23)],
                          ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_every_tile(tile, prec, diag):
     rng = np.random.default_rng(tile[0] * 1000 + tile[1])
@@ -221,7 +223,7 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
     lib = _lib()
     rng = np.random.default_rng(5)
     B, T, c0, N = 3, 167, 128, 256
-    for tile in [(0, 0, 0), (64, 128, 2), (64, 64, 2), (128, 128, 13), (64, 128, 13)]:
+    for tile in [(0, 0, 0), (64, 128, 2), (64, 64, 2), (128, 128, 13), (64, 128, 13), (128, 128, 23), (64, 128, 23)]:
         a0 = rnd(rng.standard_normal((B, T, c0)), prec)
         W = rnd(rng.standard_normal((N, 3 * c0)) / np.sqrt(3 * c0), prec)
         bias = rng.standard_normal(N).astype(np.float32)
@@ -255,7 +257,7 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 2), (64, 64, 2), (64, 128, 13), (128, 128, 13)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 2), (64, 64, 2), (64, 128, 13), (128, 128, 13), (64, 128, 23), (128, 128, 23)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_layernorm_by_linearity(tile, prec, diag):
     """LayerNorm(y) @ W'^T without a normalisation pass (attention.py:83,102,118): the producer GEMM leaves (sum, sumsq)
     per row and 64-column slice and an operand copy of y; the consumer GEMM reads the raw copy and applies

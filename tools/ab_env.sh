@@ -1,0 +1,13 @@
+#!/bin/bash
+# same-box in-situ A/B of an environment switch of the library: bash tools/ab_env.sh VAR "v0 v1 ..." [rounds] > out
+# prints, per run: VAR=value  ms/step  launches  graph==eager  isolated family ms
+VAR=$1; VALS=$2; ROUNDS=${3:-2}
+for r in $(seq $ROUNDS); do
+  for v in $VALS; do
+    env $VAR=$v python bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 20 --reps 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline())
+print('$VAR=$v', round(d['ms_per_step'],4), d.get('launches_per_step'), d['loop_check'].get('graph_loop_equals_eager_loop'), {k: v2['ms_per_step_isolated'] for k,v2 in d['roofline']['families'].items()})
+"
+  done
+done

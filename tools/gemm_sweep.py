@@ -31,6 +31,21 @@ ABLATE = [(64, 128, 2), (64, 128, 2 | 256), (64, 128, 2 | 512), (64, 128, 2 | 10
 ABLATE4 = [(bm, 128, 13 | (f << 8)) for bm in (64, 128) for f in (0, 2, 4, 8, 16, 4 | 8, 4 | 16)]
 
 
+# loader / consumer specialised gemm4 (stages 23 / 24 = ring 3 / 4) beside the plain K-split kernel
+# (the 8 + 8 / 8 + 4 wave modes and ring 2 / 4 of profiles/r03_gemm_spec.txt need their NS2VC_CASE4S / NS2VC_SET4S lines back in gemm.hip)
+SPEC = [(64, 128, 13), (64, 128, 23), (128, 128, 12), (128, 128, 13), (128, 128, 23)]
+
+
+def stride_shapes():
+    """power-of-two vs odd-multiple row strides (L2 channel spread of the weight / activation rows)"""
+    out = []
+    for K in (512, 576, 1024, 1088, 1536, 1600, 2048, 2112, 3072, 3136):
+        out.append((f"M3776 N512 lin K={K}", 32 * 118, 512, K, 1, 0, 0, "f32"))
+    for K in (1152, 1216):
+        out.append((f"M7520 N384 lin K={K}", 32 * 235, 384, K, 1, 0, 0, "f32"))
+    return out
+
+
 def shapes(B=32, T=938):
     Ts = [T, (T + 1) // 2, ((T + 1) // 2 + 1) // 2, (((T + 1) // 2 + 1) // 2 + 1) // 2]
     Cs = [128, 256, 384, 512]
@@ -55,8 +70,14 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--ablate", action="store_true", help="time the ABLATE list (K rotation / loads-only / compute-only variants)")
     ap.add_argument("--ablate4", action="store_true", help="time the ABLATE4 list (gemm4_kernel with parts of its K loop removed; needs the NS2VC_GEMM_ABLATE build)")
+    ap.add_argument("--rotate", type=int, default=1, help="cycle over this many copies of the operands (A, W): with enough copies to exceed the "
+                                                        "32 MB of L2 every launch reads L2-cold data, as inside the captured step")
+    ap.add_argument("--strides", action="store_true", help="time stride_shapes() instead of the plan's shapes")
+    ap.add_argument("--spec", action="store_true", help="time the SPEC list (loader / consumer wave specialisation)")
     a = ap.parse_args()
     global CONFIGS
+    if a.spec:
+        CONFIGS = SPEC
     if a.ablate:
         CONFIGS = ABLATE
     if a.ablate4:
@@ -67,13 +88,14 @@ def main():
     st = Stream()
     rng = np.random.default_rng(0)
     print(f"# prec={a.prec}; time in us (best config marked *)")
-    for name, M, N, K, taps, geglu, res, outk in shapes():
+    for name, M, N, K, taps, geglu, res, outk in (stride_shapes() if a.strides else shapes()):
         Cin = K // taps
         Tt = M // 32 if M >= 32 * 8 else 1
         Bb = M // Tt
         M = Bb * Tt
-        A = DevBuf(M * Cin * esz + 4096)
-        W = DevBuf(N * K * esz)
+        As = [DevBuf(M * Cin * esz + 4096) for _ in range(a.rotate)]
+        Ws = [DevBuf(N * K * esz) for _ in range(a.rotate)]
+        A, W = As[0], Ws[0]
         bias = DevBuf.from_numpy(rng.standard_normal(N).astype(np.float32))
         Nout = N // 2 if geglu else N
         R = DevBuf(M * Nout * 4) if res else None
@@ -102,7 +124,9 @@ def main():
                 check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
             e0, e1 = Event(), Event()
             e0.record(st)
-            for _ in range(a.reps):
+            for i in range(a.reps):
+                if a.rotate > 1:
+                    g.a0 = As[i % a.rotate].ptr; g.w = Ws[i % a.rotate].ptr
                 check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
             e1.record(st)
             st.sync()
@@ -112,7 +136,9 @@ def main():
             check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
         e0, e1 = Event(), Event()
         e0.record(st)
-        for _ in range(a.reps):
+        for i in range(a.reps):
+            if a.rotate > 1:
+                g.a0 = As[i % a.rotate].ptr; g.w = Ws[i % a.rotate].ptr
             check(lib.ns2vc_k_gemm(C.byref(g), prec, st.ptr), "gemm")
         e1.record(st)
         st.sync()
