@@ -25,6 +25,7 @@ namespace ns2vc {
 hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
 hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
+void set_rc_trace(unsigned long long* p);
 }
 
 namespace {
@@ -1629,6 +1630,7 @@ int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, flo
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) {
   set_gemm_trace((unsigned long long*)dev_u64_blocks_x8);
   set_ffn_trace((unsigned long long*)dev_u64_blocks_x8);
+  set_rc_trace((unsigned long long*)dev_u64_blocks_x8);
   return 0;
 }
 int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream) {

@@ -26,6 +26,20 @@ namespace ns2vc {
 
 typedef ::ns2vc_rowchain_args RowchainArgs;
 
+// optional per-workgroup phase timing (cycles, thread 0): [block][8] = entry, prologue end (panel / constants / first pairs issued, GroupNorm
+// applied), stage-1 loop end, stage-1 epilogue end, stage-2 loop end, exit (stores drained).  `make TRACE=1` builds only;
+// set through ns2vc_debug_set_gemm_trace, read by tools/rowchain_trace.py
+__device__ unsigned long long* g_rc_trace = nullptr;
+#ifndef NS2VC_GEMM_TRACE
+#define NS2VC_GEMM_TRACE 0
+#endif
+#if NS2VC_GEMM_TRACE
+#define RC_TR(i) do { if (tr && tid == 0) tr[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RC_TR(i) do { (void)tr; } while (0)
+#endif
+void set_rc_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rc_trace), &p, sizeof(p)); }
+
 constexpr int RC_TILE = 128 * 128;        // bytes: [128 rows][128 B of K]
 constexpr int RC_PAIR = 2 * RC_TILE;
 
@@ -58,6 +72,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned long long* const tr = (NS2VC_GEMM_TRACE && g_rc_trace) ? g_rc_trace + (size_t)blockIdx.x * 8 : nullptr;
+  RC_TR(0);
   const int tw = wave & 1, cg = wave >> 1;          // token half, row group
   const int l31 = lane & 31, hi = lane >> 5;
   const int sw = (l31 >> 1) & 7;                    // XOR swizzle of every fragment / panel row this lane touches
@@ -168,6 +184,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     // (no barrier here: the first step_begin drains the LDS writes and synchronises the block before any fragment read)
   }
 
+  RC_TR(1);
   int p = 0;                                        // next pair to consume (compile-time after unrolling)
   auto step_begin = [&](bool first = false) __attribute__((always_inline)) -> const char* {
     // pair p has landed when only the pieces (four per wave and pair) of the pair behind it may still be in flight.  Loads
@@ -234,16 +251,23 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
 
   // ---- stage-1 epilogue, per lane: + bias (+ fp32 residual), fp32 result row segments, LayerNorm sums, operand copy
   // into the panel
+  RC_TR(2);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();                     // every wave is done reading A: the panel may be overwritten with y
   float mean[NT], rstd[NT];
+  // fp32 rows of y: a lane owns ONE token, so a direct store writes 32 B to each of 32 different rows per instruction --
+  // measured (tools/rowchain_trace.py) at 5-7 k cycles of this epilogue.  Instead every wave turns its 32 token x 32 channel
+  // block around through 4 KB of the ring slot that is free between the stages (wave-private, XOR-swizzled 16-B chunks, no
+  // barrier), so that 8 lanes write the 128 contiguous bytes of one row.
+  char* const wscr = ring + ((p + RING - 1) % RING) * RC_PAIR + wave * 4096;     // slot of the last stage-1 pair
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
     const int tok = tok0 + 32 * u, mtok = m0 + tok;
     const bool tok_ok = mtok < a.M;
     float ps = 0.f, pq = 0.f;
 #pragma unroll
-    for (int rb = 0; rb < NB1; ++rb)
+    for (int rb = 0; rb < NB1; ++rb) {
+      float4 vq[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float4 v;
@@ -253,16 +277,35 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
         v.w = acc1[rb][u][4 * g + 3] + b1[rb][g].w + rr[u][rb][g].w;
         const int n = 128 * rb + 32 * cg + 8 * g + 4 * hi;
         if (tok_ok) {
-          if (a.out1_f32) out_f4(a.out1_f32 + (size_t)mtok * a.ldo1 + n, v.x, v.y, v.z, v.w);
           ps += (v.x + v.y) + (v.z + v.w);
           pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         } else {
           v = make_float4(0.f, 0.f, 0.f, 0.f);      // rows past M: a zero operand row (nothing of it is stored)
         }
+        vq[g] = v;
         // operand copy: channel n -> k tile n / 64, 16-B chunk (n % 64) / 8, bytes 8 hi .. + 7 of the chunk
         char* dst = panel + (n >> 6) * PTILE + tok * 128 + ((((n & 63) >> 3) ^ sw) * 16) + 8 * hi;
         *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(v.x, v.y), Op16<TM>::pack(v.z, v.w));
       }
+      if (a.out1_f32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(wscr + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) * 16)) = vq[g];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 wv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int T = 8 * k + (lane >> 3), seg = lane & 7;
+          wv[k] = *reinterpret_cast<const float4*>(wscr + T * 128 + ((seg ^ (T & 7)) * 16));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int T = 8 * k + (lane >> 3), seg = lane & 7;
+          const int mt = m0 + 32 * NT * tw + 32 * u + T;
+          if (mt < a.M) out_f4(a.out1_f32 + (size_t)mt * a.ldo1 + 128 * rb + 32 * cg + 4 * seg, wv[k].x, wv[k].y, wv[k].z, wv[k].w);
+        }
+      }
+    }
     // the two lane halves of a token, then the four row groups through LDS
     const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ps), __float_as_uint(ps), false, false);
     const auto q2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(pq), __float_as_uint(pq), false, false);
@@ -295,6 +338,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   }
 
   // ---- stage 2: z^T = W2' y_op^T, all R2 row blocks accumulate at once (k-tile outer)
+  RC_TR(3);
   f32x16_t acc2[R2][NT];
 #pragma unroll
   for (int i = 0; i < R2; ++i)
@@ -313,6 +357,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     ++p;
   }
 
+  RC_TR(4);
   // ---- stage-2 epilogue: LayerNorm fix-up + bias per element, operand rows out.  A lane holds 4 consecutive channels per
   // register group g; the two lane halves trade groups so that every lane stores 8 consecutive channels (16 B)
   TM* const oo = reinterpret_cast<TM*>(a.out2_op);
@@ -346,6 +391,10 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       }
     }
   }
+#if NS2VC_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only so that the last stamp includes the store drain)
+#endif
+  RC_TR(5);
 }
 
 // ---------------------------------------------------------------------------
