@@ -38,7 +38,7 @@ for d in dims:
         z = DevBuf(M * n2 * 2)
         f = RowchainArgs()
         f.a_op = None if gn else p.value; f.lda = d; f.wstream = stream.value; f.bias1 = b1.ptr; f.consts2 = consts.ptr
-        f.res = None if gn else res.ptr; f.ldres = d; f.out1_f32 = None if os.environ.get("RC_NO_Y") else y.ptr; f.ldo1 = d; f.out2_op = z.ptr; f.ldo2 = n2
+        f.res = None if (gn or os.environ.get('RC_NO_RES')) else res.ptr; f.ldres = d; f.out1_f32 = None if os.environ.get("RC_NO_Y") else y.ptr; f.ldo1 = d; f.out2_op = z.ptr; f.ldo2 = n2
         f.ln_eps = 1e-5; f.M = M; f.dim = d; f.n2 = n2; f.ln_health = None
         if gn:
             f.gn_x = d_x.ptr; f.ldx = d; f.gn_stats = st.ptr; f.gn_gamma = gam.ptr; f.gn_beta = bet.ptr; f.gn_eps = 1e-6; f.T = T; f.G = 8
