@@ -157,6 +157,7 @@ PROTOTYPES = {
     "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),
     "ns2vc_debug_set_rowchain_tokens": (_I, [_I]),
     "ns2vc_debug_set_attn_keys": (_I, [_I]),
+    "ns2vc_debug_set_attn_optimistic": (_I, [_I]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),

@@ -133,6 +133,12 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
   return (uint32_t)v;
 }
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
+#ifndef NS2VC_ATTN_OPT
+#define NS2VC_ATTN_OPT 1
+#endif
+template <bool B> struct OptTag { static constexpr bool value = B; };
+// test hook (ns2vc_debug_set_attn_optimistic): 1 = every workgroup takes the exact pass only
+__device__ int g_attn_exact_only = 0;
 // slot of key (0..63) inside a 64-slot V^T row of the fp8 path
 __device__ __forceinline__ int vpos8(int key) { return ((key & 4) << 3) | ((key & 32) >> 1) | ((key & 24) >> 1) | (key & 3); }
 template <typename TM, int HD, int KEYS, bool P8>
@@ -272,14 +278,26 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   };
 
   f32x16_t o[DT];
+  const int ntile = (a.Lk + KEYS - 1) / KEYS;
+  // OPT (r3, 16-bit operand types without the fp8 PV): the per-tile maximum (16 v_max3 + a lane exchange + a vote per tile, ~15 %
+  // of the loop's VALU work, which is what bounds this kernel) only guards the 16-bit range of the probabilities.  The optimistic
+  // pass takes the reference from the FIRST tile alone (its maximum + OPT_MARGIN: later scores may exceed the first tile's by
+  // 2^(14 + margin) before the check at the end sends the row to the exact pass) and checks nothing afterwards; an overflow (or a
+  // row whose probabilities all flushed to zero behind a fully masked first tile) shows up in the denominator, which the PV MFMA
+  // accumulates anyway, and sends the whole workgroup through the exact pass below.  Softmax is shift-invariant: both passes are
+  // exact up to the rounding of the probabilities.
+  constexpr bool OPT = NS2VC_ATTN_OPT && !P8 && sizeof(TM) == 2;
+  constexpr float OPT_MARGIN = 4.0f;
+  auto run = [&](auto optimistic) __attribute__((always_inline)) {
+  constexpr bool O = decltype(optimistic)::value;
 #pragma unroll
   for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-
-  const int ntile = (a.Lk + KEYS - 1) / KEYS;
+  m_ref = 0.f;
+  qaux = hi == 0 ? aux_chunk<TM>(-m_ref, 1.0f) : u32x4_t{0, 0, 0, 0};
   load_tile(0);
-  __syncthreads();          // constants written
+  __syncthreads();          // constants written (first pass) / everybody is done with the stages (second pass)
   store_tile(0, 0);
   __syncthreads();
 
@@ -298,30 +316,33 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
       for (int sl = 0; sl < NS; ++sl) AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + sl * 32), qf[sl]);
     }
     // ---- reference check (per query = per lane; both lane halves agree): lane's keys are k2*32 + 8*g + 4*hi + i
-    float mx = s[0][0];
-#pragma unroll
-    for (int k2 = 0; k2 < NSUB; ++k2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
-    mx = half_max(mx);
-    if (t == 0 || __any(mx > THRESH)) {                 // wave-uniform; after the first tile this is rare
-      float target = t == 0 ? mx : fmaxf(mx, 0.f);
-      if (!(target > -INFINITY)) target = 0.f;          // nothing but masked keys so far
-      const float m_new = round_op<TM>(m_ref + target);
-      const float dsh = m_new - m_ref;
-      if (t > 0) {
-        const float alpha = __builtin_amdgcn_exp2f(-dsh);    // dsh >= 0
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-      }
+    if (!O || t == 0) {
+      float mx = s[0][0];
 #pragma unroll
       for (int k2 = 0; k2 < NSUB; ++k2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[k2][r] -= dsh;
-      m_ref = m_new;
-      if (hi == 0) qaux = aux_chunk<TM>(-m_ref, 1.0f);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[k2][r]);
+      mx = half_max(mx);
+      if (t == 0 || __any(mx > THRESH)) {                 // wave-uniform; after the first tile this is rare
+        float target = t == 0 ? mx : fmaxf(mx, 0.f);
+        if (!(target > -INFINITY)) target = 0.f;          // nothing but masked keys so far
+        if (O) target += OPT_MARGIN;
+        const float m_new = round_op<TM>(m_ref + target);
+        const float dsh = m_new - m_ref;
+        if (t > 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-dsh);    // dsh >= 0
+#pragma unroll
+          for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < NSUB; ++k2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[k2][r] -= dsh;
+        m_ref = m_new;
+        if (hi == 0) qaux = aux_chunk<TM>(-m_ref, 1.0f);
+      }
     }
 #pragma unroll
     for (int k2 = 0; k2 < NSUB; ++k2)
@@ -367,11 +388,24 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     if (t + 1 < ntile) store_tile((t + 1) & 1, (t + 1) * KEYS);
     __syncthreads();
   }
+  };
+
+  constexpr int LB = HD / 32, LR = ((HD % 32) / 8) * 4;
+  static_assert(HD % 32 == 0 || HD % 32 == 16, "ones row must sit at row 0 or 16 of its 32-row block");
+  if (OPT && !g_attn_exact_only) {
+    run(OptTag<true>{});
+    // the denominator of this lane's query (lane half 0 holds it) bounds every probability of the row: below 2^14 none of them
+    // reached the fp16 range (the converts SATURATE under MODE.FP16_OVFL, so an overflow would not show up as inf), and it is
+    // positive unless every probability flushed to zero -- otherwise the exact pass decides
+    const float lq = o[LB][LR];
+    const int bad = (hi == 0 && q < a.Lq && !(lq > 0.f && lq < 16384.f)) ? 1 : 0;
+    if (__syncthreads_or(bad)) run(OptTag<false>{});
+  } else {
+    run(OptTag<false>{});
+  }
 
   // ---- normalise and store O[q][h*HD + d]; lane holds d = dt*32 + 8*g + 4*hi + i.  The denominator is row HD of the
   // accumulator: block HD/32, register ((HD%32)/8)*4, lane half 0 -> broadcast to both halves
-  constexpr int LB = HD / 32, LR = ((HD % 32) / 8) * 4;
-  static_assert(HD % 32 == 0 || HD % 32 == 16, "ones row must sit at row 0 or 16 of its 32-row block");
   const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[LB][LR]), __float_as_uint(o[LB][LR]), false, false);
   const float l_tot = __uint_as_float(lsw[0]);
   const float inv = 1.0f / l_tot;
@@ -400,6 +434,7 @@ template <typename TM, int HD, int KEYS> static constexpr size_t attn_lds() {
 template <typename TM, int HD> static constexpr bool attn_has128() { return sizeof(TM) == 2 && HD <= 32; }
 static int g_force_keys = getenv("NS2VC_ATTN_KEYS") ? atoi(getenv("NS2VC_ATTN_KEYS")) : 0;   // test / tuning hook: 128 selects the 128-key kernels
 void set_forced_attn_keys(int keys) { g_force_keys = keys; }
+void set_attn_optimistic(int on) { const int v = on ? 0 : 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_exact_only), &v, sizeof(v)); }
 
 template <typename TM, int HD, int KEYS> static hipError_t launch_hdk(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Lq + 127) / 128) * a.H * a.B);

@@ -26,6 +26,7 @@ hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, 
 hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
 void set_rc_trace(unsigned long long* p);
+void set_attn_optimistic(int on);
 }
 
 namespace {
@@ -1625,6 +1626,10 @@ int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, flo
   HIPCHK(hipMalloc(&d, ws.size() * sizeof(float)));
   HIPCHK(hipMemcpy(d, ws.data(), ws.size() * sizeof(float), hipMemcpyHostToDevice));
   *out_dev = (float*)d;
+  return 0;
+}
+int ns2vc_debug_set_attn_optimistic(int on) {
+  set_attn_optimistic(on);
   return 0;
 }
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) {

@@ -733,6 +733,60 @@ def test_attention_reference_shift_extremes(prec, diag):
     assert e < (3e-5 if prec == 0 else 16 * eps16(prec)), e        # 16-bit: near one-hot softmax over rounded P / scaled Q
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+def test_attention_optimistic_pass_and_its_fallback(prec, diag):
+    """16-bit attention first runs an OPTIMISTIC pass (reference = first tile's maximum + a margin, no per-tile maximum) and
+    falls back to the exact pass when the denominator says a probability may have left the fp16 range (csrc/attn.hip OPT).
+    (a) ordinary logits: both passes are within the operand rounding of fp64 and of each other; (b) scores that grow by far
+    more than the margin along the keys, and a fully masked first tile: the optimistic result is rejected and the output is
+    BITWISE the exact pass's (ns2vc_debug_set_attn_optimistic(0) = exact pass only)."""
+    from ns2vc_amd._lib import AttnArgs, check
+    from ns2vc_amd.engine import sync
+    lib = _lib()
+    rng = np.random.default_rng(91)
+    B, H, hd, Lq, Lk = 2, 8, 16, 200, 333
+    D = H * hd
+    v = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    for case in ("ordinary", "growing", "masked_first_tile"):
+        q = rng.standard_normal((B, Lq, D)).astype(np.float32) * (1.0 if case != "growing" else 4.0)
+        k = rng.standard_normal((B, Lk, D)).astype(np.float32) * (1.0 if case != "growing" else 3.0)
+        if case == "growing":
+            k *= np.linspace(0.1, 3.0, Lk, dtype=np.float32)[None, :, None]
+        keep = np.ones((B, Lk), dtype=bool)
+        if case == "masked_first_tile":
+            keep[:, :64] = False
+            k[:, 64:] *= 6.0                                   # ... and what follows sits far from the reference the masked tile left
+            q *= 2.0
+        bias = np.where(keep, 0.0, -10000.0).astype(np.float32)
+        qr, kr, vr = (rnd(t, prec) for t in (q, k, v))
+        ref = ref_attention(qr, kr, vr, bias, H, prec)
+        a = AttnArgs()
+        d_q, d_kv, d_bias = OpBuf(q, prec), OpBuf(np.concatenate([k, v], axis=-1), prec), _dev(bias)
+        a.q, a.k, a.v = d_q.ptr, d_kv.ptr, d_kv.ptr + D * 2
+        a.ldq, a.ldk, a.ldv = D, 2 * D, 2 * D
+        a.B, a.H, a.Lq, a.Lk = B, H, Lq, Lk
+        a.bias = d_bias.ptr
+        a.scale = 1.0 / np.sqrt(hd)
+        outs = []
+        for opt in (1, 0):
+            d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
+            a.out, a.ldo = d_out.ptr, D
+            check(lib.ns2vc_debug_set_attn_optimistic(opt), "set_attn_optimistic")
+            try:
+                check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
+                sync()
+            finally:
+                lib.ns2vc_debug_set_attn_optimistic(1)
+            outs.append(d_out.read((B, Lq, D)))
+        e_opt, e_exact, same = rel_l2(outs[0], ref), rel_l2(outs[1], ref), np.array_equal(outs[0], outs[1])
+        diag(f"attn optimistic pass prec={prec} {case}: default {e_opt:.3e} exact-only {e_exact:.3e} vs fp64; bitwise equal = {same}")
+        assert np.isfinite(outs[0]).all() and np.isfinite(outs[1]).all()
+        tol = 16 * eps16(prec) if case != "ordinary" else 2 * eps16(prec)
+        assert e_opt < tol and e_exact < tol
+        if case != "ordinary" and prec == 2:
+            assert same                                         # fp16: the check rejected the optimistic pass in every workgroup
+
+
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("shape", [(2, 37, 128, 0), (2, 90, 512, 384), (3, 200, 384, 256), (1, 5, 128, 128), (2, 938, 128, 0)], ids=str)
 def test_groupnorm(shape, prec, diag):
