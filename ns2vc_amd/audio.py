@@ -11,8 +11,9 @@
   window, reflect padding, magnitude spectrum, HTK mel scale, no filter normalisation, f_min 0, f_max sr/2) on
   ``torch.stft`` -- **parity unpinned** against torchaudio itself; tests check it against an independent numpy DFT.
 
-The vocoder (``vocos.decode``, ``model.py:689-691``) and the ContentVec / f0 extractors are third-party models outside the
-reference tree; they plug in as ``decode_fn`` / as the producer of ``Segment.content`` (ns2vc_amd/service.py).
+The vocoder (``vocos.decode``, ``model.py:689-691``) and the ContentVec extractor are third-party models outside the
+reference tree; their published architectures are restated in ``vocoder.py`` / ``contentvec.py`` (parity unpinned) and plug in
+as ``decode_fn`` / as the producer of ``Segment.content`` (ns2vc_amd/service.py).
 """
 from __future__ import annotations
 

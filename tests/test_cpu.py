@@ -543,3 +543,53 @@ def test_vocos_decoder_restatement_shapes_keys_and_inverse_stft():
         env[256 * t: 256 * t + 1024] += win ** 2
     want = (want / np.maximum(env, 1e-11))[:, 512: n - 512]
     assert got.shape == want.shape and rel_l2(got, want) < 1e-4
+
+
+def test_contentvec_restatement_shapes_names_and_pieces():
+    """ns2vc_amd/contentvec.py restates the HuBERT-base / ContentVec encoder the reference loads through fairseq (utils.py:209-236;
+    parity unpinned: neither fairseq nor the checkpoint exists offline).  What CAN be pinned here: the frame arithmetic (hop 320,
+    receptive field 400 -> 50 Hz), the published parameter count and fairseq's key names, the weight-norm reconstruction of
+    pos_conv against torch's own weight_norm, the attention against torch's multi_head_attention_forward, and the output shape."""
+    import torch
+    import torch.nn.functional as F
+    from ns2vc_amd.contentvec import ContentVec, PosConv, SelfAttention
+    torch.manual_seed(0)
+    m = ContentVec().eval()
+    assert ContentVec.frames_for(16000) == 49 and ContentVec.frames_for(400) == 1 and ContentVec.frames_for(160000) == 499
+    sd = m.state_dict()
+    assert sum(v.numel() for v in sd.values()) == 94_567_808
+    for k, shape in {"feature_extractor.conv_layers.0.0.weight": (512, 1, 10), "feature_extractor.conv_layers.0.2.weight": (512,),
+                     "feature_extractor.conv_layers.6.0.weight": (512, 512, 2), "layer_norm.weight": (512,), "post_extract_proj.weight": (768, 512),
+                     "encoder.pos_conv.0.weight_g": (1, 1, 128), "encoder.pos_conv.0.weight_v": (768, 48, 128), "encoder.pos_conv.0.bias": (768,),
+                     "encoder.layers.11.self_attn.q_proj.weight": (768, 768), "encoder.layers.0.fc1.weight": (3072, 768),
+                     "encoder.layers.5.final_layer_norm.bias": (768,), "encoder.layer_norm.weight": (768,), "final_proj.weight": (256, 768)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    norms = [k for k in sd if k.startswith("feature_extractor.conv_layers.") and k.split(".")[3] == "2"]
+    assert norms == ["feature_extractor.conv_layers.0.2.weight", "feature_extractor.conv_layers.0.2.bias"]      # only the first conv block carries a norm
+    # a fairseq-style state dict (with the pre-training leftovers) loads; a missing key is an error
+    full = dict(sd, mask_emb=torch.zeros(768), label_embs_concat=torch.zeros(504, 256))
+    m.load_fairseq_state_dict(full)
+    with pytest.raises(RuntimeError):
+        m.load_fairseq_state_dict({k: v for k, v in full.items() if k != "final_proj.bias"})
+    # weight normalisation over dim 2, as fairseq builds it
+    pc = PosConv()
+    ref = torch.nn.utils.weight_norm(torch.nn.Conv1d(768, 768, 128, padding=64, groups=16), name="weight", dim=2)
+    with torch.no_grad():
+        ref.weight_g.copy_(torch.rand_like(ref.weight_g) + 0.5); ref.weight_v.copy_(torch.randn_like(ref.weight_v))
+        pc.weight_g.copy_(ref.weight_g); pc.weight_v.copy_(ref.weight_v); pc.bias.copy_(ref.bias)
+        x = torch.randn(2, 768, 37)
+        assert torch.allclose(pc(x), F.gelu(ref(x)[:, :, :-1]), atol=1e-5)
+    # the attention block against torch's reference implementation with separate projection weights
+    sa = SelfAttention(768, 12).eval()
+    with torch.no_grad():
+        x = torch.randn(2, 29, 768)
+        want, _ = F.multi_head_attention_forward(
+            x.transpose(0, 1), x.transpose(0, 1), x.transpose(0, 1), 768, 12, None, torch.cat([sa.q_proj.bias, sa.k_proj.bias, sa.v_proj.bias]),
+            None, None, False, 0.0, sa.out_proj.weight, sa.out_proj.bias, training=False, need_weights=False, use_separate_proj_weight=True,
+            q_proj_weight=sa.q_proj.weight, k_proj_weight=sa.k_proj.weight, v_proj_weight=sa.v_proj.weight)
+        assert torch.allclose(sa(x), want.transpose(0, 1), atol=2e-5)
+        # end to end: (B, samples) -> (B, 256, frames), batched == one by one
+        wav = torch.randn(2, 8000) * 0.1
+        y = m.extract(wav)
+        assert y.shape == (2, 256, ContentVec.frames_for(8000)) and torch.isfinite(y).all()
+        assert torch.allclose(m.extract(wav[1]), y[1:2], atol=1e-4)

@@ -232,3 +232,48 @@ def test_pipeline_end_to_end_with_the_vocoder_stage(pre_model, diag):
     diag("end-to-end WITH the vocoder stage (32 x 10 s, 20-step UniPC; Vocos restatement, procedural weights, parity unpinned): " +
          "; ".join(f"{k}: vocoder alone {v[0]:.1f} ms/batch, sequential {v[1]:.1f}, three streams {v[2]:.1f} ms/batch (RTF {v[3]:.2e})" for k, v in res.items()))
     assert res["fp32"][2] < 1.3 * res["fp32"][1]
+
+
+@pytest.mark.gpu
+def test_content_encoder_stage_from_waveform_to_sampled_latent(pre_model, diag):
+    """The stage in FRONT of the conditioning front end: 16 kHz waveform -> ContentVec / HuBERT-base features (ns2vc_amd/contentvec.py:
+    restated architecture, random weights, parity unpinned) -> repeat_expand_2d to the latent frame count (infer_tool.py:163-166)
+    -> Pre_model.infer -> denoiser.  Checks the frame arithmetic on the device, that batched == per-utterance extraction, that the
+    16-bit autocast stays close, that the result drives the rest of the path to a finite latent, and reports what the stage costs."""
+    import torch
+    from ns2vc_amd.contentvec import ContentVec
+    from ns2vc_amd.pipeline import Denoiser
+    from ns2vc_amd.weights import procedural_state_dict
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    enc = ContentVec().eval().to(dev)
+    B, T, Lp, steps = 8, 938, 469, 4
+    g = torch.Generator(device=dev).manual_seed(11)
+    wav = 0.1 * torch.randn((B, 160000), device=dev, generator=g)                      # 10 s at 16 kHz
+    feats = enc.extract(wav)
+    assert feats.shape == (B, 256, ContentVec.frames_for(160000)) == (B, 256, 499) and torch.isfinite(feats).all()
+    one = enc.extract(wav[3])
+    e_batch = float((one - feats[3:4]).norm() / feats[3:4].norm())
+    f16 = enc.extract(wav, autocast=torch.float16)
+    e_f16 = float((f16 - feats).norm() / feats.norm())
+    c = enc.content(wav, T)
+    assert c.shape == (B, 256, T)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        enc.content(wav, T, autocast=torch.float16)
+    torch.cuda.synchronize()
+    ms16 = (time.perf_counter() - t0) / 3 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        enc.content(wav, T)
+    torch.cuda.synchronize()
+    ms32 = (time.perf_counter() - t0) / 3 * 1e3
+    refer = torch.randn((B, 100, Lp), device=dev, generator=g)
+    lengths, rlens = torch.full((B,), T, device=dev), torch.full((B,), Lp, device=dev)
+    content, prompt, mask = pre_model.infer(c, refer, lengths, rlens)
+    den = Denoiser(procedural_state_dict(seed=0))
+    lat = den.sample(content, prompt, mask, torch.randn((B, 100, T), device=dev, generator=g), solver="unipc", steps=steps)
+    diag(f"content encoder stage: {B} x 10 s -> {tuple(feats.shape)}; batched vs single {e_batch:.1e}; fp16 autocast {e_f16:.1e}; "
+         f"{ms32:.1f} ms fp32 / {ms16:.1f} ms fp16 autocast per batch of {B}; latent finite {bool(torch.isfinite(lat).all())}")
+    assert e_batch < 1e-4 and e_f16 < 2e-2 and torch.isfinite(lat).all()
