@@ -38,6 +38,15 @@ class Segment:
     tag: object = None
 
 
+def segment_from_audio(content_encoder, wav16k: torch.Tensor, samples_at_target_rate: int, refer_mel: torch.Tensor, hop: int = 256,
+                       tag: object = None, autocast=None) -> Segment:
+    """``Svc.get_unit_f0_code`` minus the file I/O (``infer_tool.py:141-182``): the 16 kHz copy of ONE source segment -> ContentVec
+    features (``ns2vc_amd.contentvec.ContentVec`` or anything with its ``content(wav16k, frames)``) stretched to the segment's latent
+    frame count ``len(wav at 24 kHz) // hop`` (what the reference takes from its f0 track, ``utils.py:160``), plus the prompt mel."""
+    frames = int(samples_at_target_rate) // hop
+    return Segment(content=content_encoder.content(wav16k, frames, autocast=autocast)[0], refer=refer_mel, tag=tag)
+
+
 class GroupedConverter:
     def __init__(self, pre_model: PreModel, denoiser: Denoiser, decode_fn: Optional[Callable] = None, max_batch: int = 32,
                  solver: str = "unipc", steps: int = 30, order: int = 2, seed: int = 1234):

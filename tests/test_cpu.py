@@ -593,3 +593,7 @@ def test_contentvec_restatement_shapes_names_and_pieces():
         y = m.extract(wav)
         assert y.shape == (2, 256, ContentVec.frames_for(8000)) and torch.isfinite(y).all()
         assert torch.allclose(m.extract(wav[1]), y[1:2], atol=1e-4)
+        # the converter's unit of work straight from audio: 0.5 s at 24 kHz = 12000 samples -> 46 latent frames
+        from ns2vc_amd.service import segment_from_audio
+        seg = segment_from_audio(m, wav[0], 12000, torch.zeros(100, 40), tag="a")
+        assert seg.content.shape == (256, 12000 // 256) and seg.refer.shape == (100, 40) and seg.tag == "a"
