@@ -938,8 +938,9 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
       bn = 128; st = 13;
       bm = (big_m && nk >= 12) ? 128 : 64;
       // loader / consumer waves where the tile was 64 rows anyway, and instead of the 128-row tiles of the coarse levels (one
-      // workgroup per CU either way); the 128-row tiles of levels 0-1 stay (per-launch table in profiles/r03_gemm_spec.txt)
+      // workgroup per CU either way; per-launch table in profiles/r03_gemm_spec.txt)
       if (g_spec && nk >= 4 && (bm == 64 || g.M < 12000)) { bm = 64; st = 23; }
+      else if (g_spec && bm == 128) st = 23;                               // ... and the 128-row tiles of levels 0-1 keep their shape, specialised (-0.8 % family, same-box)
       if (g.M >= 12000 && g.N > 128 && nk <= 2) { bm = 128; st = 12; }     // level-0 q|k|v: short K, wide-ish N
     } else if (n128) {
       bn = 128;
