@@ -149,8 +149,9 @@ struct ns2vc_unet {
   // GroupNorm-apply as the prologue of the GEMM that consumes it (gemm.hip gn_prologue, ns2vc_gemm_args.gnp_*) wherever the norm has
   // one source, one consumer and epilogue statistics: resnet norm2 -> conv2, norm1 -> conv1 of the resnets without a
   // shortcut, the transformer norm in front of a plain proj_in, conv_norm_out -> conv_out.  Bit-identical to the gn_apply
-  // launches it removes.  NS2VC_FUSE_GN_GEMM=0 restores them.
-  bool fuse_gn_gemm = false;   // (experiment: not run-to-run deterministic at the bench shapes, profiles/r03_gn_prologue_experiment.txt)
+  // launches it removes (210 -> 174 launches at the bench shape).  NS2VC_FUSE_GN_GEMM=0 restores them.  (r3 had this off: not
+  // run-to-run deterministic; root cause and fix in r4, profiles/r04_gn_prologue_rootcause.txt.)
+  bool fuse_gn_gemm = true;
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -730,7 +731,7 @@ struct Planner {
     const long long* st0 = find_stats(a0);
     const long long* st1 = a1 ? find_stats(a1) : nullptr;
     const bool epi = st0 && (!a1 || st1) && (((c0 + c1) / Gq) % 16 == 0) && (c0 % 16 == 0);
-    if (epi && h->fuse_gn_gemm && consumer_n > 0 && (consumer_n % 128) == 0 && !a1 && !raw && Tl >= 130 && c0 <= 512 && (c0 % Gq) == 0 &&
+    if (epi && h->fuse_gn_gemm && consumer_n > 0 && (consumer_n % 128) == 0 && !a1 && !raw && Tl >= 66 && c0 <= 512 && (c0 % Gq) == 0 &&
         Gq <= 8 && (lda0 & 3) == 0) {
       GnPro p;
       p.x = a0; p.ldx = lda0; p.st = st0; p.gamma = gamma; p.beta = beta; p.temb = temb ? temb + temb_off : nullptr; p.ldtemb = ldt;

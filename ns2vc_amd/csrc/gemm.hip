@@ -626,7 +626,7 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #define NS2VC_G4_FLAG(b) false
 #endif
 // ---------------------------------------------------------------------------
-// GroupNorm-apply prologue (r3; GemmArgs.gnp_*).  The step had 51 gn_apply launches whose only job is to turn fp32 rows into
+// GroupNorm-apply prologue (built in r3, shipped in r4; GemmArgs.gnp_*).  The step had 51 gn_apply launches whose only job is to turn fp32 rows into
 // the operand rows ONE following GEMM reads.  A consumer-side fusion that normalises while it loads (r1 conv3gn) pays the
 // normalisation once per tap and column tile on the MFMA waves' critical path; a producer-side fusion needs the whole-item
 // statistic (r2 gn_producer, r3 convgn).  This one keeps the K loop and its LDS-DMA untouched: every workgroup first
@@ -636,18 +636,6 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 // column tiles of one row panel are produced redundantly with identical bytes (no ordering between workgroups needed; the
 // XCD-aware tile mapping keeps a row panel's column tiles on one L2, so the repeated fp32 reads hit it).
 // ---------------------------------------------------------------------------
-#ifndef NS2VC_GNP_PLAIN_STORES
-#define NS2VC_GNP_PLAIN_STORES 0
-#endif
-#ifndef NS2VC_GNP_DETECT
-#define NS2VC_GNP_DETECT 0
-#endif
-#ifndef NS2VC_GNP_FIX
-#define NS2VC_GNP_FIX 0
-#endif
-#if NS2VC_GNP_DETECT
-__device__ unsigned g_gnp_dbg[8 + 20 * 12];      // [0] lanes whose gamma changed between the counted wait and a later read; records from [8]
-#endif
 template <typename TM>
 __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, int tid, int nth, char* smem) {
   const int C = g.c0, T = g.Tin, G = g.gnp_G, Cg = C / G;
@@ -662,18 +650,10 @@ __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, i
   float4 ga, be, t1[3], t2[3];
 #pragma unroll
   for (int bi = 0; bi < 3; ++bi) t1[bi] = t2[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef NS2VC_GNP_E1
-#define NS2VC_GNP_E1 0
-#endif
-#ifndef NS2VC_GNP_XB
-#define NS2VC_GNP_XB 6
-#endif
-  constexpr int XB = NS2VC_GNP_XB;                                          // rows in flight per thread
+  constexpr int XB = 6;                                                     // rows in flight per thread (1: no gain in the loop, 6: -1 %)
   float4 xb[XB];
   const int r0 = rlo + rlane;
-  // (every lane loads, from a clamped row: predicated loads + zero fills of a batch made this prologue non-deterministic at
-  //  the bench shapes -- single 16-lane passes of a loaded register read back as zero, tools/gnp_probe.py -- a straight-line
-  //  batch of plain loads does not)
+  // (every lane loads, from a clamped row: a straight-line batch of plain loads)
   const int cq = active ? c : 0;
   auto fetch = [&](int rb) __attribute__((always_inline)) {
 #pragma unroll
@@ -683,9 +663,6 @@ __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, i
     }
   };
   fetch(r0);                                                                // first batch in flight under the finalisation
-#if NS2VC_GNP_E1
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
   // (after the loads above: they are in flight while wave 0 walks this chain of dependent loads and double arithmetic)
   if (tid < nbi * G) {                                                      // same finalisation as gn_apply_kernel (misc.hip)
     const int bi = tid / G, gg = tid - bi * G;
@@ -705,38 +682,8 @@ __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, i
   }
   __syncthreads();
   // (unconditional loads, no zero defaults: inactive threads read column 0)
-#if NS2VC_GNP_DETECT == 1
-  {  // root-cause instrumentation (r4): gamma / beta go through fixed registers; gamma is read right after the counted wait the
-     // compiler had placed there (vmcnt(1): beta may still be out), then again after a sleep.  The early value is what the kernel
-     // uses (= the failing build's behaviour); every lane whose early and late values differ is recorded in g_gnp_dbg.
-    unsigned e0[4], e1[4];
-    asm volatile("v_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\tv_mov_b32 v122, 0\n\tv_mov_b32 v123, 0\n\t"
-                 "global_load_dwordx4 v[120:123], %8, off\n\tglobal_load_dwordx4 v[124:127], %9, off\n\ts_waitcnt vmcnt(1)\n\t"
-                 "v_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\tv_mov_b32 %2, v122\n\tv_mov_b32 %3, v123\n\ts_sleep 8\n\t"
-                 "v_mov_b32 %4, v120\n\tv_mov_b32 %5, v121\n\tv_mov_b32 %6, v122\n\tv_mov_b32 %7, v123\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(e0[0]), "=&v"(e0[1]), "=&v"(e0[2]), "=&v"(e0[3]), "=&v"(e1[0]), "=&v"(e1[1]), "=&v"(e1[2]), "=&v"(e1[3])
-                 : "v"(g.gnp_gamma + cq), "v"(g.gnp_beta + cq)
-                 : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
-    unsigned b[4];
-    asm volatile("v_mov_b32 %0, v124\n\tv_mov_b32 %1, v125\n\tv_mov_b32 %2, v126\n\tv_mov_b32 %3, v127" : "=v"(b[0]), "=v"(b[1]), "=v"(b[2]), "=v"(b[3]) :: "v124", "v125", "v126", "v127");
-    ga = make_float4(__uint_as_float(e0[0]), __uint_as_float(e0[1]), __uint_as_float(e0[2]), __uint_as_float(e0[3]));
-    be = make_float4(__uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3]));
-    if (e0[0] != e1[0] || e0[1] != e1[1] || e0[2] != e1[2] || e0[3] != e1[3]) {
-      const unsigned slot = atomicAdd(&g_gnp_dbg[0], 1u);
-      if (slot < 20) {
-        unsigned* r = g_gnp_dbg + 8 + slot * 12;
-        r[0] = blockIdx.x; r[1] = tid; r[2] = (unsigned)cq; r[3] = (unsigned)m0;
-        for (int e = 0; e < 4; ++e) { r[4 + e] = e0[e]; r[8 + e] = e1[e]; }
-      }
-    }
-  }
-#else
   ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);
   be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
-#if NS2VC_GNP_FIX == 1
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");          // full wait + 16 wait states before the first read
-#endif
-#endif
   if (g.gnp_temb) {
 #pragma unroll
     for (int bi = 0; bi < 3; ++bi) {
@@ -755,68 +702,23 @@ __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, i
     float sc[3][4], sh[3][4];
     const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
     float2 mrs[3];
-#if NS2VC_GNP_DETECT == 2 || NS2VC_GNP_DETECT == 3
-    {  // second instrumentation (r4): the three (mean, rstd) reads through fixed registers; the FIRST pair is consumed right after
-       // the counted wait the compiler had placed there (lgkmcnt(2): the other two may still be out) and again after a sleep.
-       // DETECT 2 snapshots the registers with v_mov_b32, DETECT 3 with the packed multiply the compiler used (op_sel:[0,1]).
-      const unsigned a0 = (unsigned)(size_t)(gtab + min(0, nbi - 1) * 8 + gg), a1 = (unsigned)(size_t)(gtab + min(1, nbi - 1) * 8 + gg),
-                     a2 = (unsigned)(size_t)(gtab + min(2, nbi - 1) * 8 + gg);
-      unsigned e0[2], e1[2], o[4];
-#if NS2VC_GNP_DETECT == 2
-      asm volatile("v_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\t"
-                   "ds_read_b64 v[120:121], %8\n\tds_read_b64 v[122:123], %9\n\tds_read_b64 v[124:125], %10\n\ts_waitcnt lgkmcnt(2)\n\t"
-                   "v_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\ts_sleep 8\n\tv_mov_b32 %2, v120\n\tv_mov_b32 %3, v121\n\ts_waitcnt lgkmcnt(0)\n\t"
-                   "v_mov_b32 %4, v122\n\tv_mov_b32 %5, v123\n\tv_mov_b32 %6, v124\n\tv_mov_b32 %7, v125"
-                   : "=&v"(e0[0]), "=&v"(e0[1]), "=&v"(e1[0]), "=&v"(e1[1]), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
-                   : "v"(a0), "v"(a1), "v"(a2) : "memory", "v120", "v121", "v122", "v123", "v124", "v125");
-      mrs[0] = make_float2(__uint_as_float(e0[0]), __uint_as_float(e0[1]));
-#else
-      // v[126:127] = (1.0, 1.0): the packed product with op_sel:[0,1] returns (rstd, rstd) -- early and late
-      asm volatile("v_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\tv_mov_b32 v126, 1.0\n\tv_mov_b32 v127, 1.0\n\t"
-                   "ds_read_b64 v[120:121], %8\n\tds_read_b64 v[122:123], %9\n\tds_read_b64 v[124:125], %10\n\ts_waitcnt lgkmcnt(2)\n\t"
-                   "v_pk_mul_f32 v[128:129], v[126:127], v[120:121] op_sel:[0,1]\n\ts_sleep 8\n\t"
-                   "v_pk_mul_f32 v[130:131], v[126:127], v[120:121] op_sel:[0,1]\n\ts_waitcnt lgkmcnt(0)\n\t"
-                   "v_mov_b32 %0, v128\n\tv_mov_b32 %1, v129\n\tv_mov_b32 %2, v130\n\tv_mov_b32 %3, v131\n\t"
-                   "v_mov_b32 %4, v122\n\tv_mov_b32 %5, v123\n\tv_mov_b32 %6, v124\n\tv_mov_b32 %7, v125"
-                   : "=&v"(e0[0]), "=&v"(e0[1]), "=&v"(e1[0]), "=&v"(e1[1]), "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
-                   : "v"(a0), "v"(a1), "v"(a2)
-                   : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131");
-      { float mean0; asm volatile("v_mov_b32 %0, v120" : "=v"(mean0) :: "v120"); mrs[0] = make_float2(mean0, __uint_as_float(e0[0])); }
-#endif
-      mrs[1] = make_float2(__uint_as_float(o[0]), __uint_as_float(o[1]));
-      mrs[2] = make_float2(__uint_as_float(o[2]), __uint_as_float(o[3]));
-      if (e0[0] != e1[0] || e0[1] != e1[1]) {
-        const unsigned slot = atomicAdd(&g_gnp_dbg[0], 1u);
-        if (slot < 20) {
-          unsigned* r = g_gnp_dbg + 8 + slot * 12;
-          r[0] = blockIdx.x; r[1] = tid; r[2] = (unsigned)cq; r[3] = (unsigned)m0;
-          r[4] = e0[0]; r[5] = e0[1]; r[6] = 0; r[7] = 0; r[8] = e1[0]; r[9] = e1[1]; r[10] = 0; r[11] = 0;
-        }
-      }
-    }
-#else
 #pragma unroll
     for (int bi = 0; bi < 3; ++bi) mrs[bi] = gtab[min(bi, nbi - 1) * 8 + gg];
-#if NS2VC_GNP_FIX == 2
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // every (mean, rstd) pair has landed before the first one is used
+    // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
+    //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
+    // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
+    // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
+    // "gamma reads zero" non-determinism of round 3.  With every (mean, rstd) pair landed before the first packed product the
+    // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(mrs[0].x), "+v"(mrs[0].y), "+v"(mrs[1].x), "+v"(mrs[1].y), "+v"(mrs[2].x), "+v"(mrs[2].y));
-#endif
-#endif
 #pragma unroll
     for (int bi = 0; bi < 3; ++bi) {
       const float2 mr = mrs[bi];
       const float ts[4] = {t1[bi].x, t1[bi].y, t1[bi].z, t1[bi].w}, tf[4] = {t2[bi].x, t2[bi].y, t2[bi].z, t2[bi].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-#if NS2VC_GNP_FIX == 3      // no op_sel crossing: rstd in a register of its own (the other (mean, rstd) reads stay outstanding)
-        float ry = mr.y;
-        if (e == 0) asm volatile("" : "+v"(ry));
-        sc[bi][e] = ry * gam[e];
-#elif NS2VC_GNP_FIX == 4    // scalar products through inline asm: no packed fp32 instruction can be formed from them
-        asm("v_mul_f32 %0, %1, %2" : "=v"(sc[bi][e]) : "v"(mr.y), "v"(gam[e]));
-#else
         sc[bi][e] = mr.y * gam[e];
-#endif
         sh[bi][e] = bet[e] - mr.x * sc[bi][e];
         if (g.gnp_temb) {
           const float s1 = 1.0f + ts[e];
@@ -825,21 +727,6 @@ __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, i
         }
       }
     }
-#if NS2VC_GNP_DETECT == 4
-    if (!g.gnp_temb) {   // third instrumentation (r4): the compiler's (packed) products against scalar products of the SAME registers, taken after a full wait
-      float chk[4];
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 4\n\tv_mul_f32 %0, %4, %8\n\tv_mul_f32 %1, %5, %8\n\tv_mul_f32 %2, %6, %8\n\tv_mul_f32 %3, %7, %8"
-                   : "=&v"(chk[0]), "=&v"(chk[1]), "=&v"(chk[2]), "=&v"(chk[3]) : "v"(gam[0]), "v"(gam[1]), "v"(gam[2]), "v"(gam[3]), "v"(mrs[0].y));
-      if (chk[0] != sc[0][0] || chk[1] != sc[0][1] || chk[2] != sc[0][2] || chk[3] != sc[0][3]) {
-        const unsigned slot = atomicAdd(&g_gnp_dbg[0], 1u);
-        if (slot < 20) {
-          unsigned* r = g_gnp_dbg + 8 + slot * 12;
-          r[0] = blockIdx.x; r[1] = tid; r[2] = __float_as_uint(mrs[0].y); r[3] = __float_as_uint(gam[0]);
-          for (int e = 0; e < 4; ++e) { r[4 + e] = __float_as_uint(sc[0][e]); r[8 + e] = __float_as_uint(chk[e]); }
-        }
-      }
-    }
-#endif
     TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
     for (int rb = r0; rb < rhi; rb += XB * rl) {
       float4 w[XB];
@@ -856,11 +743,7 @@ __device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, i
           for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
           float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
           if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-#if NS2VC_GNP_PLAIN_STORES
-          store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
-#else
           out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
-#endif
         }
       }
     }
@@ -1037,22 +920,17 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
   const int nk = g.K / BKE;
   NS2VC_STAMP(1);
   const bool gnp = g.gnp_x != nullptr;             // (uniform over the grid)
-#ifndef NS2VC_GNP_EARLY_B
-#define NS2VC_GNP_EARLY_B 1
-#endif
   if (gnp) {
     // the weight tiles do not depend on the prologue: in flight first, then the rows this tile reads are built (the table of
     // the prologue lives in the ring stage nobody has been issued into yet), then their DMA
-#if NS2VC_GNP_EARLY_B
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
       if (s < nk) issue_b(s, s);
-#endif
     gn_prologue<TM>(g, m0, BM, tid, 64 * NW, smem + (STAGES - 1) * STAGE);
   }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_tile(s, !(gnp && NS2VC_GNP_EARLY_B));
+    if (s < nk) issue_tile(s, !gnp);
   NS2VC_STAMP(2);
 
   const int l31 = lane & 31, hi = lane >> 5;
@@ -1063,7 +941,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 #endif
   for (int kt = 0; kt < nk; ++kt) {
     const int after = min(STAGES - 2, nk - 1 - kt);
-    if (kt == 0 && gnp && NS2VC_GNP_EARLY_B) {            // issue order was B(0) B(1) .. A(0) A(1) ..: tile 0 is complete when only the later A halves are out
+    if (kt == 0 && gnp) {            // issue order was B(0) B(1) .. A(0) A(1) ..: tile 0 is complete when only the later A halves are out
       if (STAGES == 3 && after >= 1) wait_vmcnt<LA>(); else wait_vmcnt<0>();
     } else if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
     else if (STAGES >= 3 && after >= 1) wait_vmcnt<LPT>();
@@ -1255,7 +1133,7 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
   if (g.gnp_x) {     // GroupNorm-apply prologue: one source, same-length rows, whole 16-channel blocks per group, <= 3 batch items per tile + halo
     if (g.c1 || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 512 || (g.c0 & 3) || !g.gnp_stats || !g.gnp_gamma ||
-        !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (g.c0 % g.gnp_G) || ((g.c0 / g.gnp_G) & 15) || g.Tin < 130 || (g.gnp_ldx & 3) || (g.lda0 & 3))
+        !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (g.c0 % g.gnp_G) || ((g.c0 / g.gnp_G) & 15) || g.Tin < 66 || (g.gnp_ldx & 3) || (g.lda0 & 3))
       return hipErrorInvalidValue;
   }
   {   // the DMA addresses rows by 32-bit byte offsets from each tensor's base: every operand must stay below 4 GB
@@ -1310,13 +1188,3 @@ hipError_t init_gemm_attributes() {
 }
 
 }  // namespace ns2vc
-
-#if NS2VC_GNP_DETECT
-extern "C" int ns2vc_debug_gnp_dump(unsigned* host, int n) {      // experiment builds only: read and clear the detector's records
-  using namespace ns2vc;
-  if (n > 8 + 20 * 12) n = 8 + 20 * 12;
-  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gnp_dbg), n * sizeof(unsigned)) != hipSuccess) return 1;
-  static unsigned zero[8 + 20 * 12];
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_gnp_dbg), zero, sizeof(zero)) == hipSuccess ? 0 : 1;
-}
-#endif

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""GroupNorm prologue of the GEMM at the bench shapes, repeated: fused launch vs ns2vc_k_groupnorm_stats + GEMM, bit for bit (GPU box)."""
+"""The in-situ repro of round 3's non-deterministic GroupNorm prologue (profiles/r04_gn_prologue_rootcause.txt): the fused launch at the bench
+shape, repeated, against ns2vc_k_groupnorm_stats + the same GEMM, bit for bit (GPU box).  22 of 22 launches failed before the r4 fix; the
+instrumented variants it was run on (NS2VC_GNP_DETECT / NS2VC_GNP_FIX builds) are in the history at commit 4fc9071."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
