@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NS2VC_ABI_VERSION 3
+#define NS2VC_ABI_VERSION 4
 #define NS2VC_MAX_LEVELS 8
 #define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
 
@@ -194,6 +194,18 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   float* rowstats;
   const float* ln_stats; const float* ln_wsum; float ln_eps; int32_t ln_dim;
   unsigned* ln_health;            /* optional (consumer): atomicMax of the bits of |mean| * rstd over the rows, or NULL */
+  /* optional GroupNorm-apply prologue (ABI v4; replaces a separate ns2vc_k_groupnorm launch in front of this GEMM, the
+   * `group_norm` (+ time scale/shift) (+ SiLU) of resnet.py:606-629 / transformer_1d.py:268): when gnp_x != NULL every
+   * workgroup FIRST writes act(GroupNorm(gnp_x)) for exactly the rows its tile will read (its output rows, plus one row
+   * either side for taps == 3) into a0 -- same arithmetic as ns2vc_k_groupnorm, bit-identical rows -- and then runs as
+   * usual, reading them back through its own L2.  a0 must be writable; c1 == 0, tmode == 0, Tin == Tout, N % 128 == 0,
+   * c0 <= 512, (c0 / gnp_G) % 16 == 0, gnp_G <= 8, Tin >= 130.  gnp_x fp32 [B*Tin][gnp_ldx]; gnp_stats = int64
+   * [B][c0/16][2] as left by a producer's `stats`; gnp_gamma / gnp_beta [c0]; gnp_temb (or NULL) points at row 0 of the
+   * per-item (scale | shift) pairs: scale at [b*gnp_ldtemb + c], shift at [b*gnp_ldtemb + c0 + c]. */
+  const float* gnp_x; int32_t gnp_ldx;
+  const long long* gnp_stats; const float* gnp_gamma; const float* gnp_beta;
+  const float* gnp_temb; int32_t gnp_ldtemb;
+  float gnp_eps; int32_t gnp_G, gnp_silu;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {
@@ -280,6 +292,10 @@ int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, voi
 int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
                       const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off, int silu,
                       void* out_op, void* raw_op, int precision, void* stream);
+/* the engine's form of the same launch: statistics = the int64 fixed-point sums a producer GEMM's epilogue left
+ * (ns2vc_gemm_args.stats, [B][c0/16][2]); one source, asynchronous on `stream`.  What ns2vc_gemm_args.gnp_* reproduces bit for bit. */
+int ns2vc_k_groupnorm_stats(const float* a0, int lda0, int c0, const long long* stats0, int B, int T, int G, float eps, const float* gamma,
+                            const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, int precision, void* stream);
 /* LayerNorm without affine (gamma/beta are folded into the consumer's weights): fp32 rows -> operand rows */
 int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream);
 int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream);

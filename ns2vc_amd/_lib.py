@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
 NCOEF = 12
 MAX_LEVELS = 8
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Ns2vcError(RuntimeError):
@@ -46,6 +46,10 @@ class GemmArgs(C.Structure):
         ("rowstats", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_wsum", C.c_void_p), ("ln_eps", C.c_float), ("ln_dim", C.c_int32),
         ("ln_health", C.c_void_p),
+        ("gnp_x", C.c_void_p), ("gnp_ldx", C.c_int32),
+        ("gnp_stats", C.c_void_p), ("gnp_gamma", C.c_void_p), ("gnp_beta", C.c_void_p),
+        ("gnp_temb", C.c_void_p), ("gnp_ldtemb", C.c_int32),
+        ("gnp_eps", C.c_float), ("gnp_G", C.c_int32), ("gnp_silu", C.c_int32),
     ]
 
 
@@ -158,6 +162,7 @@ PROTOTYPES = {
     "ns2vc_debug_set_rowchain_tokens": (_I, [_I]),
     "ns2vc_debug_set_attn_keys": (_I, [_I]),
     "ns2vc_debug_set_attn_optimistic": (_I, [_I]),
+    "ns2vc_k_groupnorm_stats": (_I, [_P, _I, _I, _P, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),

@@ -146,6 +146,12 @@ struct ns2vc_unet {
   bool attn_fp8 = false;     // PV product of every attention on the fp8 MFMA (16-bit precisions; BASELINE config 5's fp8 path; costs parity)
   bool fuse_ffn_pre = true;  // attn2.to_out + residual computed inside the fused feed-forward kernel
   bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
+  // GroupNorm-apply as the prologue of the GEMM that consumes it (gemm.hip gn_prologue, ns2vc_gemm_args.gnp_*) wherever the norm has
+  // one source, one consumer and epilogue statistics: resnet norm2 -> conv2, norm1 -> conv1 of the resnets without a
+  // shortcut, the transformer norm in front of a plain proj_in, conv_norm_out -> conv_out.  Bit-identical to the gn_apply
+  // launches it removes (210 -> 174 launches at the bench shape).  NS2VC_FUSE_GN_GEMM=0 restores them.  (r3 had this off: not
+  // run-to-run deterministic; root cause and fix in r4, profiles/r04_gn_prologue_rootcause.txt.)
+  bool fuse_gn_gemm = true;
   unsigned* ln_health = nullptr;
   std::vector<Tap> taps;
   bool has_mask = false;
@@ -688,7 +694,9 @@ struct Planner {
     const double in_rows = (double)g.B * g.Tin;
     const double bytes = in_rows * (g.c0 + g.c1 + g.c2) * osz + (double)g.N * g.K * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
                          (g.out_op ? g.M * nout * osz : 0.0) + (g.res ? g.M * nout * 4.0 : 0.0);
-    add(name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes);
+    // (a GroupNorm prologue reads the fp32 rows and writes + re-reads the operand rows it builds)
+    const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz) : 0.0;
+    add(g.gnp_x ? name + "[+norm]" : name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes + pro);
   }
   // A = operand tensor [B*Tin][c0]; results to out_f32 and/or out_op (row stride = logical width)
   GemmArgs base(const void* a0, int lda0, int c0, int Tin, int Tout, const PackedW& w, float* out_f32, void* out_op, int ldo) {
@@ -704,8 +712,18 @@ struct Planner {
   }
   // GroupNorm of a (possibly concatenated) fp32 input: statistics -> per-(b,c) affine -> operand tensor `dst`
   // (= act(GN(x)) with the concat materialised), optionally also the raw concat `raw` for a 1x1 shortcut.
-  void groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
-                 const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw) {
+  // `consumer_n` > 0: `dst` has exactly one reader, a GEMM with that many output columns that is planned next -- where the
+  // norm qualifies (see fuse_gn_gemm) no launch is added and the returned GnPro is handed to that GEMM with gn_fuse().
+  struct GnPro { const float* x = nullptr; int ldx = 0; const long long* st = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
+                 const float* temb = nullptr; int ldtemb = 0; float eps = 0.f; int G = 0, silu = 0; };
+  static void gn_fuse(GemmArgs& g, const GnPro& p) {
+    if (!p.x) return;
+    g.gnp_x = p.x; g.gnp_ldx = p.ldx; g.gnp_stats = p.st; g.gnp_gamma = p.gamma; g.gnp_beta = p.beta;
+    g.gnp_temb = p.temb; g.gnp_ldtemb = p.ldtemb; g.gnp_eps = p.eps; g.gnp_G = p.G; g.gnp_silu = p.silu;
+  }
+  GnPro groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
+                  const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw,
+                  int consumer_n = 0) {
     (void)cout;
     const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N, pr = prec;
     double* part = gn_partial;
@@ -713,6 +731,13 @@ struct Planner {
     const long long* st0 = find_stats(a0);
     const long long* st1 = a1 ? find_stats(a1) : nullptr;
     const bool epi = st0 && (!a1 || st1) && (((c0 + c1) / Gq) % 16 == 0) && (c0 % 16 == 0);
+    if (epi && h->fuse_gn_gemm && consumer_n > 0 && (consumer_n % 128) == 0 && !a1 && !raw && Tl >= 66 && c0 <= 512 && (c0 % Gq) == 0 &&
+        Gq <= 8 && (lda0 & 3) == 0) {
+      GnPro p;
+      p.x = a0; p.ldx = lda0; p.st = st0; p.gamma = gamma; p.beta = beta; p.temb = temb ? temb + temb_off : nullptr; p.ldtemb = ldt;
+      p.eps = eps; p.G = Gq; p.silu = silu;
+      return p;
+    }
     if (!epi) {
       st0 = st1 = nullptr;
       add(name + ".gn_stats", [=](hipStream_t s) { return launch_gn_partial(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, part, nchunk, rows, s); },
@@ -722,6 +747,7 @@ struct Planner {
       return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, eps, part, nchunk, st0, st1, gamma, beta, temb, ldt, temb_off, silu, dst,
                              raw, pr, s);
     }, 3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0)));
+    return GnPro();
   }
 
   // ResnetBlock2D (resnet.py:591-641).  out (fp32) [+ out_op operand copy when a conv consumes it next]
@@ -729,15 +755,19 @@ struct Planner {
               float* out, void* out_op) {
     const int cin = c0 + c1;
     // ---- conv1(act(norm1(x)))
-    groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn, r.shortcut ? xr : nullptr);
+    const GnPro p1 = groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn,
+                               r.shortcut ? xr : nullptr, r.conv1.N);
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
+    gn_fuse(g, p1);
     g.stats = new_stats(h1, Tl, r.cout);
     gemm(r.prefix + ".conv1", g);
     // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut
-    groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn, nullptr);
+    const GnPro p2 = groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn,
+                               nullptr, r.conv2.N);
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3;
+    gn_fuse(g2, p2);
     if (r.shortcut) {      // out = conv2(hn) + conv_shortcut(x): the 1x1 conv rides along as a second K segment
       g2.a2 = xr; g2.lda2 = cin; g2.c2 = cin;
     } else {
@@ -793,12 +823,14 @@ struct Planner {
     };
     const bool rows_ok = lin && h->fuse_rows && a.chain_in && a.chain_mid && rowchain_eligible(d, d, Tl, pr);
     const long long* xst = (rows_ok && h->fuse_rows_gn && Tl >= 64 && (d % G) == 0 && ((d / G) % 16) == 0) ? find_stats(x) : nullptr;
-    if (!xst) groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr);
+    GnPro pn;
+    if (!xst) pn = groupnorm(a.prefix + ".norm", x, d, d, nullptr, 0, 0, Tl, 1e-6f, a.ng, a.nb, nullptr, 0, 0, 0, xn, nullptr, rows_ok ? 0 : a.proj_in.N);
     if (rows_ok) {
       rowchain(a.prefix + (xst ? ".rows[norm+proj_in+qkv]" : ".rows[proj_in+qkv]"), xn, xst, a.chain_in, a.proj_in.bias, a.chain_in_consts, nullptr, qkv,
                3 * d);
     } else {
       g = base(xn, d, d, Tl, Tl, a.proj_in, y, r1 ? yn : nullptr, d);
+      gn_fuse(g, pn);
       g.rowstats = r1;
       gemm(a.prefix + ".proj_in", g);
       // self attention
@@ -1093,9 +1125,10 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   }
   if (!skips.empty()) return fail("internal: %zu skips left over", skips.size());
   {
-    P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr);
+    const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N);
     GemmArgs g = P.base(P.xn, curC, curC, T, T, h->conv_out, h->x0, nullptr, CP);
     g.taps = 3;
+    P.gn_fuse(g, pno);
     if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
     P.gemm("conv_out", g);
     P.tap("out", h->x0, B * T, CP);
@@ -1201,6 +1234,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
@@ -1279,9 +1313,10 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_ffn")) opt = &h->fuse_ffn;
   else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
+  else if (!strcmp(name, "fuse_gn_gemm")) opt = &h->fuse_gn_gemm;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, attn_fp8)", name);
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, attn_fp8)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1740,6 +1775,14 @@ int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int ld
   (void)hipFree(part);
   if (e != hipSuccess) return fail("groupnorm launch: %s", hipGetErrorString(e));
   if (e2 != hipSuccess) return fail("groupnorm sync: %s", hipGetErrorString(e2));
+  return 0;
+}
+int ns2vc_k_groupnorm_stats(const float* a0, int lda0, int c0, const long long* stats0, int B, int T, int G, float eps, const float* gamma,
+                            const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, int precision, void* stream) {
+  if (!stats0 || (c0 % G) || ((c0 / G) & 15)) return fail("groupnorm_stats: needs the int64 epilogue statistics and groups of whole 16-channel blocks");
+  hipError_t e = launch_gn_apply(a0, lda0, c0, nullptr, 0, 0, B, T, G, eps, nullptr, 0, stats0, nullptr, gamma, beta, temb, ldtemb, temb_off, silu,
+                                 out_op, nullptr, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("groupnorm_stats launch: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream) {

@@ -625,6 +625,133 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #define NS2VC_G4_FLAGS_PARAM
 #define NS2VC_G4_FLAG(b) false
 #endif
+// ---------------------------------------------------------------------------
+// GroupNorm-apply prologue (built in r3, shipped in r4; GemmArgs.gnp_*).  The step had 51 gn_apply launches whose only job is to turn fp32 rows into
+// the operand rows ONE following GEMM reads.  A consumer-side fusion that normalises while it loads (r1 conv3gn) pays the
+// normalisation once per tap and column tile on the MFMA waves' critical path; a producer-side fusion needs the whole-item
+// statistic (r2 gn_producer, r3 convgn).  This one keeps the K loop and its LDS-DMA untouched: every workgroup first
+// materialises the operand rows ITS tile will read -- its BM output rows plus one halo row either side for k = 3, all c0
+// channels -- in the operand tensor a0, with exactly gn_apply_kernel's arithmetic (bit-identical rows), waits for its own
+// stores, and then runs as before: the DMA reads the rows back from the L2 they were just written through.  Halo rows and the
+// column tiles of one row panel are produced redundantly with identical bytes (no ordering between workgroups needed; the
+// XCD-aware tile mapping keeps a row panel's column tiles on one L2, so the repeated fp32 reads hit it).
+// ---------------------------------------------------------------------------
+template <typename TM>
+__device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, int tid, int nth, char* smem) {
+  const int C = g.c0, T = g.Tin, G = g.gnp_G, Cg = C / G;
+  const int toff = g.taps >> 1;
+  const int rlo = max(m0 - toff, 0), rhi = min(m0 + BM + toff, g.M);       // rows [rlo, rhi) of the flattened (item, frame) index
+  float2* const gtab = reinterpret_cast<float2*>(smem);                     // (mean, rstd) of (item - b_lo, group): <= 3 x 8
+  const int b_lo = rlo / T;
+  const int nbi = (rhi - 1) / T - b_lo + 1;                                 // <= 3 (the launcher checks T against the tile)
+  const int nq = C >> 2, rl = nth / nq;                                     // float4 quads per row, rows per pass
+  const int quad = tid % nq, rlane = tid / nq, c = quad * 4;
+  const bool active = rlane < rl;
+  float4 ga, be, t1[3], t2[3];
+#pragma unroll
+  for (int bi = 0; bi < 3; ++bi) t1[bi] = t2[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int XB = 6;                                                     // rows in flight per thread (1: no gain in the loop, 6: -1 %)
+  float4 xb[XB];
+  const int r0 = rlo + rlane;
+  // (every lane loads, from a clamped row: a straight-line batch of plain loads)
+  const int cq = active ? c : 0;
+  auto fetch = [&](int rb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < XB; ++k) {
+      const int r = min(rb + k * rl, rhi - 1);
+      xb[k] = *reinterpret_cast<const float4*>(g.gnp_x + (size_t)r * g.gnp_ldx + cq);
+    }
+  };
+  fetch(r0);                                                                // first batch in flight under the finalisation
+  // (after the loads above: they are in flight while wave 0 walks this chain of dependent loads and double arithmetic)
+  if (tid < nbi * G) {                                                      // same finalisation as gn_apply_kernel (misc.hip)
+    const int bi = tid / G, gg = tid - bi * G;
+    const int nb = Cg >> 4, nblk = C >> 4;
+    const long long* st = g.gnp_stats + ((size_t)(b_lo + bi) * nblk + (size_t)gg * nb) * 2;
+    double ds = 0.0, dq = 0.0;
+    for (int j = 0; j < nb; ++j) { ds += (double)st[2 * j] * (1.0 / GN_SUM_SCALE); dq += (double)st[2 * j + 1] * (1.0 / GN_SQ_SCALE); }
+    const float inv_nf = 1.0f / ((float)T * (float)Cg);
+    const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
+    const double mean = ds * inv_n;
+    double var = dq * inv_n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float ve = (float)var + g.gnp_eps;
+    float r = rsqrtf(ve);
+    r = r * (1.5f - 0.5f * ve * r * r);
+    gtab[bi * 8 + gg] = make_float2((float)mean, r);
+  }
+  __syncthreads();
+  // (unconditional loads, no zero defaults: inactive threads read column 0)
+  ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);
+  be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
+  if (g.gnp_temb) {
+#pragma unroll
+    for (int bi = 0; bi < 3; ++bi) {
+      const float* tp = g.gnp_temb + (size_t)(b_lo + min(bi, nbi - 1)) * g.gnp_ldtemb + cq;
+      if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
+        t1[bi] = *reinterpret_cast<const float4*>(tp);
+        t2[bi] = *reinterpret_cast<const float4*>(tp + C);
+      } else {
+        t1[bi] = make_float4(tp[0], tp[1], tp[2], tp[3]);
+        t2[bi] = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
+      }
+    }
+  }
+  if (active) {
+    const int gg = c / Cg;
+    float sc[3][4], sh[3][4];
+    const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+    float2 mrs[3];
+#pragma unroll
+    for (int bi = 0; bi < 3; ++bi) mrs[bi] = gtab[min(bi, nbi - 1) * 8 + gg];
+    // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
+    //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
+    // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
+    // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
+    // "gamma reads zero" non-determinism of round 3.  With every (mean, rstd) pair landed before the first packed product the
+    // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(mrs[0].x), "+v"(mrs[0].y), "+v"(mrs[1].x), "+v"(mrs[1].y), "+v"(mrs[2].x), "+v"(mrs[2].y));
+#pragma unroll
+    for (int bi = 0; bi < 3; ++bi) {
+      const float2 mr = mrs[bi];
+      const float ts[4] = {t1[bi].x, t1[bi].y, t1[bi].z, t1[bi].w}, tf[4] = {t2[bi].x, t2[bi].y, t2[bi].z, t2[bi].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[bi][e] = mr.y * gam[e];
+        sh[bi][e] = bet[e] - mr.x * sc[bi][e];
+        if (g.gnp_temb) {
+          const float s1 = 1.0f + ts[e];
+          sc[bi][e] *= s1;
+          sh[bi][e] = sh[bi][e] * s1 + tf[e];
+        }
+      }
+    }
+    TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
+    for (int rb = r0; rb < rhi; rb += XB * rl) {
+      float4 w[XB];
+#pragma unroll
+      for (int k = 0; k < XB; ++k) w[k] = xb[k];
+      fetch(min(rb + XB * rl, rhi - 1));                                    // next batch before this one is stored (clamped: the last one is a dummy)
+#pragma unroll
+      for (int k = 0; k < XB; ++k) {
+        const int r = rb + k * rl;
+        if (r < rhi) {
+          const int bi = (r >= (b_lo + 1) * T ? 1 : 0) + (r >= (b_lo + 2) * T ? 1 : 0);
+          float a[4], b[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
+          float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
+          if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+          out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
+  __syncthreads();                                        // ... and so are everybody else's: the DMA may read them (and smem is free)
+}
+
 // SPEC (r3): loader / consumer wave specialisation.  profiles/r03_gemm_ablate4.txt: the DMA stream alone and the reads + MFMAs
 // alone each take about half of the full loop's time -- they do not overlap, because every wave issues its DMA pieces (an
 // LDS-DMA instruction holds the issuing wave until the CU's load path has taken its 1 KB: ~117 cycles per piece and wave) and
@@ -732,7 +859,13 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
   // K-order walk state (tiles are issued strictly in order): tap, channel offset inside the tap, position in K
   int is_tap = 0, is_cc = 0, is_k = 0;
   const int K1 = g.taps * Ctot;
-  auto issue_tile = [&](int stage) __attribute__((always_inline)) {
+  auto issue_b = [&](int stage, int kt) __attribute__((always_inline)) {     // the weight half of tile kt alone
+    if (!loader) return;
+    const unsigned bbase = lds0 + stage * STAGE + wave * 1024 + BM * TROW;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)(kt * BKE) * SZB, bbase + j * PASSB);
+  };
+  auto issue_tile = [&](int stage, bool with_b = true) __attribute__((always_inline)) {
     if (!loader) return;
     const unsigned sbase = lds0 + stage * STAGE + wave * 1024;
     // every branch below is wave-uniform: one fixed descriptor and one fixed offset register per DMA instruction
@@ -767,8 +900,10 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
     }
     const unsigned bbase = sbase + BM * TROW;
     const unsigned soffW = (unsigned)is_k * SZB;
+    if (with_b) {
 #pragma unroll
-    for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * PASSB);
+      for (int j = 0; j < LB; ++j) blds16(rW, vw[j], soffW, bbase + j * PASSB);
+    }
     is_k += BKE;
     is_cc += BKE;
     if (is_cc >= Ctot) { is_cc = 0; ++is_tap; }
@@ -784,9 +919,18 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 
   const int nk = g.K / BKE;
   NS2VC_STAMP(1);
+  const bool gnp = g.gnp_x != nullptr;             // (uniform over the grid)
+  if (gnp) {
+    // the weight tiles do not depend on the prologue: in flight first, then the rows this tile reads are built (the table of
+    // the prologue lives in the ring stage nobody has been issued into yet), then their DMA
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) issue_b(s, s);
+    gn_prologue<TM>(g, m0, BM, tid, 64 * NW, smem + (STAGES - 1) * STAGE);
+  }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_tile(s);
+    if (s < nk) issue_tile(s, !gnp);
   NS2VC_STAMP(2);
 
   const int l31 = lane & 31, hi = lane >> 5;
@@ -797,7 +941,9 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 #endif
   for (int kt = 0; kt < nk; ++kt) {
     const int after = min(STAGES - 2, nk - 1 - kt);
-    if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
+    if (kt == 0 && gnp) {            // issue order was B(0) B(1) .. A(0) A(1) ..: tile 0 is complete when only the later A halves are out
+      if (STAGES == 3 && after >= 1) wait_vmcnt<LA>(); else wait_vmcnt<0>();
+    } else if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
     else if (STAGES >= 3 && after >= 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -949,6 +1095,7 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
   }
+  if (g.gnp_x && !((st >= 12 && st <= 13) || (st >= 22 && st <= 44))) return hipErrorInvalidValue;   // the prologue lives in gemm4_kernel
   if (st >= 22 && st <= 44) {   // loader / consumer specialised kernels: st = 10 * (1 + SPEC) + ring depth
     if (bn != 128) return hipErrorInvalidValue;
 #define NS2VC_CASE4S(BM_, ST_, SP_) if (bm == BM_ && st == 10 * (1 + SP_) + ST_) return launch_cfg4<TM, BM_, 128, ST_, SP_>(g, s)
@@ -984,6 +1131,11 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
   if (g.ln_stats && (!g.ln_wsum || g.ln_dim <= 0 || (g.ln_dim & 127) || g.ln_dim > 512)) return hipErrorInvalidValue;
   if (g.rowstats && (g.N & 127)) return hipErrorInvalidValue;
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
+  if (g.gnp_x) {     // GroupNorm-apply prologue: one source, same-length rows, whole 16-channel blocks per group, <= 3 batch items per tile + halo
+    if (g.c1 || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 512 || (g.c0 & 3) || !g.gnp_stats || !g.gnp_gamma ||
+        !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (g.c0 % g.gnp_G) || ((g.c0 / g.gnp_G) & 15) || g.Tin < 66 || (g.gnp_ldx & 3) || (g.lda0 & 3))
+      return hipErrorInvalidValue;
+  }
   {   // the DMA addresses rows by 32-bit byte offsets from each tensor's base: every operand must stay below 4 GB
     const unsigned long long sz = operand_bytes(prec), lim = 0xFFF00000ull;
     const unsigned long long rows = (unsigned long long)g.B * g.Tin;

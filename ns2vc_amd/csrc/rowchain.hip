@@ -167,13 +167,25 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     }
     __syncthreads();
     const int g = c / Cg;
+    float2 mrs[NPASS];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = ps * RPP + r0, m = m0 + row;
+      const int m = m0 + ps * RPP + r0;
       int bi = 0;                                    // batch item of this row, relative to b_lo (no division)
 #pragma unroll
       for (int k = 1; k < 4; ++k) bi += (m >= (b_lo + k) * a.T) ? 1 : 0;
-      const float2 mr = gtab[min(bi, 3) * 8 + g];
+      mrs[ps] = gtab[min(bi, 3) * 8 + g];
+    }
+    // gfx950 hazard guard (profiles/r04_gn_prologue_rootcause.txt): every (mean, rstd) pair has landed before the first packed
+    // fp32 product is formed from them (the compiler's counted lgkmcnt(N) waits in front of v_pk_* with op_sel is the pattern
+    // that returned zeros in gemm.hip's prologue; tools/isa_pk_lds_check.py keeps the library free of it)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) asm volatile("" : "+v"(mrs[ps].x), "+v"(mrs[ps].y));
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + r0, m = m0 + row;
+      const float2 mr = mrs[ps];
       const float s0 = mr.y * ga.x, s1 = mr.y * ga.y, s2 = mr.y * ga.z, s3 = mr.y * ga.w;
       float y0 = xv[ps].x * s0 + (be.x - mr.x * s0), y1 = xv[ps].y * s1 + (be.y - mr.x * s1);
       float y2 = xv[ps].z * s2 + (be.z - mr.x * s2), y3 = xv[ps].w * s3 + (be.w - mr.x * s3);
@@ -369,6 +381,9 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       const float* cv = consts + (size_t)(128 * rb + 32 * cg + 8 * g + 4 * hi) * 2;      // (rowsum, bias) x 4 rows
       c0[g] = *reinterpret_cast<const float4*>(cv); c1[g] = *reinterpret_cast<const float4*>(cv + 4);
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (hazard guard, see the GroupNorm prologue above: no packed fp32 op under outstanding LDS reads here)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(c0[g].x), "+v"(c0[g].y), "+v"(c0[g].z), "+v"(c0[g].w), "+v"(c1[g].x), "+v"(c1[g].y), "+v"(c1[g].z), "+v"(c1[g].w));
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
       const int mtok = m0 + tok0 + 32 * u;

@@ -362,7 +362,25 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ns2vc_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.ns2vc_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.ns2vc_abi_version() == _lib.ABI_VERSION == 4
+
+
+def test_no_packed_fp32_of_the_failing_form_under_outstanding_lds_reads():
+    """Static guard for the gfx950 hazard behind round 3's non-deterministic GroupNorm prologue (profiles/r04_gn_prologue_rootcause.txt):
+    no kernel of the library may hold a packed fp32 instruction whose LOW half takes a HIGH source dword (op_sel) at a point where
+    LDS read returns of the wave can still be outstanding.  tools/isa_pk_lds_check.py disassembles the built objects (no GPU needed)."""
+    import glob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_pk_lds_check", os.path.join(ROOT, "tools", "isa_pk_lds_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    objs = sorted(glob.glob(os.path.join(ROOT, "ns2vc_amd", "lib", "obj", "*.o")))
+    assert len(objs) >= 5, "build the library first (__graft_entry__.build())"
+    sites = chk.check(objs)
+    bad = [x for x in sites if chk.is_signature(x[3])]
+    assert not bad, "\n".join(f"{o}: {f[:80]} {a}: {t}" for o, f, a, t, _ in bad)
+    # the scanner itself: it must see the chain kernels' (harmless, counted) packed epilogue arithmetic, or it is blind
+    assert any("rowchain" in x[1] or "ffn" in x[1] for x in sites)
 
 
 def test_host_operand_rounding_matches_ieee():

@@ -215,6 +215,127 @@ def test_gemm_every_tile(tile, prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 13), (128, 128, 13), (64, 128, 23), (128, 128, 23)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+def test_gemm_groupnorm_prologue(tile, prec, diag):
+    """ns2vc_gemm_args.gnp_*: the GEMM writes act(GroupNorm(x)) for the rows its tiles read into its own A operand and then runs as
+    usual (resnet.py:606-629 norm -> act -> conv, transformer_1d.py:268 norm -> proj_in) -- against the two-launch path
+    (ns2vc_k_groupnorm_stats + the same GEMM) BIT FOR BIT: operand rows and results, for k = 3 and k = 1, with and without the
+    time scale / shift and SiLU, row tiles that straddle up to three batch items (T = 70 / 131 / 167 is no multiple of 64), several
+    column tiles per row panel (N = 384), an operand buffer that starts as NaN, and a reference in numpy fp64 on top."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    for (B, T, Cc, N, taps, temb_on, silu, Gn) in ((3, 167, 128, 128, 3, 1, 1, 8), (2, 131, 256, 384, 3, 0, 1, 8), (3, 140, 384, 384, 1, 0, 0, 8),
+                                                   (4, 131, 512, 256, 3, 1, 1, 8), (5, 70, 256, 256, 3, 1, 1, 8)):
+        rng = np.random.default_rng(B * 1000 + T + Cc + taps)
+        M, K = B * T, taps * Cc
+        x = (rng.standard_normal((B, T, Cc)) * (1.0 + rng.random((B, 1, Cc))) + rng.standard_normal((B, 1, Cc))).astype(np.float32)
+        gam, bet = (1.0 + 0.2 * rng.standard_normal(Cc)).astype(np.float32), (0.2 * rng.standard_normal(Cc)).astype(np.float32)
+        ldt, toff = 2 * Cc + 24, 8                       # (scale | shift) pairs somewhere inside a wider per-item row, as in the engine
+        temb = (0.3 * rng.standard_normal((B, ldt))).astype(np.float32)
+        blk = x.astype(np.float64).reshape(B, T, Cc // 16, 16)
+        st = np.stack([np.rint(blk.sum(axis=(1, 3)) * 2.0 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2.0 ** 16)], axis=-1).astype(np.int64)
+        W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
+        bias = rng.standard_normal(N).astype(np.float32)
+        d_x, d_g, d_b, d_t, d_st = _dev(x.reshape(M, Cc)), _dev(gam), _dev(bet), _dev(temb), DevBuf.from_numpy(st)
+        d_w, d_bias = _pack(W, prec), _dev(bias)
+        t_ptr = (d_t.ptr + 4 * toff) if temb_on else None
+        outs, ops = [], []
+        for fused in (0, 1):
+            d_a = OpBuf(np.full((M, Cc), np.nan, dtype=np.float32), prec)
+            d_o = DevBuf(M * N * 4)
+            d_o.upload(np.full((M, N), np.nan, dtype=np.float32))
+            g = GemmArgs()
+            g.a0 = d_a.ptr; g.lda0 = Cc; g.c0 = Cc
+            g.B, g.Tin, g.Tout, g.M = B, T, T, M
+            g.taps, g.tmode = taps, 0
+            g.w = d_w.value; g.K = K; g.N = N; g.bias = d_bias.ptr
+            g.out_f32 = d_o.ptr; g.ldo_f32 = N
+            if fused:
+                g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_st.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
+                g.gnp_temb = t_ptr; g.gnp_ldtemb = ldt; g.gnp_eps = 1e-5; g.gnp_G = Gn; g.gnp_silu = silu
+            else:
+                check(lib.ns2vc_k_groupnorm_stats(d_x.ptr, Cc, Cc, d_st.ptr, B, T, Gn, 1e-5, d_g.ptr, d_b.ptr, d_t.ptr if temb_on else None, ldt, toff, silu,
+                                                  d_a.ptr, prec, None), "groupnorm_stats")
+            check(lib.ns2vc_debug_set_gemm_tile(*tile), "set tile")
+            try:
+                check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+                sync()
+            finally:
+                lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+            outs.append(d_o.to_numpy((M, N)))
+            ops.append(d_a.read())
+        lib.ns2vc_dev_free(d_w)
+        # fp64 reference of the normalised rows and of the product on the device's operand rows
+        xg = x.astype(np.float64).reshape(B, T, Gn, Cc // Gn)
+        mean, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+        y = ((xg - mean) / np.sqrt(var + 1e-5)).reshape(B, T, Cc) * gam.astype(np.float64) + bet.astype(np.float64)
+        if temb_on:
+            y = y * (1.0 + temb[:, None, toff:toff + Cc].astype(np.float64)) + temb[:, None, toff + Cc:toff + 2 * Cc].astype(np.float64)
+        if silu:
+            y = y / (1.0 + np.exp(-y))
+        e_op = rel_l2(ops[1], y.reshape(M, Cc))
+        Gr = gather_rows(ops[1].astype(np.float64).reshape(B, T, Cc), B, T, T, taps, 0).reshape(M, K)
+        e_out = rel_l2(outs[1], Gr @ W.astype(np.float64).T + bias)
+        same_op, same_out = np.array_equal(ops[0], ops[1]), np.array_equal(outs[0], outs[1])
+        diag(f"gemm+GroupNorm prologue tile={tile} prec={prec} B={B} T={T} C={Cc} N={N} taps={taps} temb={temb_on} silu={silu}: "
+             f"rows vs fp64 {e_op:.2e}  result vs fp64 {e_out:.2e}  rows==two-launch {same_op}  result==two-launch {same_out}")
+        assert np.isfinite(ops[1]).all() and np.isfinite(outs[1]).all()          # every row the tiles read was produced
+        assert same_op and same_out
+        assert e_op < (1e-6 if prec == 0 else eps16(prec)) and e_out < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
+def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, diag):
+    """The fused launch at the bench shape (32 x 938 rows, 128 -> 128 channels, k = 3; the loader / consumer tiles), eight times:
+    operand rows and results equal the two-launch path bit for bit EVERY time.  This is the probe that showed round 3's
+    "gamma reads zero" failure (a packed fp32 product formed under outstanding LDS reads came back as 0.0 for lanes 48-63 of a
+    few waves per launch; tools/gnp_probe.py, profiles/r04_gn_prologue_rootcause.txt): it failed 22 of 22 launches before the
+    fix and must stay at zero."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    B, T, Cc, N, taps = 32, 938, 128, 128, 3
+    rng = np.random.default_rng(0)
+    M, K = B * T, taps * Cc
+    x = rng.standard_normal((B, T, Cc)).astype(np.float32)
+    gam, bet = (1.0 + np.arange(Cc) / 256.0).astype(np.float32), (np.arange(Cc) / 64.0 + 0.25).astype(np.float32)
+    blk = x.astype(np.float64).reshape(B, T, Cc // 16, 16)
+    st = np.stack([np.rint(blk.sum(axis=(1, 3)) * 2.0 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2.0 ** 16)], axis=-1).astype(np.int64)
+    W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
+    d_x, d_g, d_b, d_st, d_w = _dev(x.reshape(M, Cc)), _dev(gam), _dev(bet), DevBuf.from_numpy(st), _pack(W, prec)
+
+    def run(fused, rep):
+        d_a = OpBuf(np.full((M, Cc), np.nan, dtype=np.float32), prec)
+        d_o = DevBuf(M * N * 4)
+        d_o.upload(np.full((M, N), float(rep), dtype=np.float32))
+        g = GemmArgs()
+        g.a0 = d_a.ptr; g.lda0 = Cc; g.c0 = Cc
+        g.B, g.Tin, g.Tout, g.M = B, T, T, M
+        g.taps, g.tmode = taps, 0
+        g.w = d_w.value; g.K = K; g.N = N
+        g.out_f32 = d_o.ptr; g.ldo_f32 = N
+        if fused:
+            g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_st.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
+            g.gnp_eps = 1e-5; g.gnp_G = 8; g.gnp_silu = 1
+        else:
+            check(lib.ns2vc_k_groupnorm_stats(d_x.ptr, Cc, Cc, d_st.ptr, B, T, 8, 1e-5, d_g.ptr, d_b.ptr, None, 0, 0, 1, d_a.ptr, prec, None), "groupnorm_stats")
+        check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+        sync()
+        return d_a.read(), d_o.to_numpy((M, N))
+
+    ref_a, ref_o = run(0, 0)
+    bad = 0
+    for rep in range(8):
+        a, o = run(1, rep + 1)
+        bad += int(not (np.array_equal(a, ref_a) and np.array_equal(o, ref_o)))
+    lib.ns2vc_dev_free(d_w)
+    diag(f"gemm+GroupNorm prologue at the bench shape prec={prec}: {bad} of 8 fused launches differ from the two-launch path")
+    assert bad == 0
+
+
+
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 def test_gemm_epilogue_groupnorm_stats(prec, diag):
     """The epilogue's int64 fixed-point (sum, sumsq) per (batch item, 16-channel block) == numpy on the stored result,
     for every tile shape, with row tiles that straddle batch boundaries (T = 167 is not a multiple of 32)."""
