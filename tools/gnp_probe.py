@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The in-situ repro of round 3's non-deterministic GroupNorm prologue (profiles/r04_gn_prologue_rootcause.txt): the fused launch at the bench
 shape, repeated, against ns2vc_k_groupnorm_stats + the same GEMM, bit for bit (GPU box).  22 of 22 launches failed before the r4 fix; the
-instrumented variants it was run on (NS2VC_GNP_DETECT / NS2VC_GNP_FIX builds) are in the history at commit 4fc9071."""
+instrumented variants it was run on (NS2VC_GNP_DETECT / NS2VC_GNP_FIX builds) are in the history at commit 1694573."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
