@@ -20,6 +20,9 @@ N > 1: launched by torchrun (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the en
 or plainly as `python bench.py --gpus N` -- then this process spawns the N ranks itself
 (127.0.0.1 rendezvous) and fails loudly if fewer than N devices are visible.
 
+`python bench.py --dry-dist N` rehearses that multi-rank path on CPU (gloo, stub engine): the driver's 8-GPU run is the first time
+RCCL sees more than one rank, but not the first time the harness around it runs.
+
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with
   roofline      dominant kernel family (implicit GEMM: gemm4 + fused feed-forward + row chains) vs the dense MFMA peak;
                 `achieved` = the family's share of the TIMED loop, `isolated` = its launches timed back to back with HIP events
@@ -73,6 +76,9 @@ def parse():
     ap.add_argument("--tail-fp32", type=int, default=0, help="last evaluations of the timed loop on a second, fp32 engine (mixed precision; "
                     "0 = the headline's pure 16-bit loop)")
     ap.add_argument("--strong-batch", type=int, default=256, help="global batch of the strong_scaling block (BASELINE config 4: 256)")
+    ap.add_argument("--dry-dist", type=int, default=0, metavar="N", help="harness rehearsal WITHOUT GPUs: N ranks on the gloo backend, the engine replaced by "
+                    "a sleep + deterministic fill; exercises the spawn, every barrier, the all-gather of latents, the per-rank reduction, the "
+                    "strong_scaling block and the JSON line exactly as --gpus N does (tests/test_cpu.py runs it at N = 2 and 8)")
     ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the baseline legs")
     ap.add_argument("--ops", default="", help="write the per-launch table (name, kind, ms, GFLOP, MB) to this file")
     ap.add_argument("--detail", action="store_true", help="print the per-kernel-family table to stderr")
@@ -220,10 +226,11 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
 def spawn_ranks(a) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL rendezvous on
     127.0.0.1) and relay rank 0's JSON line."""
-    from ns2vc_amd import engine as E
-    n_dev = E.device_count()
-    if n_dev < a.gpus:
-        raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} ROCm device(s) visible")
+    if not a.dry_dist:
+        from ns2vc_amd import engine as E
+        n_dev = E.device_count()
+        if n_dev < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {n_dev} ROCm device(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -310,6 +317,9 @@ def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
         "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
         "achieved_method": "family FLOP / (timed ms_per_step x the family's share of the per-launch HIP-event times)",
         "family_share_of_step": share, "family_ms_in_loop": loop_ms,
+        # (the two cross-checks as flat scalars too: a consumer that keeps only scalar roofline keys still sees them)
+        "frac_isolated": iso_tflops / peak, "frac_rocprof": rocprof["frac"] if rocprof else None,
+        "family_ms_rocprof": rocprof["family_ms_per_step"] if rocprof else None, "rocprof_measured_at": rocprof["measured_at"] if rocprof else None,
         "isolated": {"tflops": iso_tflops, "frac": iso_tflops / peak, "ms_per_step": g["ms"],
                      "method": "every launch 8x back to back between one HIP event pair on the launch stream (L2-warm)"},
         "rocprof": rocprof,
@@ -327,8 +337,56 @@ def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
     }
 
 
+class DryEngine:
+    """--dry-dist: stands in for ns2vc_amd.engine.Engine with the same call sequence.  A job sleeps ~0.2 ms per step and utterance
+    and returns x_T / 2 (deterministic, so the gathered latents can be checked on every rank)."""
+
+    def __init__(self, B, K):
+        self.B, self.K = B, K
+
+    def set_condition(self, *a, **k):
+        pass
+
+    def sample(self, x, use_graph=True, stream=None, tail=None, tail_steps=0):
+        time.sleep(2e-4 * self.K * max(self.B, 1))
+        x.mul_(0.5)
+
+    def launches(self):
+        return (0, 0)
+
+    def workspace_bytes(self):
+        return 0
+
+    def attn_fallbacks(self, reset=True, stream=None):
+        return 0
+
+    def close(self):
+        pass
+
+
+class _DryStream:
+    def synchronize(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _DryEvent:
+    def record(self, stream=None):
+        self.t = time.perf_counter()
+
+    def elapsed_ms(self, other):
+        return (other.t - self.t) * 1e3
+
+
 def main():
     a = parse()
+    if a.dry_dist:
+        a.gpus = a.dry_dist
     T_frames = int(math.floor(24000 * a.seconds / 256)) + 1
     if a.cpu_worker > 0:
         if a.cpu_pin:                                   # one all-core worker on its own disjoint set of cores (before torch starts its thread pool)
@@ -356,27 +414,39 @@ def main():
     from ns2vc_amd.weights import procedural_state_dict
     from ns2vc_amd.dist import gather_latents
 
-    if not torch.cuda.is_available() or E.device_count() == 0:
-        raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
-    if E.device_count() <= local:
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {E.device_count()} ROCm device(s) visible")
-    torch.cuda.set_device(local)
-    E.set_device(local)
-    if world > 1:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    dev = torch.device("cuda", local)
+    dry = bool(a.dry_dist)
+    if dry:
+        torch.set_num_threads(1)
+        if world > 1:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available() or E.device_count() == 0:
+            raise SystemExit("bench.py needs an MI355X: no ROCm device visible (there is no CPU fallback)")
+        if E.device_count() <= local:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {E.device_count()} ROCm device(s) visible")
+        torch.cuda.set_device(local)
+        E.set_device(local)
+        if world > 1:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dev = torch.device("cuda", local)
 
     cfg = UNetConfig()
     B, T, Lp, K = a.batch, frames_for_seconds(a.seconds), a.prompt_frames, a.steps
     assert T == T_frames
     order = 2 if K >= 2 else 1
     solver = a.solver
-    W = procedural_state_dict(cfg, 0)
+    W = None if dry else procedural_state_dict(cfg, 0)
     use_graph = not a.no_graph
-    stream = torch.cuda.Stream(device=dev)
+    stream = _DryStream() if dry else torch.cuda.Stream(device=dev)
+    on_stream = (lambda: stream) if dry else (lambda: torch.cuda.stream(stream))
+    new_event = _DryEvent if dry else E.Event
+    dev_sync = (lambda: None) if dry else (lambda: torch.cuda.synchronize(dev))
 
     def build(precision, B_=None, T_=None, solver_=None, K_=None, attn_fp8=None):
-        B_, T_, solver_, K_ = B_ or B, T_ or T, solver_ or solver, K_ or K
+        B_, T_, solver_, K_ = B_ if B_ is not None else B, T_ or T, solver_ or solver, K_ or K
+        if dry:
+            return DryEngine(B_, K_)
         eng = E.Engine(cfg, precision=precision)
         if (a.attn_fp8 if attn_fp8 is None else attn_fp8) and precision != "fp32":
             eng.set_option("attn_fp8", True)
@@ -386,15 +456,19 @@ def main():
         return eng
 
     def dev_inputs(tag, B_, T_):
+        if dry:                                               # only the latent matters to the harness
+            g = torch.Generator().manual_seed(1234 + sum(map(ord, tag)))
+            n = torch.randn((B_, cfg.latent_channels, T_), generator=g)
+            return {"noise": n, "content": None, "prompt": None, "mask": None, "x": torch.empty_like(n)}
         n_np, c_np, p_np = bench_inputs(tag, B_, T_, Lp)
         c, p_, n = (torch.from_numpy(v).to(dev) for v in (c_np, p_np, n_np))
         return {"noise": n, "content": c, "prompt": p_, "mask": torch.ones((B_, Lp), dtype=torch.uint8, device=dev), "x": torch.empty_like(n)}
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        dev_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        dev_sync()
 
     def timed_jobs(eng, io, K_, warmup_steps, reps, with_gather, tail=None, tail_steps=0, n_total=None):
         """`reps` timed jobs of exactly K_ steps, each bracketed by barrier + synchronize; returns per-job wall seconds
@@ -409,13 +483,13 @@ def main():
                 tail.set_condition(io["content"], io["prompt"], io["mask"], stream=stream)
             eng.sample(x, use_graph=use_graph, stream=stream, tail=tail, tail_steps=tail_steps)
         walls, gpu_ms, t_gather = [], 0.0, 0.0
-        with torch.cuda.stream(stream):
+        with on_stream():
             for _ in range(max(1, math.ceil(warmup_steps / max(K_, 1)))):
                 job()
             stream.synchronize()
             for _ in range(reps):
                 barrier()
-                ev0, ev1 = E.Event(), E.Event()
+                ev0, ev1 = new_event(), new_event()
                 t0 = time.perf_counter()
                 ev0.record(stream)
                 job()
@@ -424,9 +498,12 @@ def main():
                     stream.synchronize()
                     tg = time.perf_counter()
                     full = gather_latents(x, n_total)
-                    torch.cuda.synchronize(dev)
+                    dev_sync()
                     t_gather = time.perf_counter() - tg
                     assert full.shape[0] == n_total
+                    if dry:                                   # the stub engine halves x_T: every rank must hold every rank's slice, in order
+                        lo_, hi_ = io.get("range", (0, 0))
+                        assert torch.equal(full[lo_:hi_], x) and bool(torch.isfinite(full).all())
                 stream.synchronize()
                 barrier()
                 wall = time.perf_counter() - t0
@@ -442,6 +519,7 @@ def main():
         return float((y.double() - ref.double()).norm() / ref.double().norm())
 
     io = dev_inputs(f"bench.r{rank}", B, T)
+    io["range"] = (rank * B, (rank + 1) * B)
     x = io["x"]
     eng = build(a.precision)
     tail_eng = build("fp32") if (a.tail_fp32 > 0 and a.precision != "fp32") else None
@@ -453,7 +531,8 @@ def main():
     x_timed = x.clone()
     # the timed (captured-graph) loop must return exactly what the same loop launched eagerly returns
     loop_check = None
-    if use_graph:
+    attn_fb = None if dry else eng.attn_fallbacks(reset=True, stream=stream)          # workgroups that paid an attention kernel twice, all jobs so far
+    if use_graph and not dry:
         with torch.cuda.stream(stream):
             x.copy_(io["noise"])
             eng.set_condition(io["content"], io["prompt"], io["mask"], stream=stream)
@@ -471,36 +550,19 @@ def main():
         per_rank_ms = [float(v[0]) for v in allr]
         gather_ms = max(float(v[1]) for v in allr)
 
-    # ---- strong scaling: BASELINE config 4's global batch split over the ranks (every rank takes part; rank 0 reports)
-    strong = None
-    if not a.skip_strong:
-        from ns2vc_amd.dist import shard_range
-        GB = a.strong_batch
-        lo, hi = shard_range(GB, rank, world)
-        try:
-            es = build(a.precision, B_=hi - lo)
-            ios = dev_inputs(f"strong.r{rank}", hi - lo, T)
-            ws, _, tg = timed_jobs(es, ios, K, K, min(reps, 3), world > 1, None, 0, GB)
-            es.close()
-            del ios
-            wm = statistics.median(ws)
-            strong = {"global_batch": GB, "per_rank_batch": hi - lo, "n_gpus": world, "steps": K, "solver": solver, "ms_per_step": wm * 1e3 / K,
-                      "value": K / wm, "unit": f"denoiser-steps/s at global batch {GB} (strong scaling: the batch is split over the ranks)",
-                      "sample_steps_per_s": GB * K / wm, "jobs_ms": [w * 1e3 for w in ws], "all_gather_ms": tg * 1e3 if world > 1 else 0.0,
-                      "scaling": "strong"}
-        except Exception as ex:                                # never take the headline down
-            strong = {"error": repr(ex)}
-
+    out = None
     if rank == 0:
         gflop_sample = PUBLISHED_GFLOP.get((T, Lp), algorithmic_gflop_per_sample_step(T, Lp))
         step_ms = wall * 1e3 / K
-        fam = family_table(eng, stream, a.ops)
-        roof = roofline_block(fam, a.precision, step_ms, gflop_sample, B, (B, T, Lp))
+        fam = roof = None
+        if not dry:
+            fam = family_table(eng, stream, a.ops)
+            roof = roofline_block(fam, a.precision, step_ms, gflop_sample, B, (B, T, Lp))
 
         # ---- CPU baseline (oracle on the host cores) + parity of the timed precision at the bench shape
         cpu = parity = None
         ref = samp = None
-        if world == 1 and not a.skip_cpu:
+        if world == 1 and not a.skip_cpu and not dry:
             try:
                 cpu, ref, samp = cpu_baseline(T, Lp, B, a.cpu_budget, sampler=(solver, K, 4 if K <= 20 else 2))
             except Exception as ex:                      # the baseline leg must never take the GPU number down
@@ -528,10 +590,33 @@ def main():
                     "solver": solver, "steps": K, "tail_fp32": a.tail_fp32, "oracle_seconds": round(samp["seconds"], 1),
                     "reference": f"oracle/sampler_ref.py (pinned to the reference's own samplers by tests/golden) on utterances 0..{nb - 1} of the timed batch, identical noise"}
 
+        # ---- what the served API measures about itself on this workload: Denoiser's precision self-check (16-bit vs exact-fp32 engine at
+        # the first / middle / last evaluation point of the trajectory, batch figure and worst utterance) and the LayerNorm guard's ratio
+        self_check = None
+        if world == 1 and not dry and a.precision != "fp32" and not a.skip_fp32:
+            try:
+                from ns2vc_amd.pipeline import Denoiser
+                den = Denoiser(W, cfg, precision=a.precision)
+                with torch.cuda.stream(stream):
+                    ys = den.sample(io["content"], io["prompt"], io["mask"].bool(), io["noise"], solver=solver, steps=K, order=order, use_graph=use_graph,
+                                    tail_fp32=a.tail_fp32)
+                    stream.synchronize()
+                self_check = {
+                    "what": "ns2vc_amd.pipeline.Denoiser on the timed inputs: relative L2 of the 16-bit engine vs the exact-fp32 engine at the first / middle / "
+                            "last evaluation point of the sampling trajectory (gate: both figures <= threshold, else the Denoiser serves from fp32)",
+                    "points": [{"t": t_, "batch_rel_l2": b_, "worst_utterance_rel_l2": w_} for t_, b_, w_ in den.precision_errors],
+                    "precision_error_seen": den.precision_error_seen, "precision_error_worst_item": den.precision_error_worst_item,
+                    "threshold": den.precision_check, "serving_fp32": den.serving_fp32,
+                    "ln_ratio_seen": den.ln_ratio_seen, "ln_guard": den.ln_guard,
+                    "denoiser_output_equals_timed_loop": bool(torch.equal(ys, x_timed))}
+                del den
+            except Exception as ex:
+                self_check = {"error": repr(ex)}
+
         # ---- the exact-fp32 precision: same job, same roofline definition (peak = 157.3 TFLOP/s fp32 MFMA)
         fp32_block = None
         e32 = None
-        if world == 1 and a.precision != "fp32" and not a.skip_fp32:
+        if world == 1 and a.precision != "fp32" and not a.skip_fp32 and not dry:
             eng.close()
             e32 = build("fp32")
             w32, _, _ = timed_jobs(e32, io, K, K, min(reps, 3), False)
@@ -562,7 +647,7 @@ def main():
 
         # ---- BASELINE configs 2 and 5, timed the same way (one GPU): parity against the exact-fp32 engine at the same shape
         others = None
-        if world == 1 and not a.skip_others:
+        if world == 1 and not a.skip_others and not dry:
             others = []
             try:
                 eng.close()
@@ -599,6 +684,18 @@ def main():
                         e2.set_condition(io2["content"], io2["prompt"], io2["mask"], stream=stream)
                         e2.forward(io2["noise"], t_par, y2, stream=stream)
                         stream.synchronize()
+                    oracle_fwd = None
+                    if not a.skip_cpu:                 # one utterance through the ORACLE at this shape (CPU, ~seconds): parity vs the reference itself, not vs the fp32 engine
+                        from oracle import unet_ref
+                        if "P" not in ref32:
+                            ref32["P"] = _oracle_setup(min(_host_cores(), 16))[1]
+                        t0o = time.perf_counter()
+                        yo = unet_ref.denoiser(ref32["P"], cfg, io2["noise"][:1].cpu(), io2["content"][:1].cpu(), io2["prompt"][:1].cpu(),
+                                               torch.ones(1, Lp, dtype=torch.bool), t_par[:1].cpu()).double()
+                        oracle_fwd = {"utterance": 0, "rel_l2_vs_oracle": float((y2[:1].cpu().double() - yo).norm() / yo.norm()),
+                                      "fp32_engine_rel_l2_vs_oracle": float((y32[:1].cpu().double() - yo).norm() / yo.norm()),
+                                      "oracle_seconds": round(time.perf_counter() - t0o, 1),
+                                      "reference": "oracle/unet_ref.py, one UNet forward of utterance 0 at this shape (timestep 40)"}
                     g2 = PUBLISHED_GFLOP.get((T2, Lp), algorithmic_gflop_per_sample_step(T2, Lp))
                     ms2, ms2p = statistics.median(w2) * 1e3 / K2, statistics.median(w2p) * 1e3 / K2
                     fam2 = family_table(e2, stream)
@@ -612,14 +709,15 @@ def main():
                         "pure_16bit_loop": {"ms_per_step": ms2p, "value": K2 / statistics.median(w2p)},
                         "parity": {"reference": "the exact-fp32 engine at the same shape and inputs (itself 1e-6 from the oracle: tests/test_engine_gpu.py, fp32_parity_mode)",
                                    "forward_rel_l2": rel_l2_dev(y2, y32), "sampled_latent_rel_l2": rel_l2_dev(s_mixed, s32),
-                                   "sampled_latent_rel_l2_pure_16bit": rel_l2_dev(s_pure, s32), "tolerance": 1e-3},
+                                   "sampled_latent_rel_l2_pure_16bit": rel_l2_dev(s_pure, s32), "tolerance": 1e-3, "forward_vs_oracle": oracle_fwd},
                         "roofline": roofline_block(fam2, a.precision, ms2p, g2, B2, (B2, T2, Lp)),
                         "launches_per_step": e2.launches()[0]})
                     e2.close()
                 except Exception as ex:
                     others.append({"config": name, "error": repr(ex)})
-            for r32, *_ in ref32.values():
-                r32.close()
+            for k32, v32 in ref32.items():
+                if k32 != "P":
+                    v32[0].close()
 
         value = world * K / wall
         out = {
@@ -634,19 +732,62 @@ def main():
             "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,
                        "max_ms_per_step": max(walls) * 1e3 / K},
             "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
-            "launches_per_step": launches, "workspace_gb": workspace_gb, "device": E.device_info(),
+            "launches_per_step": launches, "workspace_gb": workspace_gb, "device": "none (dry run)" if dry else E.device_info(),
+            "attention_fallback_workgroups": attn_fb,
             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "parity": parity, "fp32_parity_mode": fp32_block, "other_configs": others, "strong_scaling": strong, "cpu_baseline": cpu,
+            "roofline": roof, "parity": parity, "self_check": self_check, "fp32_parity_mode": fp32_block, "other_configs": others, "strong_scaling": None,
+            "cpu_baseline": cpu,
         }
+        if dry:
+            out["dry_dist"] = {"backend": "gloo", "engine": "stub (sleep + deterministic fill)", "note": "harness rehearsal, not a measurement"}
+            out["data"] = "dry run"
         if world > 1:
             out["all_gather_ms"] = gather_ms
             out["all_gather_bytes"] = int(B * world * cfg.latent_channels * T * 4)     # what every rank receives: the finished latents of the global batch
             out["spawned_by"] = "bench.py" if os.environ.get("NS2VC_BENCH_SPAWNED") else "launcher"
         if cpu and cpu.get("value"):
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-        if a.detail:
+        if a.detail and roof:
             for k, v in roof["families"].items():
                 print(f"  {k:14s} {v}", file=sys.stderr)
+    # ---- strong scaling: BASELINE config 4's global batch split over the ranks (every rank takes part; rank 0 reports).  It runs
+    # AFTER everything the headline needs (the headline engines are closed by now), and the ranks AGREE on having built their shard
+    # engine before anyone enters the timed jobs' collectives: a rank that fails (e.g. out of memory) cannot leave the others in a barrier.
+    strong = None
+    if not a.skip_strong:
+        from ns2vc_amd.dist import shard_range
+        GB = a.strong_batch
+        lo, hi = shard_range(GB, rank, world)
+        es, ios, err = None, None, None
+        try:
+            eng.close()
+            if tail_eng is not None:
+                tail_eng.close()
+            es = build(a.precision, B_=hi - lo)
+            ios = dev_inputs(f"strong.r{rank}", hi - lo, T)
+            ios["range"] = (lo, hi)
+        except Exception as ex:
+            err = repr(ex)
+        ok = 0 if err else 1
+        if world > 1:
+            tt = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            ok = int(tt.item())
+        if ok:
+            ws, _, tg = timed_jobs(es, ios, K, K, min(reps, 3), world > 1, None, 0, GB)
+            wm = statistics.median(ws)
+            strong = {"global_batch": GB, "per_rank_batch": hi - lo, "n_gpus": world, "steps": K, "solver": solver, "ms_per_step": wm * 1e3 / K,
+                      "value": K / wm, "unit": f"denoiser-steps/s at global batch {GB} (strong scaling: the batch is split over the ranks)",
+                      "sample_steps_per_s": GB * K / wm, "jobs_ms": [w * 1e3 for w in ws], "all_gather_ms": tg * 1e3 if world > 1 else 0.0,
+                      "scaling": "strong"}
+        else:
+            strong = {"error": err or "another rank could not build its shard engine", "global_batch": GB}
+        if es is not None:
+            es.close()
+        del ios
+
+    if rank == 0:
+        out["strong_scaling"] = strong
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -134,7 +134,13 @@ int ns2vc_sampler_run(ns2vc_unet* h, float* x_inout_bct, int use_graph, void* st
 int ns2vc_sampler_begin(ns2vc_unet* h, const float* x_T_bct, void* stream);
 int ns2vc_sampler_steps(ns2vc_unet* h, int n_steps, int use_graph, void* stream);
 int ns2vc_sampler_end(ns2vc_unet* h, float* x_out_bct, void* stream);
-int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream);
+int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream);   /* both engines must hold the SAME table (compared by hash) */
+/* x_e of a loop in progress (the point the next evaluation is taken at) without ending the loop: what a precision self-check
+ * evaluates two engines on (ns2vc_amd.pipeline.Denoiser) */
+int ns2vc_sampler_peek(ns2vc_unet* h, float* x_out_bct, void* stream);
+/* workgroups of the attention launches of this engine whose optimistic pass (no per-tile maximum; r3) had to be repeated by the
+ * exact pass since the last reset -- each of them paid the kernel twice.  Synchronises `stream`. */
+int ns2vc_unet_attn_fallbacks(ns2vc_unet* h, unsigned long long* count, int reset, void* stream);
 
 /* ---- introspection for tests / profiling -------------------------------------------- */
 int ns2vc_unet_set_debug(ns2vc_unet* h, int enable);  /* keep a copy of every block output; drops the plan: call before prepare() */
@@ -216,6 +222,8 @@ typedef struct ns2vc_attn_args {
   float scale;
   void* out; int32_t ldo;         /* operand-typed */
   int32_t pv_fp8;                 /* 16-bit precisions only: 1 = the PV product on the fp8 MFMA (V and the probabilities rounded to OCP e4m3) */
+  int32_t exact_only;             /* 1 = skip the optimistic pass (no per-tile maximum) and take the exact pass directly */
+  unsigned* fallbacks;            /* device counter or NULL: += 1 per workgroup whose optimistic pass had to be repeated exactly */
 } ns2vc_attn_args;
 
 /* Fused feed-forward + proj_out of one transformer block (attention.py:178-203 GEGLU feed-forward, transformer_1d.py:287-295),
@@ -285,7 +293,7 @@ int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
 int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev); /* [N] fp32: sum_k round_to_operand(rows[n][k]) */
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
 int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream); /* test tool: leave `pattern` in every CU's LDS (first lds_bytes) and in vector registers, as a foreign kernel would */
-int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile: stages 2..4 = 4-wave kernel ring depth, 12|13 = 8-wave K-split kernel ring 2|3; 0,0,0 = heuristic */
+int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile: stages 2..4 = 4-wave kernel ring depth, 12|13 = 8-wave K-split kernel ring 2|3; 0,0,0 = heuristic; (-1,0,0) = heuristic without the loader/consumer tiles, (-2,0,0) = with them again */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
 /* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,
  * written as an operand tensor [B*T][c0+c1]; raw_op (optional) receives the un-normalised concat. Synchronous. */

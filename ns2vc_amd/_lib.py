@@ -92,7 +92,7 @@ class AttnArgs(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Lq", C.c_int32), ("Lk", C.c_int32),
         ("bias", C.c_void_p), ("scale", C.c_float),
         ("out", C.c_void_p), ("ldo", C.c_int32),
-        ("pv_fp8", C.c_int32),
+        ("pv_fp8", C.c_int32), ("exact_only", C.c_int32), ("fallbacks", C.c_void_p),
     ]
 
 
@@ -124,6 +124,8 @@ PROTOTYPES = {
     "ns2vc_sampler_steps": (_I, [_P, _I, _I, _P]),
     "ns2vc_sampler_end": (_I, [_P, _P, _P]),
     "ns2vc_sampler_handoff": (_I, [_P, _P, _P]),
+    "ns2vc_sampler_peek": (_I, [_P, _P, _P]),
+    "ns2vc_unet_attn_fallbacks": (_I, [_P, C.POINTER(C.c_ulonglong), _I, _P]),
     "ns2vc_unet_set_debug": (_I, [_P, _I]),
     "ns2vc_unet_set_option": (_I, [_P, C.c_char_p, _I]),
     "ns2vc_unet_ln_ratio": (_I, [_P, C.POINTER(C.c_float), _P]),

@@ -392,14 +392,17 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
   constexpr int LB = HD / 32, LR = ((HD % 32) / 8) * 4;
   static_assert(HD % 32 == 0 || HD % 32 == 16, "ones row must sit at row 0 or 16 of its 32-row block");
-  if (OPT && !g_attn_exact_only) {
+  if (OPT && !g_attn_exact_only && !a.exact_only) {
     run(OptTag<true>{});
     // the denominator of this lane's query (lane half 0 holds it) bounds every probability of the row: below 2^14 none of them
     // reached the fp16 range (the converts SATURATE under MODE.FP16_OVFL, so an overflow would not show up as inf), and it is
     // positive unless every probability flushed to zero -- otherwise the exact pass decides
     const float lq = o[LB][LR];
     const int bad = (hi == 0 && q < a.Lq && !(lq > 0.f && lq < 16384.f)) ? 1 : 0;
-    if (__syncthreads_or(bad)) run(OptTag<false>{});
+    if (__syncthreads_or(bad)) {
+      if (a.fallbacks && threadIdx.x == 0) atomicAdd(a.fallbacks, 1u);      // (this workgroup pays the kernel twice: counted, ns2vc_unet_attn_fallbacks)
+      run(OptTag<false>{});
+    }
   } else {
     run(OptTag<false>{});
   }
@@ -432,7 +435,7 @@ template <typename TM, int HD, int KEYS> static constexpr size_t attn_lds() {
 // (128), attention 0.68 vs 0.73 ms -- 64 more score registers and twice the LDS per workgroup cost more occupancy than the
 // bookkeeping saves in a VALU-bound loop.
 template <typename TM, int HD> static constexpr bool attn_has128() { return sizeof(TM) == 2 && HD <= 32; }
-static int g_force_keys = getenv("NS2VC_ATTN_KEYS") ? atoi(getenv("NS2VC_ATTN_KEYS")) : 0;   // test / tuning hook: 128 selects the 128-key kernels
+static int g_force_keys = 0;   // test / tuning hook (ns2vc_debug_set_attn_keys): 128 selects the 128-key kernels
 void set_forced_attn_keys(int keys) { g_force_keys = keys; }
 void set_attn_optimistic(int on) { const int v = on ? 0 : 1; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_exact_only), &v, sizeof(v)); }
 

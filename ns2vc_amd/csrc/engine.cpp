@@ -153,6 +153,9 @@ struct ns2vc_unet {
   // run-to-run deterministic; root cause and fix in r4, profiles/r04_gn_prologue_rootcause.txt.)
   bool fuse_gn_gemm = true;
   unsigned* ln_health = nullptr;
+  bool attn_optimistic = true;   // attention without the per-tile maximum + exact fallback (attn.hip OPT); 0 = exact pass only, on every device
+  unsigned* attn_fallbacks = nullptr;     // device counter: workgroups that needed the fallback (ns2vc_unet_attn_fallbacks)
+  unsigned long long coef_hash = 0;       // FNV-1a of the loaded solver table (handoff compares)
   std::vector<Tap> taps;
   bool has_mask = false;
 
@@ -786,6 +789,8 @@ struct Planner {
     a.scale = 1.0f / std::sqrt((float)hd);
     a.out = out; a.ldo = ldo;
     a.pv_fp8 = (h->attn_fp8 && prec != PREC_F32) ? 1 : 0;
+    a.exact_only = h->attn_optimistic ? 0 : 1;
+    a.fallbacks = h->attn_fallbacks;
     const int pr = prec;
     add(name, [=](hipStream_t s) { return launch_attention(a, hd, pr, s); }, 2, 4.0 * B * a.H * (double)Lq * Lk * hd,
         (double)opsz * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
@@ -964,6 +969,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   h->t_dev = P.alloc<float>((size_t)B);
   h->step_dev = P.alloc<int>(64);
   h->ln_health = P.alloc<unsigned>(64);
+  h->attn_fallbacks = h->ln_health + 32;          // (same zero-initialised block; the LayerNorm read-out uses words 0 and 16)
   // ---- shared scratch
   P.gn_rows = 32;
   P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
@@ -1237,6 +1243,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_ATTN_OPTIMISTIC")) h->attn_optimistic = atoi(e) != 0;
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1316,7 +1323,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_gn_gemm")) opt = &h->fuse_gn_gemm;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, attn_fp8)", name);
+  else if (!strcmp(name, "attn_optimistic")) opt = &h->attn_optimistic;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, attn_fp8, attn_optimistic)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1445,6 +1453,12 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
   if (!h->coef_dev) HIPCHK(hipMalloc((void**)&h->coef_dev, (size_t)kMaxSteps * NS2VC_NCOEF * sizeof(float)));
   HIPCHK(hipDeviceSynchronize());   // a previous loop may still be reading the table
   HIPCHK(hipMemcpy(h->coef_dev, coef_host, (size_t)steps * NS2VC_NCOEF * sizeof(float), hipMemcpyHostToDevice));
+  {
+    unsigned long long hsh = 1469598103934665603ull;
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(coef_host);
+    for (size_t i = 0; i < (size_t)steps * NS2VC_NCOEF * sizeof(float); ++i) { hsh ^= pb[i]; hsh *= 1099511628211ull; }
+    h->coef_hash = hsh;
+  }
   h->steps = steps;
   h->temb_table_valid = false;
   h->next_step = -1;
@@ -1531,6 +1545,7 @@ int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream) {
   if (dst->device != src->device) return fail("handoff between engines on different devices");
   if (src->next_step < 0) return fail("source engine has no sampling loop in progress");
   if (!dst->coef_dev || dst->steps != src->steps) return fail("destination engine must hold the same solver table (%d vs %d steps)", dst->steps, src->steps);
+  if (dst->coef_hash != src->coef_hash) return fail("destination engine holds a DIFFERENT solver table with the same number of steps (solver / order / betas differ)");
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)src->B * src->T * src->CP;
   HIPCHK(launch_copy16(src->xe, dst->xe, n * sizeof(float), s));
@@ -1541,6 +1556,26 @@ int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream) {
   HIPCHK(launch_fill_i32(dst->step_dev, src->next_step - 1, s));
   dst->next_step = src->next_step;
   src->next_step = -1;
+  return 0;
+}
+
+int ns2vc_sampler_peek(ns2vc_unet* h, float* x_out_bct, void* stream) {
+  if (check_ready(h, true)) return 1;
+  if (!x_out_bct) return fail("null tensor");
+  if (h->next_step < 0) return fail("no sampling loop in progress");
+  HIPCHK(launch_btc_to_nct(h->xe, h->CP, h->cfg.latent_channels, h->T, h->B, x_out_bct, (hipStream_t)stream));
+  return 0;
+}
+
+int ns2vc_unet_attn_fallbacks(ns2vc_unet* h, unsigned long long* count, int reset, void* stream) {
+  if (!h || !count) return fail("null argument");
+  *count = 0;
+  if (!h->attn_fallbacks) return 0;             // no plan yet
+  unsigned v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->attn_fallbacks, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  *count = v;
+  if (reset) HIPCHK(launch_zero(h->attn_fallbacks, 16, (hipStream_t)stream));
   return 0;
 }
 

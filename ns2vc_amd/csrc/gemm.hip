@@ -1055,8 +1055,9 @@ static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
 }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
-static int g_spec = getenv("NS2VC_GEMM_SPEC") ? atoi(getenv("NS2VC_GEMM_SPEC")) : 1;   // A/B hook: 0 = round-2 tile choice
-void set_forced_gemm_tile(int bm, int bn, int stages) { g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
+static int g_spec = 1;   // loader / consumer tiles where the heuristic wants them; tests / tuning: ns2vc_debug_set_gemm_tile(-1, 0, 0) selects the round-2 (plain) tile choice, (-2, 0, 0) restores
+void set_forced_gemm_tile(int bm, int bn, int stages) {
+  if (bm == -1 || bm == -2) { g_spec = bm == -2 ? 1 : 0; return; } g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
 // Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
 // The compiled set is exactly what this function can return:

@@ -450,7 +450,7 @@ template <typename TM, int D, int R2, int NT> static hipError_t launch_rc(const 
 }
 // 64-token workgroups by default.  At dim 128 a workgroup's weights are small and M is large: when 64-token blocks would not
 // fit the chip in one round (one workgroup per CU: the LDS ring), 128-token blocks halve the grid and the weight traffic
-static int g_force_nt = getenv("NS2VC_ROWCHAIN_NT") ? atoi(getenv("NS2VC_ROWCHAIN_NT")) : 0;   // test / tuning hook: 1 / 2 forces the block size (2 only exists for dim 128)
+static int g_force_nt = 0;   // test / tuning hook (ns2vc_debug_set_rowchain_tokens): 1 / 2 forces the block size (2 only exists for dim 128)
 void set_forced_rowchain_tokens(int nt) { g_force_nt = nt; }
 template <typename TM> static hipError_t launch_rc_tm(const RowchainArgs& a, hipStream_t s) {
   if (a.dim == 128) {

@@ -224,7 +224,8 @@ class Engine:
             self.shape = None
 
     def set_option(self, name: str, value: bool) -> None:
-        """Plan options ("ln_linear", "fold_ff"; include/ns2vc_hip.h).  Changing one drops the plan: ``prepare`` again."""
+        """Plan options ("ln_linear", "fold_ff", "fuse_gn_gemm", "attn_optimistic", ...; include/ns2vc_hip.h).  Changing one drops
+        the plan: ``prepare`` again."""
         check(self.lib.ns2vc_unet_set_option(self.h, name.encode(), int(value)), f"set_option({name})")
         self.shape = None
 
@@ -300,8 +301,9 @@ class Engine:
         if tail is None or tail_steps <= 0:
             check(self.lib.ns2vc_sampler_run(self.h, _ptr(x_inout), int(use_graph), _stream_ptr(stream)), "sampler_run")
             return
-        if self.table is None or tail.table is None or tail.table.steps != self.table.steps:
-            raise Ns2vcError("mixed-precision sampling: both engines need the same solver table loaded")
+        if self.table is None or tail.table is None or tail.table.steps != self.table.steps or \
+                not np.array_equal(np.asarray(self.table.coef, dtype=np.float32), np.asarray(tail.table.coef, dtype=np.float32)):
+            raise Ns2vcError("mixed-precision sampling: both engines need the SAME solver table loaded (solver, steps, order, betas)")
         n, k = self.table.steps, min(int(tail_steps), self.table.steps)
         sp = _stream_ptr(stream)
         check(self.lib.ns2vc_sampler_begin(self.h, _ptr(x_inout), sp), "sampler_begin")
@@ -309,6 +311,27 @@ class Engine:
         check(self.lib.ns2vc_sampler_handoff(tail.h, self.h, sp), "sampler_handoff")
         check(self.lib.ns2vc_sampler_steps(tail.h, k, int(use_graph), sp), "sampler_steps(tail)")
         check(self.lib.ns2vc_sampler_end(tail.h, _ptr(x_inout), sp), "sampler_end")
+
+    # the loop in parts (what ``sample(tail=...)`` is made of), for callers that look at the state in mid-loop
+    def sample_begin(self, x_T, stream=None) -> None:
+        check(self.lib.ns2vc_sampler_begin(self.h, _ptr(x_T), _stream_ptr(stream)), "sampler_begin")
+
+    def sample_steps(self, n: int, use_graph: bool = True, stream=None) -> None:
+        check(self.lib.ns2vc_sampler_steps(self.h, int(n), int(use_graph), _stream_ptr(stream)), "sampler_steps")
+
+    def sample_peek(self, x_out, stream=None) -> None:
+        """x_e of the loop in progress (the point the NEXT evaluation is taken at) -> x_out (B,100,T); the loop goes on"""
+        check(self.lib.ns2vc_sampler_peek(self.h, _ptr(x_out), _stream_ptr(stream)), "sampler_peek")
+
+    def sample_end(self, x_out, stream=None) -> None:
+        check(self.lib.ns2vc_sampler_end(self.h, _ptr(x_out), _stream_ptr(stream)), "sampler_end")
+
+    def attn_fallbacks(self, reset: bool = True, stream=None) -> int:
+        """attention workgroups whose optimistic pass (no per-tile maximum) had to be repeated by the exact pass since the last
+        reset: each paid its kernel twice (scores rising > ~18 log2 units above their first 64 keys).  Waits for ``stream``."""
+        n = C.c_ulonglong()
+        check(self.lib.ns2vc_unet_attn_fallbacks(self.h, C.byref(n), int(reset), _stream_ptr(stream)), "attn_fallbacks")
+        return int(n.value)
 
     # -- profiling --------------------------------------------------------------------
     def op_info(self, which: int = 0) -> List[Tuple[str, int, float, float]]:

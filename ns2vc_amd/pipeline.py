@@ -49,11 +49,17 @@ class Denoiser:
 
     ``precision_check``: the 8e-4 of the fp16 mode was measured on procedural weights; a trained checkpoint with a few hot
     channels can land on either side of the 1e-3 bar (or saturate fp16 operands outright).  So a 16-bit Denoiser MEASURES
-    itself on the first call with a new set of weights / shape: the first evaluation is run on the 16-bit engine and on
-    the exact-fp32 engine (pinned to the reference at 1e-6) on the caller's own inputs, and the relative L2 between the two
-    (over the batch, the parity bar's own measure) is kept in ``precision_error_seen``.  Above ``precision_check`` (default 1e-3 for fp16;
-    None disables; bf16 is checked against 2e-2, its own level) the Denoiser warns and serves this and all later calls
-    from the fp32 engine (3.6x the step time, inside the bar by construction).  One host wait, once."""
+    itself ONCE PER SET OF WEIGHTS (the first call; ``recheck_precision()`` forces another): evaluations are run on the 16-bit
+    engine and on the exact-fp32 engine (pinned to the reference at 1e-6) on the caller's own inputs.  ``sample`` checks at
+    THREE points of its own trajectory -- the first, the middle and the last evaluation point of the loaded table (x_e taken
+    from a preliminary 16-bit loop; the last evaluations are the ones that set the sampled latent) --, ``denoise`` at the
+    given (x, t).  Two figures are kept and BOTH gated against ``precision_check`` (default 1e-3 for fp16; None disables;
+    bf16: 2e-2, its own level): the relative L2 over the batch -- the parity bar's own measure -- in ``precision_error_seen``
+    and the worst single utterance in ``precision_error_worst_item`` (maxima over the points; ``precision_errors`` has the
+    per-point list).  Above it the Denoiser warns and serves this and all later calls from the fp32 engine (3.6x the step time,
+    inside the bar by construction).  The verdict belongs to the weights, not to a shape: new shapes do NOT repeat it (they
+    used to: an fp32 re-prepare, two extra forwards and two host waits per group of ``GroupedConverter``), and the fp32 engine is
+    released again after a passed check unless a tail needs it (it is rebuilt on demand)."""
 
     def __init__(self, state: Dict[str, object], cfg: UNetConfig = UNetConfig(), precision: str = DEFAULT_PRECISION,
                  betas: Optional[np.ndarray] = None, ln_guard: Optional[float] = -1.0, tail_fp32: Optional[int] = None,
@@ -70,6 +76,7 @@ class Denoiser:
         self.ln_ratio_seen: Optional[float] = None
         self._ln_checked = False
         self._ln_pending = False
+        self._ln_switched = False
         self.tail_fp32 = tail_fp32
         self.tail_engine: Optional[Engine] = None
         if precision_check is not None and precision_check < 0:
@@ -77,6 +84,7 @@ class Denoiser:
         self.precision_check = precision_check if self.precision != "fp32" else None
         self.precision_error_seen: Optional[float] = None
         self.precision_error_worst_item: Optional[float] = None
+        self.precision_errors: list = []          # [(timestep, batch rel-L2, worst utterance)] of the last self-check
         self._precision_checked = False
         self.serving_fp32 = False        # set by a failed precision check: every call then runs on the fp32 engine
         self._tail_shape = None
@@ -92,6 +100,10 @@ class Denoiser:
                       f"{self.engine.precision} engine to explicit LayerNorm passes (ln_linear=0)" +
                       ("; the PREVIOUS result was computed above the threshold" if late else ""))
         self.engine.set_option("ln_linear", False)
+        if self.tail_engine is not None:     # the fp32 engine loses ~ratio^2 * 2^-24 under the same plan: switch it too
+            self.tail_engine.set_option("ln_linear", False)
+            self._tail_shape = None
+        self._ln_switched = True
         self._shape = None
         self._ln_checked = True          # the explicit plan does not depend on the ratio
         self.ln_guard = None
@@ -130,7 +142,6 @@ class Denoiser:
             self._shape = (B, T, Lp)
             self._ln_checked = False                # a new shape is a new set of rows: check synchronously once
             self._ln_pending = False
-            self._precision_checked = self.serving_fp32     # ... and measure the 16-bit engine against fp32 once (unless already demoted)
 
     def _table(self, solver: str, steps: int, order: int) -> None:
         key = (solver, steps, order)
@@ -143,6 +154,10 @@ class Denoiser:
         if self.tail_engine is None:
             self.tail_engine = Engine(self.cfg, precision="fp32")
             self.tail_engine.load_state_dict(self._state)
+            if self._ln_switched:
+                self.tail_engine.set_option("ln_linear", False)
+            self._tail_shape = None
+            self._tail_table_key = None
         if self._tail_shape != self._shape:
             import torch
             torch.cuda.synchronize()
@@ -161,30 +176,67 @@ class Denoiser:
             self._tail_table_key = key
         return e
 
-    def _self_check(self, x, t, c32, p32, mask, stream) -> None:
-        """first call: the same evaluation on the 16-bit and on the fp32 engine (class docstring, ``precision_check``)"""
+    def recheck_precision(self) -> None:
+        """forget the verdict of the precision self-check (after the weights were changed in place): the next call measures again"""
+        self._precision_checked = False
+        self.serving_fp32 = False
+
+    def _self_check(self, points, c32, p32, mask, stream, keep_fp32: bool) -> None:
+        """once per set of weights: the same evaluations on the 16-bit and on the fp32 engine (class docstring, ``precision_check``);
+        ``points`` = [(x, t)] with x (B,100,T) fp32 and t (B,) fp32"""
         import torch
         if self.precision_check is None or self._precision_checked:
             return
         self._precision_checked = True
         e32 = self._fp32_engine()
-        outs = []
-        for eng in (self.engine, e32):
-            o = torch.empty_like(x, dtype=torch.float32)
-            eng.set_condition(c32, p32, mask, stream=stream)
-            eng.forward(x, t, o, stream=stream)
-            outs.append(o)
-        num = (outs[0] - outs[1]).flatten(1).norm(dim=1)
-        den = outs[1].flatten(1).norm(dim=1).clamp_min(1e-30)
-        finite = bool(torch.isfinite(outs[0]).all())
-        # the parity bar's own measure: relative L2 over the whole batch (the worst single utterance is kept beside it)
-        err = float(num.norm() / den.norm()) if finite else float("inf")
-        self.precision_error_seen = err
-        self.precision_error_worst_item = float((num / den).max()) if finite else float("inf")
-        if not (err <= self.precision_check):
-            warnings.warn(f"{self.precision} engine is {err:.2e} (relative L2) from the exact-fp32 engine on this checkpoint / input "
-                          f"(> {self.precision_check:g}): serving from the fp32 engine from now on (precision_check=None disables)")
+        self.engine.set_condition(c32, p32, mask, stream=stream)
+        e32.set_condition(c32, p32, mask, stream=stream)
+        self.precision_errors = []
+        err, worst = 0.0, 0.0
+        for x, t in points:
+            outs = []
+            for eng in (self.engine, e32):
+                o = torch.empty_like(x, dtype=torch.float32)
+                eng.forward(x, t, o, stream=stream)
+                outs.append(o)
+            num = (outs[0] - outs[1]).flatten(1).norm(dim=1)
+            den = outs[1].flatten(1).norm(dim=1).clamp_min(1e-30)
+            finite = bool(torch.isfinite(outs[0]).all())
+            # the parity bar's own measure: relative L2 over the whole batch; the worst single utterance beside it
+            e_b = float(num.norm() / den.norm()) if finite else float("inf")
+            e_w = float((num / den).max()) if finite else float("inf")
+            self.precision_errors.append((float(t.flatten()[0]), e_b, e_w))
+            err, worst = max(err, e_b), max(worst, e_w)
+        self.precision_error_seen, self.precision_error_worst_item = err, worst
+        if not (err <= self.precision_check and worst <= self.precision_check):
+            warnings.warn(f"{self.precision} engine is {err:.2e} (relative L2 over the batch; worst utterance {worst:.2e}) from the exact-fp32 "
+                          f"engine on this checkpoint / input (> {self.precision_check:g}): serving from the fp32 engine from now on "
+                          f"(precision_check=None disables)")
             self.serving_fp32 = True
+        elif not keep_fp32:      # passed and no tail wants it: do not keep a second set of weights + workspace resident
+            self.tail_engine = None
+            self._tail_shape = None
+            self._tail_table_key = None
+
+    def _trajectory_points(self, x_T, use_graph, stream):
+        """(x_e, t) at the first, middle and last evaluation of the loaded table, from a preliminary loop on the 16-bit engine
+        (its condition must be set)"""
+        import torch
+        tm = np.asarray(self.engine.table.t_model, dtype=np.float32)
+        n = len(tm)
+        idx = sorted({0, n // 2, n - 1})
+        B = x_T.shape[0]
+        pts, pos = [], 0
+        self.engine.sample_begin(x_T, stream=stream)
+        for i in idx:
+            self.engine.sample_steps(i - pos, use_graph=use_graph, stream=stream)
+            pos = i
+            xe = torch.empty_like(x_T)
+            self.engine.sample_peek(xe, stream=stream)
+            pts.append((xe, torch.full((B,), float(tm[i]), dtype=torch.float32, device=x_T.device)))
+        scratch = torch.empty_like(x_T)
+        self.engine.sample_end(scratch, stream=stream)
+        return pts
 
     def denoise(self, x, t, content, prompt, prompt_mask=None):
         """One evaluation: x (B,100,T), t (B,), content (B,256,T), prompt (B,Lp,256), mask (B,Lp) bool -> x0_pred."""
@@ -195,7 +247,7 @@ class Denoiser:
         s = torch.cuda.current_stream(x.device)
         mask = None if prompt_mask is None else prompt_mask.to(torch.uint8).contiguous()
         c32, p32, x32, t32 = content.float().contiguous(), prompt.float().contiguous(), x.float().contiguous(), t.float().contiguous()
-        self._self_check(x32, t32, c32, p32, mask, s)
+        self._self_check([(x32, t32)], c32, p32, mask, s, keep_fp32=bool(self.tail_fp32))
         eng = self._fp32_engine() if self.serving_fp32 else self.engine
         eng.set_condition(c32, p32, mask, stream=s)
         out = torch.empty_like(x, dtype=torch.float32)
@@ -220,7 +272,6 @@ class Denoiser:
         if n_tail is None:
             n_tail = DEFAULT_TAIL_FP32.get(solver, 0) if self.precision != "fp32" else 0
         n_tail = max(0, min(int(n_tail), steps))
-        tail = self._tail(solver, steps, order, n_tail)
         if noise is None:
             noise = torch.randn((B, self.cfg.latent_channels, T), device=dev, generator=generator)
         x = noise.to(device=dev, dtype=torch.float32).contiguous().clone()
@@ -228,10 +279,9 @@ class Denoiser:
         mask = None if prompt_mask is None else prompt_mask.to(device=dev, dtype=torch.uint8).contiguous()
         c32, p32 = content.float().contiguous(), prompt.float().contiguous()
         if self.precision_check is not None and not self._precision_checked:
-            t0 = torch.full((B,), float(self.engine.table.t_model[0]), dtype=torch.float32, device=dev)
-            self._self_check(x, t0, c32, p32, mask, s)
-            if self.serving_fp32 and tail is None:
-                tail = self._tail(solver, steps, order, n_tail)
+            self.engine.set_condition(c32, p32, mask, stream=s)
+            self._self_check(self._trajectory_points(x, use_graph, s), c32, p32, mask, s, keep_fp32=n_tail > 0)
+        tail = self._tail(solver, steps, order, n_tail)
         if self.serving_fp32:            # a failed precision check: the whole loop on the fp32 engine
             tail.set_condition(c32, p32, mask, stream=s)
             tail.sample(x, use_graph=use_graph, stream=s)

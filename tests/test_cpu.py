@@ -464,6 +464,28 @@ def test_gather_latents_gloo_world2(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_harness_dry_run_multi_rank(n):
+    """`bench.py --gpus N`'s spawn / barrier / all-gather / per-rank reduction / strong_scaling / JSON path had never
+    executed with more than one rank (no multi-GPU box so far).  `--dry-dist N` runs exactly that path on CPU: N self-spawned ranks on
+    gloo, the engine replaced by a sleep + deterministic fill (every rank checks the gathered latents)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-dist", str(n), "--steps", "3", "--warmup", "1", "--reps", "2",
+                        "--batch", "2", "--seconds", "1", "--strong-batch", "13"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in d, key
+    assert d["n_gpus"] == n and d["rccl_ranks"] == n and d["steps"] == 3 and d["scaling"] == "weak" and d["spawned_by"] == "bench.py"
+    assert len(d["per_rank_ms_per_step"]) == n and d["config"]["global_batch"] == 2 * n and d["config"]["parallelism"] == f"dp{n}"
+    assert abs(d["value"] - n * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]          # whole-job aggregate over the ranks
+    assert d["all_gather_bytes"] == 2 * n * 100 * 94 * 4 and d["all_gather_ms"] >= 0.0
+    st = d["strong_scaling"]
+    assert st["global_batch"] == 13 and st["n_gpus"] == n and st["scaling"] == "strong" and st["per_rank_batch"] == (13 + n - 1) // n
+    assert d["dry_dist"]["backend"] == "gloo" and d["roofline"] is None and d["cpu_baseline"] is None
+
+
 def test_repeat_expand_matches_reference_golden():
     """ns2vc_amd.audio.repeat_expand_2d (index map + one gather) against outputs of the reference's own utils.repeat_expand_2d
     (utils.py:482-496): bit-identical, including non-integer ratios, target shorter than source, and batched input."""
@@ -615,3 +637,47 @@ def test_contentvec_restatement_shapes_names_and_pieces():
         from ns2vc_amd.service import segment_from_audio
         seg = segment_from_audio(m, wav[0], 12000, torch.zeros(100, 40), tag="a")
         assert seg.content.shape == (256, 12000 // 256) and seg.refer.shape == (100, 40) and seg.tag == "a"
+
+
+THIRDPARTY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_thirdparty.npz")
+_needs_thirdparty = pytest.mark.skipif(not os.path.exists(THIRDPARTY), reason="tests/golden/golden_thirdparty.npz not generated yet: run "
+                                       "tests/golden/make_golden_thirdparty.py where vocos / torchaudio / fairseq exist (f2 / f4 stay parity-unpinned until then)")
+
+
+@_needs_thirdparty
+def test_thirdparty_goldens_log_mel():
+    """f2, prompt side: ns2vc_amd.audio.log_mel against torchaudio's MelSpectrogram + log-clip as the reference calls it (infer_tool.py:170-182)"""
+    from ns2vc_amd.audio import log_mel
+    g = np.load(THIRDPARTY)
+    if "mel.log_mel" not in g.files:
+        pytest.skip("the fixture holds no mel.* block")
+    y = log_mel(torch.from_numpy(g["mel.wav24k"])).numpy()
+    assert y.shape == g["mel.log_mel"].shape and rel_l2(y, g["mel.log_mel"]) < 1e-5
+
+
+@_needs_thirdparty
+def test_thirdparty_goldens_vocos_decode():
+    """f2, back end: ns2vc_amd.vocoder.VocosDecoder.decode against vocos.decode (model.py:689-691); needs the vocoder's state dict (NS2VC_VOCOS_STATE)"""
+    from ns2vc_amd.vocoder import VocosDecoder
+    g = np.load(THIRDPARTY)
+    path = os.environ.get("NS2VC_VOCOS_STATE", "")
+    if "vocos.audio" not in g.files or not os.path.exists(path):
+        pytest.skip("no vocos.* block in the fixture, or NS2VC_VOCOS_STATE does not point at the vocoder's state dict")
+    dec = VocosDecoder().eval()
+    dec.load_vocos_state_dict(torch.load(path, map_location="cpu"))
+    y = dec.decode(torch.from_numpy(g["vocos.mel"])).numpy()
+    assert y.shape == g["vocos.audio"].shape and rel_l2(y, g["vocos.audio"]) < 1e-4
+
+
+@_needs_thirdparty
+def test_thirdparty_goldens_contentvec():
+    """f4: ns2vc_amd.contentvec.ContentVec.extract against fairseq's extract_features(output_layer=12) + final_proj (utils.py:221-236); needs the checkpoint (NS2VC_HUBERT_CKPT)"""
+    from ns2vc_amd.contentvec import ContentVec
+    g = np.load(THIRDPARTY)
+    path = os.environ.get("NS2VC_HUBERT_CKPT", "")
+    if "hubert.content" not in g.files or not os.path.exists(path):
+        pytest.skip("no hubert.* block in the fixture, or NS2VC_HUBERT_CKPT does not point at checkpoint_best_legacy_500.pt")
+    cv = ContentVec().eval()
+    cv.load_fairseq_state_dict(torch.load(path, map_location="cpu")["model"])
+    y = cv.extract(torch.from_numpy(g["hubert.wav16k"])).numpy()
+    assert y.shape == g["hubert.content"].shape and rel_l2(y, g["hubert.content"]) < 1e-4

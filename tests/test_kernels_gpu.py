@@ -889,6 +889,8 @@ def test_attention_optimistic_pass_and_its_fallback(prec, diag):
         a.bias = d_bias.ptr
         a.scale = 1.0 / np.sqrt(hd)
         outs = []
+        d_cnt = _dev(np.zeros(4, dtype=np.float32))
+        a.fallbacks = d_cnt.ptr
         for opt in (1, 0):
             d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
             a.out, a.ldo = d_out.ptr, D
@@ -900,12 +902,81 @@ def test_attention_optimistic_pass_and_its_fallback(prec, diag):
                 lib.ns2vc_debug_set_attn_optimistic(1)
             outs.append(d_out.read((B, Lq, D)))
         e_opt, e_exact, same = rel_l2(outs[0], ref), rel_l2(outs[1], ref), np.array_equal(outs[0], outs[1])
-        diag(f"attn optimistic pass prec={prec} {case}: default {e_opt:.3e} exact-only {e_exact:.3e} vs fp64; bitwise equal = {same}")
+        nfb, nwg = int(d_cnt.to_numpy((4,)).view(np.uint32)[0]), ((Lq + 127) // 128) * H * B
+        diag(f"attn optimistic pass prec={prec} {case}: default {e_opt:.3e} exact-only {e_exact:.3e} vs fp64; bitwise equal = {same}; "
+             f"fallback workgroups {nfb} of {nwg}")
+        assert nfb == 0 if case == "ordinary" else (nfb == nwg if prec == 2 else nfb <= nwg)      # the counter counts exactly the repeated workgroups
+        # the per-launch switch (what the engine option attn_optimistic sets) selects the exact pass too
+        a.exact_only = 1
+        d_out = OpBuf(np.full((B, Lq, D), np.nan, dtype=np.float32), prec)
+        a.out = d_out.ptr
+        check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention"); sync()
+        a.exact_only = 0
+        assert np.array_equal(d_out.read((B, Lq, D)), outs[1])
         assert np.isfinite(outs[0]).all() and np.isfinite(outs[1]).all()
         tol = 16 * eps16(prec) if case != "ordinary" else 2 * eps16(prec)
         assert e_opt < tol and e_exact < tol
         if case != "ordinary" and prec == 2:
             assert same                                         # fp16: the check rejected the optimistic pass in every workgroup
+
+
+def test_attention_fallback_rate_and_cost_at_the_bench_shape(diag):
+    """VERDICT r3 item 5 / ADVICE: the optimistic attention pass was only ever timed on procedural weights, where no workgroup
+    falls back.  Level-0 self-attention of the bench workload (32 x 8 heads x 938 x 938, hd 16, fp16) with (a) ordinary scores,
+    (b) a LATE-RISING maximum -- a fraction of the queries meets a key in the last third of the row whose score lies ~25 log2
+    units above everything before it -- for 0 %, 1 %, 10 % and 100 % of the queries: the fallback counter gives the share of
+    workgroups that ran twice, hipEvent timing what that costs; results must equal the exact pass in every case."""
+    import torch
+    from ns2vc_amd._lib import AttnArgs, check
+    from ns2vc_amd.engine import sync
+    lib = _lib()
+    prec, B, H, hd, L = 2, 32, 8, 16, 938
+    D = H * hd
+    rng = np.random.default_rng(7)
+    q0 = rng.standard_normal((B, L, D)).astype(np.float32)
+    k0 = rng.standard_normal((B, L, D)).astype(np.float32)
+    v = rng.standard_normal((B, L, D)).astype(np.float32)
+    rows = []
+    for frac in (0.0, 0.01, 0.1, 1.0):
+        q, k = q0.copy(), k0.copy()
+        hot_q = rng.random((B, L)) < frac
+        # hot queries point along e_0 of every head with norm 12; one late key per item does too (score 12 * 12 / 4 * log2e ~ 52 above the rest)
+        for h_ in range(H):
+            q[:, :, h_ * hd][hot_q] = 12.0
+            k[:, 700, h_ * hd] = 12.0
+        a = AttnArgs()
+        d_q, d_kv = OpBuf(q, prec), OpBuf(np.concatenate([k, v], axis=-1), prec)
+        d_cnt = _dev(np.zeros(4, dtype=np.float32))
+        a.q, a.k, a.v = d_q.ptr, d_kv.ptr, d_kv.ptr + D * 2
+        a.ldq, a.ldk, a.ldv = D, 2 * D, 2 * D
+        a.B, a.H, a.Lq, a.Lk = B, H, L, L
+        a.scale = 1.0 / np.sqrt(hd)
+        a.fallbacks = d_cnt.ptr
+        res = {}
+        for exact in (0, 1):
+            d_out = OpBuf(np.zeros((B, L, D), dtype=np.float32), prec)
+            a.out, a.ldo, a.exact_only = d_out.ptr, D, exact
+            check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention"); sync()      # warm
+            d_cnt.upload(np.zeros(4, dtype=np.float32))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            st = torch.cuda.current_stream()
+            e0.record(st)
+            for _ in range(10):
+                check(lib.ns2vc_k_attention(C.byref(a), hd, prec, st.cuda_stream), "k_attention")
+            e1.record(st); st.synchronize()
+            res[exact] = (e0.elapsed_time(e1) * 100.0, d_out.read((B, L, D)), int(d_cnt.to_numpy((4,)).view(np.uint32)[0]) // 10)
+        nwg = ((L + 127) // 128) * H * B
+        same = np.array_equal(res[0][1], res[1][1]) if frac in (0.0, 1.0) else None
+        rows.append((frac, res[0][2], nwg, res[0][0], res[1][0]))
+        diag(f"attention hd 16 at the bench shape, {100 * frac:g} % of the queries with a late-rising maximum: {res[0][2]} of {nwg} workgroups fell back; "
+             f"{res[0][0]:.1f} us per launch (exact pass only: {res[1][0]:.1f} us)" + ("" if same is None else f"; bitwise equal to the exact pass = {same}"))
+        assert np.isfinite(res[0][1]).all() and rel_l2(res[0][1], res[1][1]) < 2 * eps16(prec)
+        if frac == 0.0:
+            assert res[0][2] == 0
+        if frac == 1.0:
+            assert res[0][2] == nwg and same
+    # a workgroup that falls back pays about twice: the all-fallback launch must not cost more than ~2.3x the exact pass
+    assert rows[-1][3] < 2.3 * rows[-1][4] + 5.0
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
