@@ -102,9 +102,12 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   }
   {
     const i32x4_t rC = make_rsrc(a.consts2, (unsigned long long)G::CONSTS);
-    if (wave < G::CONSTS / 1024) blds16(rC, lane16, (unsigned)(wave * 1024), lds0 + RING * RC_PAIR + G::PANEL + wave * 1024);
+#pragma unroll
+    for (int pc = 0; pc < (G::CONSTS / 1024 + 7) / 8; ++pc)
+      if (8 * pc + wave < G::CONSTS / 1024)
+        blds16(rC, lane16, (unsigned)((8 * pc + wave) * 1024), lds0 + RING * RC_PAIR + G::PANEL + (8 * pc + wave) * 1024);
   }
-  static_assert(G::CONSTS / 1024 <= 8, "constants fit one DMA piece per wave");
+  static_assert(G::CONSTS % 1024 == 0, "constants are whole DMA pieces");
   auto issue_pair = [&](int p) __attribute__((always_inline)) {
     const int slot = p % RING;
 #pragma unroll
@@ -136,13 +139,15 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       }
 
   if (a.gn_x) {
-    constexpr int QPR = D / 4, RPP = 512 / QPR, NPASS = TOK / RPP;      // float4 quads per row, rows per pass
-    const int quad = tid % QPR, r0 = tid / QPR, c = 4 * quad;
+    // float4 quads per row, rows per pass (dim 384: 96 quads, 5 rows = 480 of the 512 threads), passes over the TOK rows
+    constexpr int QPR = D / 4, RPP = 512 / QPR, NPASS = (TOK + RPP - 1) / RPP;
+    const bool act = tid < RPP * QPR;
+    const int quad = act ? tid % QPR : 0, r0 = act ? tid / QPR : 0, c = 4 * quad;
     float4 xv[NPASS];
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      const int m = m0 + ps * RPP + r0;
-      xv[ps] = m < a.M ? *reinterpret_cast<const float4*>(a.gn_x + (size_t)m * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int row = ps * RPP + r0, m = m0 + row;
+      xv[ps] = (m < a.M && row < TOK) ? *reinterpret_cast<const float4*>(a.gn_x + (size_t)m * a.ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float4 ga = *reinterpret_cast<const float4*>(a.gn_gamma + c), be = *reinterpret_cast<const float4*>(a.gn_beta + c);
     // (mean, rstd) of every (batch item touched by this block, group): at most 4 items (the launcher checks T)
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       float y2 = xv[ps].z * s2 + (be.z - mr.x * s2), y3 = xv[ps].w * s3 + (be.w - mr.x * s3);
       if (m >= a.M) { y0 = 0.f; y1 = 0.f; y2 = 0.f; y3 = 0.f; }
       char* dst = panel + (c >> 6) * PTILE + row * 128 + ((((c & 63) >> 3) ^ ((row >> 1) & 7)) * 16) + (c & 4) * 2;
-      *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(y0, y1), Op16<TM>::pack(y2, y3));
+      if (act && row < TOK) *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(y0, y1), Op16<TM>::pack(y2, y3));
     }
     // (no barrier here: the first step_begin drains the LDS writes and synchronises the block before any fragment read)
   }
@@ -439,7 +444,7 @@ hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n
 }
 
 bool rowchain_eligible(int dim, int n2, int T, int prec) {
-  return (dim == 128 || dim == 256) && (n2 == dim || n2 == 3 * dim) && T >= 1 && (prec == PREC_BF16 || prec == PREC_F16);
+  return (dim == 128 || dim == 256 || dim == 384) && (n2 == dim || n2 == 3 * dim) && T >= 1 && (prec == PREC_BF16 || prec == PREC_F16);
 }
 
 template <typename TM, int D, int R2, int NT> static hipError_t launch_rc(const RowchainArgs& a, hipStream_t s) {
@@ -458,6 +463,7 @@ template <typename TM> static hipError_t launch_rc_tm(const RowchainArgs& a, hip
     if (big) return a.n2 == 128 ? launch_rc<TM, 128, 1, 2>(a, s) : launch_rc<TM, 128, 3, 2>(a, s);
     return a.n2 == 128 ? launch_rc<TM, 128, 1, 1>(a, s) : launch_rc<TM, 128, 3, 1>(a, s);
   }
+  if (a.dim == 384) return a.n2 == 384 ? launch_rc<TM, 384, 3, 1>(a, s) : launch_rc<TM, 384, 9, 1>(a, s);
   return a.n2 == 256 ? launch_rc<TM, 256, 2, 1>(a, s) : launch_rc<TM, 256, 6, 1>(a, s);
 }
 
@@ -481,6 +487,7 @@ hipError_t init_rowchain_attributes() {
   NS2VC_RC_ATTR(bf16_t, 128, 1, 1); NS2VC_RC_ATTR(bf16_t, 128, 3, 1); NS2VC_RC_ATTR(bf16_t, 256, 2, 1); NS2VC_RC_ATTR(bf16_t, 256, 6, 1);
   NS2VC_RC_ATTR(f16_t, 128, 1, 1); NS2VC_RC_ATTR(f16_t, 128, 3, 1); NS2VC_RC_ATTR(f16_t, 256, 2, 1); NS2VC_RC_ATTR(f16_t, 256, 6, 1);
   NS2VC_RC_ATTR(bf16_t, 128, 1, 2); NS2VC_RC_ATTR(bf16_t, 128, 3, 2); NS2VC_RC_ATTR(f16_t, 128, 1, 2); NS2VC_RC_ATTR(f16_t, 128, 3, 2);
+  NS2VC_RC_ATTR(bf16_t, 384, 3, 1); NS2VC_RC_ATTR(bf16_t, 384, 9, 1); NS2VC_RC_ATTR(f16_t, 384, 3, 1); NS2VC_RC_ATTR(f16_t, 384, 9, 1);
 #undef NS2VC_RC_ATTR
   return hipSuccess;
 }

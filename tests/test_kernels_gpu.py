@@ -1058,7 +1058,8 @@ def test_layout_roundtrip(diag):
 @pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dim,mult,M,res,nt", [(128, 3, 450, False, 1), (128, 1, 450, True, 1), (256, 3, 194, False, 1), (256, 1, 1000, True, 1),
                                                (128, 3, 64, False, 1), (256, 1, 5, True, 1), (128, 3, 450, False, 2), (128, 1, 333, True, 2),
-                                               (128, 1, 70, True, 2), (128, 3, 18000, False, 0)], ids=str)
+                                               (128, 1, 70, True, 2), (128, 3, 18000, False, 0), (384, 3, 194, False, 1), (384, 1, 450, True, 1),
+                                               (384, 3, 7520, False, 0), (384, 1, 7, True, 0)], ids=str)
 def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
     """Two token-local GEMMs with a LayerNorm in between in one launch (csrc/rowchain.hip) against numpy fp64 of
         y = A W1^T + b1 (+ res);   z = LayerNorm(y) W2^T + b2
@@ -1121,7 +1122,8 @@ def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("dim,B,T,nt", [(128, 3, 150, 1), (128, 5, 64, 2), (256, 2, 97, 1), (128, 2, 300, 2), (256, 4, 64, 1)], ids=str)
+@pytest.mark.parametrize("dim,B,T,nt", [(128, 3, 150, 1), (128, 5, 64, 2), (256, 2, 97, 1), (128, 2, 300, 2), (256, 4, 64, 1), (384, 3, 97, 1),
+                                        (384, 2, 235, 1)], ids=str)
 def test_rowchain_groupnorm_prologue(dim, B, T, nt, prec, diag):
     """The row-chain kernel with the transformer's GroupNorm in its prologue: A = GroupNorm(x) (8 groups, affine, eps 1e-6) is
     built inside the kernel from the fp32 rows and the int64 per-(item, 16-channel block) statistics a producer's epilogue
