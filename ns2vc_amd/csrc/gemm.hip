@@ -816,13 +816,31 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
   // tile is a scalar added by the hardware (buffer addressing), rows in the zero padding / past M are out-of-range
   // offsets that the DMA turns into zeros.  The K loop carries no address arithmetic.
   const int prow = (tid & (LTH - 1)) >> 3, pchunk = tid & 7;
+  constexpr unsigned SZB = sizeof(TM);
+  const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;      // source-side swizzle, bytes
+  unsigned vw[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * RPP + prow) * (unsigned)g.K) * SZB + acolb;
+  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
+  const int nk = g.K / BKE;
+#ifndef NS2VC_G4_EARLY_B
+#define NS2VC_G4_EARLY_B 1
+#endif
+  // The weight halves of the first tiles depend on nothing but the tile's column: they are in flight (cold: this layer's weights were
+  // last touched a step ago) while the activation rows' offsets -- an integer division per piece -- are still being computed.
+  if (NS2VC_G4_EARLY_B && loader) {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (s < nk) {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)(s * BKE) * SZB, lds0 + s * STAGE + wave * 1024 + BM * TROW + j * PASSB);
+      }
+  }
   const int Ctot = g.c0 + g.c1;
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
   const int ulim = g.tmode == TMODE_UP2 ? g.Tout : g.Tin;
   const int ushr = g.tmode == TMODE_UP2 ? 1 : 0;
-  constexpr unsigned SZB = sizeof(TM);
-  const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;      // source-side swizzle, bytes
   unsigned p0t0[LA], p0t1[LA], p0t2[LA], p1t0[LA], p1t1[LA], p1t2[LA], p2c[LA];    // [source tensor][tap] byte offsets
   const bool plain = g.taps == 1 && g.tmode == TMODE_SAME && g.c1 == 0 && g.c2 == 0;   // a linear: source row == output row
 #pragma unroll
@@ -847,14 +865,10 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
     p1t0[j] = off(r0, g.lda1); p1t1[j] = off(r1, g.lda1); p1t2[j] = off(r2, g.lda1);
     p2c[j] = off(toff == 0 ? r0 : r1, g.lda2);                         // the fused 1x1 segment reads the centre tap's rows
   }
-  unsigned vw[LB];
-#pragma unroll
-  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * RPP + prow) * (unsigned)g.K) * SZB + acolb;
   const unsigned long long rowsA = (unsigned long long)g.B * g.Tin;
   const i32x4_t rA0 = make_rsrc(g.a0, rowsA * g.lda0 * SZB);
   const i32x4_t rA1 = make_rsrc(g.c1 ? g.a1 : g.a0, rowsA * (g.c1 ? g.lda1 : g.lda0) * SZB);
   const i32x4_t rA2 = make_rsrc(g.c2 ? g.a2 : g.a0, rowsA * (g.c2 ? g.lda2 : g.lda0) * SZB);
-  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
 
   // K-order walk state (tiles are issued strictly in order): tap, channel offset inside the tap, position in K
   int is_tap = 0, is_cc = 0, is_k = 0;
@@ -917,20 +931,22 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = g.K / BKE;
   NS2VC_STAMP(1);
   const bool gnp = g.gnp_x != nullptr;             // (uniform over the grid)
+  const bool early_b = NS2VC_G4_EARLY_B || gnp;
   if (gnp) {
     // the weight tiles do not depend on the prologue: in flight first, then the rows this tile reads are built (the table of
     // the prologue lives in the ring stage nobody has been issued into yet), then their DMA
+    if (!NS2VC_G4_EARLY_B) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-      if (s < nk) issue_b(s, s);
+      for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) issue_b(s, s);
+    }
     gn_prologue<TM>(g, m0, BM, tid, 64 * NW, smem + (STAGES - 1) * STAGE);
   }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
-    if (s < nk) issue_tile(s, !gnp);
+    if (s < nk) issue_tile(s, !early_b);
   NS2VC_STAMP(2);
 
   const int l31 = lane & 31, hi = lane >> 5;
@@ -941,7 +957,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 #endif
   for (int kt = 0; kt < nk; ++kt) {
     const int after = min(STAGES - 2, nk - 1 - kt);
-    if (kt == 0 && gnp) {            // issue order was B(0) B(1) .. A(0) A(1) ..: tile 0 is complete when only the later A halves are out
+    if (kt == 0 && early_b) {        // issue order was B(0) B(1) .. A(0) A(1) ..: tile 0 is complete when only the later A halves are out
       if (STAGES == 3 && after >= 1) wait_vmcnt<LA>(); else wait_vmcnt<0>();
     } else if (STAGES >= 4 && after >= 2) wait_vmcnt<2 * LPT>();
     else if (STAGES >= 3 && after >= 1) wait_vmcnt<LPT>();
