@@ -636,121 +636,149 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 // column tiles of one row panel are produced redundantly with identical bytes (no ordering between workgroups needed; the
 // XCD-aware tile mapping keeps a row panel's column tiles on one L2, so the repeated fp32 reads hit it).
 // ---------------------------------------------------------------------------
-template <typename TM>
-__device__ __forceinline__ void gn_prologue(const GemmArgs& g, int m0, int BM, int tid, int nth, char* smem) {
-  const int C = g.c0, T = g.Tin, G = g.gnp_G, Cg = C / G;
-  const int toff = g.taps >> 1;
-  const int rlo = max(m0 - toff, 0), rhi = min(m0 + BM + toff, g.M);       // rows [rlo, rhi) of the flattened (item, frame) index
-  float2* const gtab = reinterpret_cast<float2*>(smem);                     // (mean, rstd) of (item - b_lo, group): <= 3 x 8
-  const int b_lo = rlo / T;
-  const int nbi = (rhi - 1) / T - b_lo + 1;                                 // <= 3 (the launcher checks T against the tile)
-  const int nq = C >> 2, rl = nth / nq;                                     // float4 quads per row, rows per pass
-  const int quad = tid % nq, rlane = tid / nq, c = quad * 4;
-  const bool active = rlane < rl;
-  float4 ga, be, t1[3], t2[3];
-#pragma unroll
-  for (int bi = 0; bi < 3; ++bi) t1[bi] = t2[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int XB = 6;                                                     // rows in flight per thread (1: no gain in the loop, 6: -1 %)
-  float4 xb[XB];
-  const int r0 = rlo + rlane;
-  // (every lane loads, from a clamped row: a straight-line batch of plain loads)
-  const int cq = active ? c : 0;
-  auto fetch = [&](int rb) __attribute__((always_inline)) {
+#ifndef NS2VC_GNP_WT
+#define NS2VC_GNP_WT 1
+#endif
+// In two halves: `begin` issues EVERY load of the prologue -- the first batch of fp32 rows, the int64 statistics of the (item, group)
+// pairs this tile touches, gamma / beta and the time scale / shift rows --, `finish` does the arithmetic and the stores.  (They run back to
+// back: hoisting `begin` above the kernel's row-offset set-up was measured and lost, see NS2VC_GNP_SPLIT.)
+template <typename TM> struct GnPrologue {
+  static constexpr int XB = 6;                                              // rows in flight per thread (1: no gain in the loop, 6: -1 %)
+  int rlo, rhi, b_lo, nbi, rl, r0, c, cq, Cg;
+  bool active;
+  float4 ga, be, t1[3], t2[3], xb[XB];
+  long long sv[8];                                                          // (sum, sum of squares) of up to four 16-channel blocks of one (item, group)
+
+  __device__ __forceinline__ void fetch(const GemmArgs& g, int rb) {        // (every lane loads, from a clamped row: a straight-line batch of plain loads)
 #pragma unroll
     for (int k = 0; k < XB; ++k) {
       const int r = min(rb + k * rl, rhi - 1);
       xb[k] = *reinterpret_cast<const float4*>(g.gnp_x + (size_t)r * g.gnp_ldx + cq);
     }
-  };
-  fetch(r0);                                                                // first batch in flight under the finalisation
-  // (after the loads above: they are in flight while wave 0 walks this chain of dependent loads and double arithmetic)
-  if (tid < nbi * G) {                                                      // same finalisation as gn_apply_kernel (misc.hip)
-    const int bi = tid / G, gg = tid - bi * G;
-    const int nb = Cg >> 4, nblk = C >> 4;
-    const long long* st = g.gnp_stats + ((size_t)(b_lo + bi) * nblk + (size_t)gg * nb) * 2;
-    double ds = 0.0, dq = 0.0;
-    for (int j = 0; j < nb; ++j) { ds += (double)st[2 * j] * (1.0 / GN_SUM_SCALE); dq += (double)st[2 * j + 1] * (1.0 / GN_SQ_SCALE); }
-    const float inv_nf = 1.0f / ((float)T * (float)Cg);
-    const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
-    const double mean = ds * inv_n;
-    double var = dq * inv_n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float ve = (float)var + g.gnp_eps;
-    float r = rsqrtf(ve);
-    r = r * (1.5f - 0.5f * ve * r * r);
-    gtab[bi * 8 + gg] = make_float2((float)mean, r);
   }
-  __syncthreads();
-  // (unconditional loads, no zero defaults: inactive threads read column 0)
-  ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);
-  be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
-  if (g.gnp_temb) {
+  __device__ __forceinline__ void begin(const GemmArgs& g, int m0, int BM, int tid, int nth) {
+    const int C = g.c0, T = g.Tin, G = g.gnp_G;
+    Cg = C / G;
+    const int toff = g.taps >> 1;
+    rlo = max(m0 - toff, 0); rhi = min(m0 + BM + toff, g.M);               // rows [rlo, rhi) of the flattened (item, frame) index
+    b_lo = rlo / T;
+    nbi = (rhi - 1) / T - b_lo + 1;                                         // <= 3 (the launcher checks T against the tile)
+    const int nq = C >> 2;                                                  // float4 quads per row
+    rl = nth / nq;                                                          // rows per pass
+    const int quad = tid % nq, rlane = tid / nq;
+    c = quad * 4;
+    active = rlane < rl;
+    r0 = rlo + rlane;
+    cq = active ? c : 0;
+    fetch(g, r0);
 #pragma unroll
-    for (int bi = 0; bi < 3; ++bi) {
-      const float* tp = g.gnp_temb + (size_t)(b_lo + min(bi, nbi - 1)) * g.gnp_ldtemb + cq;
-      if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
-        t1[bi] = *reinterpret_cast<const float4*>(tp);
-        t2[bi] = *reinterpret_cast<const float4*>(tp + C);
-      } else {
-        t1[bi] = make_float4(tp[0], tp[1], tp[2], tp[3]);
-        t2[bi] = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
-      }
+    for (int j = 0; j < 8; ++j) sv[j] = 0;
+    if (tid < nbi * G) {
+      const int bi = tid / G, gg = tid - bi * G;
+      const int nb = Cg >> 4, nblk = C >> 4;
+      const long long* st = g.gnp_stats + ((size_t)(b_lo + bi) * nblk + (size_t)gg * nb) * 2;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nb) { sv[2 * j] = st[2 * j]; sv[2 * j + 1] = st[2 * j + 1]; }
     }
-  }
-  if (active) {
-    const int gg = c / Cg;
-    float sc[3][4], sh[3][4];
-    const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
-    float2 mrs[3];
+    ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);                // (unconditional loads: inactive threads read column 0)
+    be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
 #pragma unroll
-    for (int bi = 0; bi < 3; ++bi) mrs[bi] = gtab[min(bi, nbi - 1) * 8 + gg];
-    // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
-    //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
-    // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
-    // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
-    // "gamma reads zero" non-determinism of round 3.  With every (mean, rstd) pair landed before the first packed product the
-    // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(mrs[0].x), "+v"(mrs[0].y), "+v"(mrs[1].x), "+v"(mrs[1].y), "+v"(mrs[2].x), "+v"(mrs[2].y));
+    for (int bi = 0; bi < 3; ++bi) t1[bi] = t2[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.gnp_temb) {
 #pragma unroll
-    for (int bi = 0; bi < 3; ++bi) {
-      const float2 mr = mrs[bi];
-      const float ts[4] = {t1[bi].x, t1[bi].y, t1[bi].z, t1[bi].w}, tf[4] = {t2[bi].x, t2[bi].y, t2[bi].z, t2[bi].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        sc[bi][e] = mr.y * gam[e];
-        sh[bi][e] = bet[e] - mr.x * sc[bi][e];
-        if (g.gnp_temb) {
-          const float s1 = 1.0f + ts[e];
-          sc[bi][e] *= s1;
-          sh[bi][e] = sh[bi][e] * s1 + tf[e];
-        }
-      }
-    }
-    TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
-    for (int rb = r0; rb < rhi; rb += XB * rl) {
-      float4 w[XB];
-#pragma unroll
-      for (int k = 0; k < XB; ++k) w[k] = xb[k];
-      fetch(min(rb + XB * rl, rhi - 1));                                    // next batch before this one is stored (clamped: the last one is a dummy)
-#pragma unroll
-      for (int k = 0; k < XB; ++k) {
-        const int r = rb + k * rl;
-        if (r < rhi) {
-          const int bi = (r >= (b_lo + 1) * T ? 1 : 0) + (r >= (b_lo + 2) * T ? 1 : 0);
-          float a[4], b[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
-          float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
-          if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-          out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
+      for (int bi = 0; bi < 3; ++bi) {
+        const float* tp = g.gnp_temb + (size_t)(b_lo + min(bi, nbi - 1)) * g.gnp_ldtemb + cq;
+        if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
+          t1[bi] = *reinterpret_cast<const float4*>(tp);
+          t2[bi] = *reinterpret_cast<const float4*>(tp + C);
+        } else {
+          t1[bi] = make_float4(tp[0], tp[1], tp[2], tp[3]);
+          t2[bi] = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
         }
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
-  __syncthreads();                                        // ... and so are everybody else's: the DMA may read them (and smem is free)
-}
+  __device__ __forceinline__ void finish(const GemmArgs& g, int tid, char* smem) {
+    const int C = g.c0, T = g.Tin, G = g.gnp_G;
+    float2* const gtab = reinterpret_cast<float2*>(smem);                   // (mean, rstd) of (item - b_lo, group): <= 3 x 8
+    if (tid < nbi * G) {                                                    // same finalisation as gn_apply_kernel (misc.hip)
+      const int bi = tid / G, gg = tid - bi * G;
+      const int nb = Cg >> 4;
+      double ds = 0.0, dq = 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < nb) { ds += (double)sv[2 * j] * (1.0 / GN_SUM_SCALE); dq += (double)sv[2 * j + 1] * (1.0 / GN_SQ_SCALE); }
+      const float inv_nf = 1.0f / ((float)T * (float)Cg);
+      const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
+      const double mean = ds * inv_n;
+      double var = dq * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float ve = (float)var + g.gnp_eps;
+      float r = rsqrtf(ve);
+      r = r * (1.5f - 0.5f * ve * r * r);
+      gtab[bi * 8 + gg] = make_float2((float)mean, r);
+    }
+    __syncthreads();
+    if (active) {
+      const int gg = c / Cg;
+      float sc[3][4], sh[3][4];
+      const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+      float2 mrs[3];
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) mrs[bi] = gtab[min(bi, nbi - 1) * 8 + gg];
+      // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
+      //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
+      // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
+      // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
+      // "gamma reads zero" non-determinism of round 3.  With every (mean, rstd) pair landed before the first packed product the
+      // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(mrs[0].x), "+v"(mrs[0].y), "+v"(mrs[1].x), "+v"(mrs[1].y), "+v"(mrs[2].x), "+v"(mrs[2].y));
+#pragma unroll
+      for (int bi = 0; bi < 3; ++bi) {
+        const float2 mr = mrs[bi];
+        const float ts[4] = {t1[bi].x, t1[bi].y, t1[bi].z, t1[bi].w}, tf[4] = {t2[bi].x, t2[bi].y, t2[bi].z, t2[bi].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sc[bi][e] = mr.y * gam[e];
+          sh[bi][e] = bet[e] - mr.x * sc[bi][e];
+          if (g.gnp_temb) {
+            const float s1 = 1.0f + ts[e];
+            sc[bi][e] *= s1;
+            sh[bi][e] = sh[bi][e] * s1 + tf[e];
+          }
+        }
+      }
+      TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
+      for (int rb = r0; rb < rhi; rb += XB * rl) {
+        float4 w[XB];
+#pragma unroll
+        for (int k = 0; k < XB; ++k) w[k] = xb[k];
+        fetch(g, min(rb + XB * rl, rhi - 1));                               // next batch before this one is stored (clamped: the last one is a dummy)
+#pragma unroll
+        for (int k = 0; k < XB; ++k) {
+          const int r = rb + k * rl;
+          if (r < rhi) {
+            const int bi = (r >= (b_lo + 1) * T ? 1 : 0) + (r >= (b_lo + 2) * T ? 1 : 0);
+            float a[4], b[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
+            float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
+            if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+#if NS2VC_GNP_WT
+            out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
+#else
+            store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);    // only this workgroup reads these rows back (through the same L2): no need to push them to memory now
+#endif
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
+    __syncthreads();                                        // ... and so are everybody else's: the DMA may read them (and smem is free)
+  }
+};
 
 // SPEC (r3): loader / consumer wave specialisation.  profiles/r03_gemm_ablate4.txt: the DMA stream alone and the reads + MFMAs
 // alone each take about half of the full loop's time -- they do not overlap, because every wave issues its DMA pieces (an
@@ -836,6 +864,14 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
         for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)(s * BKE) * SZB, lds0 + s * STAGE + wave * 1024 + BM * TROW + j * PASSB);
       }
   }
+  const bool gnp = g.gnp_x != nullptr;             // (uniform over the grid)
+  GnPrologue<TM> gpro;
+  // (measured r4, same box: issuing the prologue's loads up here, before the row-offset set-up, LOSES 1 % -- 3.962 vs 3.921 ms/step -- and
+  //  plain instead of write-through stores of the rows change nothing, profiles/r04_ab_gn_prologue_variants.txt; both stay compile-time options)
+#ifndef NS2VC_GNP_SPLIT
+#define NS2VC_GNP_SPLIT 0
+#endif
+  if (NS2VC_GNP_SPLIT && gnp) gpro.begin(g, m0, BM, tid, 64 * NW);
   const int Ctot = g.c0 + g.c1;
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
@@ -932,7 +968,6 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   NS2VC_STAMP(1);
-  const bool gnp = g.gnp_x != nullptr;             // (uniform over the grid)
   const bool early_b = NS2VC_G4_EARLY_B || gnp;
   if (gnp) {
     // the weight tiles do not depend on the prologue: in flight first, then the rows this tile reads are built (the table of
@@ -942,7 +977,8 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue_b(s, s);
     }
-    gn_prologue<TM>(g, m0, BM, tid, 64 * NW, smem + (STAGES - 1) * STAGE);
+    if (!NS2VC_GNP_SPLIT) gpro.begin(g, m0, BM, tid, 64 * NW);
+    gpro.finish(g, tid, smem + (STAGES - 1) * STAGE);
   }
 #pragma unroll
   for (int s = 0; s < STAGES - 1; ++s)
