@@ -140,8 +140,20 @@ template <> __device__ __forceinline__ void store_op4<f16_t>(f16_t* p, float a, 
 #ifndef NS2VC_WT_STORES
 #define NS2VC_WT_STORES 1
 #endif
-#ifndef NS2VC_WT_MOD
+#ifndef NS2VC_WT_MODE
+#define NS2VC_WT_MODE 1
+#endif
+#ifndef NS2VC_WT_MOD            // cache-policy bits of those stores; NS2VC_WT_MODE selects one for A/B builds (1 = shipped).  r4, same box, ms/step:
+                                // sc1 3.709 | sc1 nt 3.827 | nt 3.808 | sc0 sc1 3.704 (profiles/r04_ab_store_policy.txt)
+#if NS2VC_WT_MODE == 2
+#define NS2VC_WT_MOD "sc1 nt"
+#elif NS2VC_WT_MODE == 3
+#define NS2VC_WT_MOD "nt"
+#elif NS2VC_WT_MODE == 4
+#define NS2VC_WT_MOD "sc0 sc1"
+#else
 #define NS2VC_WT_MOD "sc1"
+#endif
 #endif
 __device__ __forceinline__ void out_store16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
 #if NS2VC_WT_STORES

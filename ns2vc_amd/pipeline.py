@@ -327,7 +327,13 @@ class OverlappedPipeline:
     """
 
     def __init__(self, denoiser: Denoiser, pre_fn, post_fn, solver: str = "unipc", steps: int = 20, order: int = 2,
-                 use_graph: bool = True):
+                 use_graph: bool = True, pre_device=None, post_device=None):
+        """``pre_device`` / ``post_device`` (r4): run the front / back end on ANOTHER ROCm device of the node.  On one GPU the three streams
+        serialise (the denoiser's launches hold every CU: 7.8 % of the stages' kernel time overlaps, profiles/r03_overlap_trace.txt); a stage
+        on its own device overlaps by construction and only its tensors cross xGMI -- content + prompt 35 MB per 32 x 10 s batch in, the
+        latent 12 MB out, stream-ordered peer copies behind the stage's event.  ``pre_fn`` then runs with ``pre_device`` current and must
+        return tensors on it; ``post_fn`` receives the latent on ``post_device``.  None = the denoiser's device (the one-GPU pipeline).
+        NOT measured on two devices yet (no multi-GPU box this round)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("OverlappedPipeline needs a ROCm device (there is no CPU path)")
@@ -335,11 +341,18 @@ class OverlappedPipeline:
         self.kw = dict(solver=solver, steps=steps, order=order, use_graph=use_graph)
         dev = torch.device("cuda", torch.cuda.current_device())
         self.device = dev
-        self.s_pre, self.s_den, self.s_post = (torch.cuda.Stream(dev) for _ in range(3))
+        self.pre_device = torch.device(pre_device) if pre_device is not None else dev
+        self.post_device = torch.device(post_device) if post_device is not None else dev
+        for d in (self.pre_device, self.post_device):
+            if d.type != "cuda" or (d.index is not None and d.index >= torch.cuda.device_count()):
+                raise ValueError(f"stage device {d} is not a visible ROCm device")
+        self.s_pre = torch.cuda.Stream(self.pre_device)
+        self.s_den = torch.cuda.Stream(dev)
+        self.s_post = torch.cuda.Stream(self.post_device)
 
     def _launch_pre(self, item):
         import torch
-        with torch.cuda.stream(self.s_pre):
+        with torch.cuda.device(self.pre_device), torch.cuda.stream(self.s_pre):
             cond = self.pre_fn(item)
             ev = torch.cuda.Event()
             ev.record(self.s_pre)
@@ -356,17 +369,21 @@ class OverlappedPipeline:
             item, cond, ev_pre = cur
             nxt = next(it, None)
             nxt_pre = self._launch_pre(nxt) if nxt is not None else None     # front end of batch k+1 under denoise(k)
-            with torch.cuda.stream(self.s_den):
+            with torch.cuda.device(self.device), torch.cuda.stream(self.s_den):
                 self.s_den.wait_event(ev_pre)
-                for v in cond.values():
+                for k_, v in list(cond.items()):
                     if isinstance(v, torch.Tensor):
                         v.record_stream(self.s_den)
+                        if v.device != self.device:          # front end on another device: peer copy, ordered behind its event on the denoiser's stream
+                            cond[k_] = v.to(self.device, non_blocking=True)
                 latent = self.denoiser.sample(cond["content"], cond["prompt"], cond.get("prompt_mask"), cond.get("noise"), **self.kw)
                 ev_den = torch.cuda.Event()
                 ev_den.record(self.s_den)
-            with torch.cuda.stream(self.s_post):
+            with torch.cuda.device(self.post_device), torch.cuda.stream(self.s_post):
                 self.s_post.wait_event(ev_den)
                 latent.record_stream(self.s_post)
+                if latent.device != self.post_device:        # back end on another device: the latent crosses behind the denoiser's event
+                    latent = latent.to(self.post_device, non_blocking=True)
                 results.append(self.post_fn(latent, item))                   # back end of batch k under denoise(k+1)
             cur = nxt_pre
         self.s_post.synchronize()

@@ -438,6 +438,16 @@ def test_overlapped_pipeline_matches_sequential(diag):
                  f"differing {int((a != b).sum())}/{a.numel()}")
         assert torch.equal(a, b)
     diag(f"overlapped pipeline: 5 batches sequential {t_seq * 1e3:.1f} ms, three-stream {t_ovl * 1e3:.1f} ms")
+    # r4: stage devices.  With the denoiser's own device named explicitly the pipeline is the same one; with a second visible device the
+    # front end runs there and its tensors cross by stream-ordered peer copies -- results must not change (the stages are deterministic)
+    n_dev = torch.cuda.device_count()
+    other = torch.device("cuda", 1) if n_dev > 1 else dev
+    pre_dev = (lambda k: {kk: (v.to(other) if isinstance(v, torch.Tensor) else v) for kk, v in pre_fn(k).items()}) if n_dev > 1 else pre_fn
+    out2 = OverlappedPipeline(den, pre_dev, post_fn, solver="unipc", steps=6, order=2, pre_device=other, post_device=dev).run(items)
+    assert all(torch.equal(a, b) for a, b in zip(out2, seq))
+    diag(f"overlapped pipeline with pre_device={other} ({n_dev} device(s) visible): identical results")
+    with pytest.raises(ValueError):
+        OverlappedPipeline(den, pre_fn, post_fn, pre_device=torch.device("cuda", n_dev))
 
 
 _SHARD_WORKER = r'''

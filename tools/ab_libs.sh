@@ -2,8 +2,9 @@
 # same-box A/B of library builds / plan switches inside the captured bench loop:  bash tools/ab_libs.sh "<lib|default> [ENV=VAL ...]" ...
 # each argument is one configuration: a variant name under ns2vc_amd/lib/variants (or `default`) followed by environment assignments
 cd "$(dirname "$0")/.."
+CFGS=("$@")
 for r in 1 2; do
-  for cfg in "$@"; do
+  for cfg in "${CFGS[@]}"; do
     set -- $cfg; lib=$1; shift
     ( for kv in "$@"; do export "$kv"; done
       if [ "$lib" != default ]; then export NS2VC_LIB=$PWD/ns2vc_amd/lib/variants/$lib/libns2vc_hip.so; fi
