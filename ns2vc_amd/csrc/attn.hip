@@ -288,14 +288,18 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   // exact up to the rounding of the probabilities.
   constexpr bool OPT = NS2VC_ATTN_OPT && !P8 && sizeof(TM) == 2;
   constexpr float OPT_MARGIN = 4.0f;
-  auto run = [&](auto optimistic) __attribute__((always_inline)) {
+  // `compute` (wave-uniform): false = this wave keeps the accumulators it has and only helps staging the K / V tiles (r4: the exact pass of
+  // a workgroup is computed by the waves that hold a failing row; the others would only burn the VALU slots that bound this kernel)
+  auto run = [&](auto optimistic, const bool compute) __attribute__((always_inline)) {
   constexpr bool O = decltype(optimistic)::value;
+  if (compute) {
 #pragma unroll
-  for (int d = 0; d < DT; ++d)
+    for (int d = 0; d < DT; ++d)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  m_ref = 0.f;
-  qaux = hi == 0 ? aux_chunk<TM>(-m_ref, 1.0f) : u32x4_t{0, 0, 0, 0};
+      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    m_ref = 0.f;
+    qaux = hi == 0 ? aux_chunk<TM>(-m_ref, 1.0f) : u32x4_t{0, 0, 0, 0};
+  }
   load_tile(0);
   __syncthreads();          // constants written (first pass) / everybody is done with the stages (second pass)
   store_tile(0, 0);
@@ -305,6 +309,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
     if (t + 1 < ntile) load_tile(t + 1);
     const char* Ks = smem + (t & 1) * STAGE;
     const char* Vs = Ks + KBYTES;
+    if (compute) {
 
     // ---- S'^T[key][q] = sum_d K[key][d] * (Q[q][d]*scale*log2e) + 1*(-m_ref[q]) + bias[key]*1   (two 32-key sub-tiles)
     f32x16_t s[NSUB];
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
       }
     }
     }
+    }   // compute
     if (t + 1 < ntile) store_tile((t + 1) & 1, (t + 1) * KEYS);
     __syncthreads();
   }
@@ -393,18 +399,19 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   constexpr int LB = HD / 32, LR = ((HD % 32) / 8) * 4;
   static_assert(HD % 32 == 0 || HD % 32 == 16, "ones row must sit at row 0 or 16 of its 32-row block");
   if (OPT && !g_attn_exact_only && !a.exact_only) {
-    run(OptTag<true>{});
+    run(OptTag<true>{}, true);
     // the denominator of this lane's query (lane half 0 holds it) bounds every probability of the row: below 2^14 none of them
     // reached the fp16 range (the converts SATURATE under MODE.FP16_OVFL, so an overflow would not show up as inf), and it is
     // positive unless every probability flushed to zero -- otherwise the exact pass decides
     const float lq = o[LB][LR];
     const int bad = (hi == 0 && q < a.Lq && !(lq > 0.f && lq < 16384.f)) ? 1 : 0;
+    const bool wave_bad = __any(bad) != 0;
     if (__syncthreads_or(bad)) {
-      if (a.fallbacks && threadIdx.x == 0) atomicAdd(a.fallbacks, 1u);      // (this workgroup pays the kernel twice: counted, ns2vc_unet_attn_fallbacks)
-      run(OptTag<false>{});
+      if (a.fallbacks && threadIdx.x == 0) atomicAdd(a.fallbacks, 1u);      // (this workgroup stages its tiles twice: counted, ns2vc_unet_attn_fallbacks)
+      run(OptTag<false>{}, wave_bad);
     }
   } else {
-    run(OptTag<false>{});
+    run(OptTag<false>{}, true);
   }
 
   // ---- normalise and store O[q][h*HD + d]; lane holds d = dt*32 + 8*g + 4*hi + i.  The denominator is row HD of the

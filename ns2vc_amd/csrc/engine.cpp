@@ -1180,6 +1180,7 @@ void drop_plan(ns2vc_unet* h) {
   h->arena_bytes = h->arena_used = 0;
   h->next_step = -1;           // the solver state lived in the arena
   h->ln_posted = false;
+  h->attn_fallbacks = nullptr; // (the counter lived in the arena too)
 }
 
 }  // namespace

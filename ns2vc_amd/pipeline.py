@@ -15,7 +15,7 @@ import numpy as np
 from . import dist as _dist
 from .engine import DEFAULT_PRECISION, Engine
 from .schedule import linear_betas
-from .spec import UNetConfig
+from .spec import UNetConfig, attention_workgroups_per_forward
 
 
 # default number of trailing fp32 evaluations of a 16-bit sampling loop, per solver (``Denoiser(tail_fp32=None)``):
@@ -59,12 +59,22 @@ class Denoiser:
     per-point list).  Above it the Denoiser warns and serves this and all later calls from the fp32 engine (3.6x the step time,
     inside the bar by construction).  The verdict belongs to the weights, not to a shape: new shapes do NOT repeat it (they
     used to: an fp32 re-prepare, two extra forwards and two host waits per group of ``GroupedConverter``), and the fp32 engine is
-    released again after a passed check unless a tail needs it (it is rebuilt on demand)."""
+    released again after a passed check unless a tail needs it (it is rebuilt on demand).
+
+    ``attn_fallback_limit`` (r4): the 16-bit attention kernels first run an optimistic pass without the per-tile maximum (-10 % of their time) and
+    repeat a workgroup exactly when a row's scores rose far above its first 64 keys.  With procedural weights that never happens; on a
+    checkpoint with sharp attention it can: measured at the bench shape, 1 % of such rows sends 66 % of the workgroups through both passes
+    (86 us instead of 45 per launch; the exact pass alone takes 50).  So the first loop / evaluation with a set of weights reads the engine's
+    fallback counter (one host wait, once) and, above this share of workgroups (default 0.10, about the break-even), switches the engine to
+    ``attn_optimistic`` 0 with a warning; ``attn_fallback_rate_seen`` keeps the measured share.  None disables."""
 
     def __init__(self, state: Dict[str, object], cfg: UNetConfig = UNetConfig(), precision: str = DEFAULT_PRECISION,
                  betas: Optional[np.ndarray] = None, ln_guard: Optional[float] = -1.0, tail_fp32: Optional[int] = None,
-                 precision_check: Optional[float] = -1.0):
+                 precision_check: Optional[float] = -1.0, attn_fallback_limit: Optional[float] = 0.10):
         self.cfg = cfg
+        self.attn_fallback_limit = attn_fallback_limit if precision not in ("fp32", "f32") else None
+        self.attn_fallback_rate_seen: Optional[float] = None
+        self._attn_checked = False
         self.precision = {"f32": "fp32", "f16": "fp16"}.get(precision, precision)
         self.engine = Engine(cfg, precision=precision)
         self.engine.load_state_dict(state)
@@ -176,10 +186,25 @@ class Denoiser:
             self._tail_table_key = key
         return e
 
+    def _attn_check(self, evals: int, stream) -> None:
+        """once per set of weights: share of attention workgroups that needed the exact fallback during the last ``evals`` evaluations"""
+        if self.attn_fallback_limit is None or self._attn_checked or evals <= 0:
+            return
+        self._attn_checked = True
+        B, T, _ = self._shape
+        n = self.engine.attn_fallbacks(reset=True, stream=stream)
+        self.attn_fallback_rate_seen = n / float(max(1, evals * attention_workgroups_per_forward(self.cfg, B, T)))
+        if self.attn_fallback_rate_seen > self.attn_fallback_limit:
+            warnings.warn(f"{100 * self.attn_fallback_rate_seen:.0f} % of the attention workgroups needed the exact fallback on this checkpoint / input "
+                          f"(> {100 * self.attn_fallback_limit:.0f} %): each of them ran twice -- switching the engine to the exact pass only (attn_optimistic=0)")
+            self.engine.set_option("attn_optimistic", False)
+            self._shape = None
+
     def recheck_precision(self) -> None:
         """forget the verdict of the precision self-check (after the weights were changed in place): the next call measures again"""
         self._precision_checked = False
         self.serving_fp32 = False
+        self._attn_checked = False
 
     def _self_check(self, points, c32, p32, mask, stream, keep_fp32: bool) -> None:
         """once per set of weights: the same evaluations on the 16-bit and on the fp32 engine (class docstring, ``precision_check``);
@@ -251,10 +276,15 @@ class Denoiser:
         eng = self._fp32_engine() if self.serving_fp32 else self.engine
         eng.set_condition(c32, p32, mask, stream=s)
         out = torch.empty_like(x, dtype=torch.float32)
+        first_attn = not self.serving_fp32 and not self._attn_checked and self.attn_fallback_limit is not None
+        if first_attn:
+            eng.attn_fallbacks(reset=True, stream=s)          # count this evaluation alone
         eng.forward(x32, t32, out, stream=s)
         if self.serving_fp32:
             return out
         redone = self._guard_after(s, lambda: self.denoise(x, t, content, prompt, prompt_mask))
+        if first_attn and redone is None:
+            self._attn_check(1, s)                            # (after the guard's read-out: a switch drops the plan)
         return out if redone is None else redone
 
     def sample(self, content, prompt, prompt_mask=None, noise=None, solver: str = "unipc", steps: int = 20, order: int = 2,
@@ -289,9 +319,14 @@ class Denoiser:
         self.engine.set_condition(c32, p32, mask, stream=s)
         if tail is not None:
             tail.set_condition(c32, p32, mask, stream=s)
+        first_attn = not self._attn_checked and self.attn_fallback_limit is not None
+        if first_attn:
+            self.engine.attn_fallbacks(reset=True, stream=s)      # count this loop alone (the self-check's evaluations are behind us)
         self.engine.sample(x, use_graph=use_graph, stream=s, tail=tail, tail_steps=n_tail if tail is not None else 0)
         redone = self._guard_after(s, lambda: self.sample(content, prompt, prompt_mask, noise, solver, steps, order, use_graph,
                                                           tail_fp32=tail_fp32))
+        if first_attn and redone is None:
+            self._attn_check(steps - (n_tail if tail is not None else 0), s)      # (after the guard's read-out: a switch drops the plan)
         return x if redone is None else redone
 
     def sample_sharded(self, content, prompt, prompt_mask, noise, **kw):

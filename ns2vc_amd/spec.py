@@ -147,6 +147,18 @@ def topology(cfg: UNetConfig) -> List[BlockSpec]:
     return blocks
 
 
+def attention_workgroups_per_forward(cfg: UNetConfig, B: int, T: int) -> int:
+    """Workgroups of all attention launches of one denoiser evaluation (a workgroup = 128 queries of one head of one batch item; self- and
+    cross-attention of every transformer block): the denominator of the optimistic-pass fallback rate (``Engine.attn_fallbacks``)."""
+    n = 0
+    for b in topology(cfg):
+        Tl = T
+        for _ in range(b.level):
+            Tl = (Tl + 1) // 2
+        n += len(b.attns) * 2 * ((Tl + 127) // 128) * cfg.heads * B
+    return n
+
+
 def _resnet_params(r: ResnetSpec, temb: int) -> List[Tuple[str, Tuple[int, ...]]]:
     p = [
         (f"{r.prefix}.norm1.weight", (r.cin,)), (f"{r.prefix}.norm1.bias", (r.cin,)),

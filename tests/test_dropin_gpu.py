@@ -349,6 +349,40 @@ def test_precision_self_check_once_per_weights_at_three_trajectory_points(state,
     assert len(d.precision_errors) == 3 and d.precision_errors != errs
 
 
+def test_denoiser_switches_off_the_optimistic_attention_when_it_falls_back_too_often(state, diag):
+    """ADVICE r3 / r3 review item 5: the optimistic attention pass pays only while (almost) no workgroup has to repeat it; at the bench shape 1 % of
+    rows with a late-rising score maximum already send two thirds of the workgroups through both passes.  The Denoiser reads the fallback counter
+    after its first loop with a set of weights and switches the engine to the exact pass above `attn_fallback_limit`.  Procedural weights: rate 0,
+    nothing changes.  A checkpoint whose self-attention query / key projections are scaled x6 (scores x36: sharp attention, maxima far from a row's
+    first 64 keys): the rate is measured, the engine is switched, and the results before and after the switch agree to the precision's noise."""
+    import torch
+    import warnings
+    from ns2vc_amd.pipeline import Denoiser
+    _, c, p = _inputs("afb", 2, 300, 64)
+    n = torch.randn(2, 100, 300, generator=torch.Generator().manual_seed(9)).cuda()
+    d = Denoiser(state, precision="fp16", precision_check=None)
+    d.sample(c, p, None, n, solver="unipc", steps=4)
+    assert d.attn_fallback_rate_seen == 0.0
+    sharp = {k: v.clone() for k, v in state.items()}
+    for k in sharp:
+        if ".attn1.to_q.weight" in k or ".attn1.to_k.weight" in k:
+            sharp[k] *= 6.0
+    d2 = Denoiser(sharp, precision="fp16", precision_check=None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y1 = d2.sample(c, p, None, n, solver="unipc", steps=4)
+    fired = any("attn_optimistic=0" in str(i.message) for i in w)
+    y2 = d2.sample(c, p, None, n, solver="unipc", steps=4)
+    y32 = Denoiser(sharp, precision="fp32").sample(c, p, None, n, solver="unipc", steps=4).cpu().numpy()
+    e1, e2 = rel_l2(y1.cpu().numpy(), y32), rel_l2(y2.cpu().numpy(), y32)
+    diag(f"optimistic-attention guard: procedural weights rate 0; q/k x6 checkpoint: {100 * d2.attn_fallback_rate_seen:.1f} % of the workgroups fell back -> "
+         f"{'switched to the exact pass' if fired else 'kept'}; 4-step loop vs the fp32 engine before / after the switch {e1:.2e} / {e2:.2e} "
+         f"(this checkpoint's attention is sharp: the 16-bit noise itself is large)")
+    # both passes are exact up to the rounding of the probabilities: the switch must not make the result worse than the noise it already had
+    assert fired == (d2.attn_fallback_rate_seen > 0.10) and torch.isfinite(y1).all() and torch.isfinite(y2).all() and e2 < 1.5 * e1 + 1e-3
+    assert d2.engine.launches()[0] > 0
+
+
 def test_handoff_refuses_a_different_table_with_the_same_number_of_steps(state):
     """Engine.sample(tail=...) / ns2vc_sampler_handoff compared only the step COUNT of the two tables; a tail engine holding
     another solver / order / beta schedule with the same number of steps would have produced a wrong latent silently."""
