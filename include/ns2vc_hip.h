@@ -275,9 +275,13 @@ typedef struct ns2vc_rowchain_args {
   const float* gn_x; int32_t ldx;
   const long long* gn_stats; const float* gn_gamma; const float* gn_beta;
   float gn_eps; int32_t T, G;
+  /* r4: N-sliced stage 2 (dim 384): `slices` = 2 -> two workgroups per token block, each repeats stage 1 and computes one slice of the stage-2
+   * rows (5 + 4 of the 9 row blocks of q|k|v, 2 + 1 of the 3 of to_q); wstream / consts2 from ns2vc_pack_rowchain_sliced.  0 / 1 = one workgroup. */
+  int32_t slices;
 } ns2vc_rowchain_args;
 /* w1 [dim][dim], w2 [n2][dim]: fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
 int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int n2, int precision, void** out_stream_dev);
+int ns2vc_pack_rowchain_sliced(const float* w1_host, const float* w2_host, int dim, int n2, int slices, int precision, void** out_stream_dev);
 int ns2vc_k_rowchain(const ns2vc_rowchain_args* a, int precision, void* stream);
 int ns2vc_debug_set_attn_keys(int keys); /* tests / tuning: 128 selects the 128-key K/V tile kernels (16-bit precisions, hd 16 / 32); 0 or 64 = the default 64-key tiles */
 int ns2vc_debug_set_attn_optimistic(int on); /* tests: 0 = every attention workgroup takes the exact (per-tile maximum) pass only; 1 = default */

@@ -82,6 +82,7 @@ class RowchainArgs(C.Structure):
         ("gn_x", C.c_void_p), ("ldx", C.c_int32),
         ("gn_stats", C.c_void_p), ("gn_gamma", C.c_void_p), ("gn_beta", C.c_void_p),
         ("gn_eps", C.c_float), ("T", C.c_int32), ("G", C.c_int32),
+        ("slices", C.c_int32),
     ]
 
 
@@ -160,6 +161,7 @@ PROTOTYPES = {
     "ns2vc_pack_ffn_pre": (_I, [_P, _P, _P, _I, _I, _PP]),
     "ns2vc_k_ffn": (_I, [C.POINTER(FfnArgs), _I, _P]),
     "ns2vc_pack_rowchain": (_I, [_P, _P, _I, _I, _I, _PP]),
+    "ns2vc_pack_rowchain_sliced": (_I, [_P, _P, _I, _I, _I, _I, _PP]),
     "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),
     "ns2vc_debug_set_rowchain_tokens": (_I, [_I]),
     "ns2vc_debug_set_attn_keys": (_I, [_I]),

@@ -23,7 +23,8 @@ using namespace ns2vc;
 
 namespace ns2vc {
 hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, int dim, int prec, std::vector<unsigned short>& out);   // ffn.hip
-hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out);   // rowchain.hip
+hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out, int slices = 1);
+int rowchain_slice_blocks(int n2, int slices);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
 void set_rc_trace(unsigned long long* p);
 void set_attn_optimistic(int on);
@@ -81,6 +82,7 @@ struct AttnW {
   float* ffn_consts = nullptr;    // ... and (rowsum, bias) per packed ff.net.0 row; 16-bit precisions, dim <= 256 only
   // token-local chains (rowchain.hip; 16-bit precisions, dim <= 256): proj_in -> norm1 -> q|k|v and attn1.to_out -> norm2 -> attn2.to_q
   void *chain_in = nullptr, *chain_mid = nullptr;          // weight tile streams
+  void* chain_in_s2 = nullptr;                              // ... of the first chain packed for two N-slices (dim 384, r4)
   float *chain_in_consts = nullptr, *chain_mid_consts = nullptr;   // (rowsum, bias) per LayerNorm-folded stage-2 row
 };
 struct BlockW {
@@ -152,6 +154,7 @@ struct ns2vc_unet {
   // launches it removes (210 -> 174 launches at the bench shape).  NS2VC_FUSE_GN_GEMM=0 restores them.  (r3 had this off: not
   // run-to-run deterministic; root cause and fix in r4, profiles/r04_gn_prologue_rootcause.txt.)
   bool fuse_gn_gemm = true;
+  bool slice_rows = true;      // first row chain of a dim-384 block as two N-slices per token block (r4; see Planner::transformer)
   unsigned* ln_health = nullptr;
   bool attn_optimistic = true;   // attention without the per-tile maximum + exact fallback (attn.hip OPT); 0 = exact pass only, on every device
   unsigned* attn_fallbacks = nullptr;     // device counter: workgroups that needed the fallback (ns2vc_unet_attn_fallbacks)
@@ -419,7 +422,7 @@ struct Packer {
 // weight stream + stage-2 constants of one token-local chain (rowchain.hip): w1 [d][d] plain, w2 [n2][d] LayerNorm-folded
 // with its folded bias; only for the shapes / precisions the kernel serves, otherwise both outputs stay null
 static int chain_stream(Packer& P, const std::vector<float>& w1, const std::vector<float>& w2, const std::vector<float>& b2, int d, int n2,
-                        void*& stream_dev, float*& consts_dev) {
+                        void*& stream_dev, float*& consts_dev, void** sliced_dev = nullptr) {
   ns2vc_unet* h = P.h;
   stream_dev = nullptr; consts_dev = nullptr;
   if (P.err) return 1;
@@ -430,6 +433,15 @@ static int chain_stream(Packer& P, const std::vector<float>& w1, const std::vect
   if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
   h->weight_allocs.push_back(dev);
   if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
+  if (sliced_dev && d == 384) {     // the same chain packed for two N-slices (planner: where 64-token blocks fill less than half of the chip)
+    *sliced_dev = nullptr;
+    if (pack_rowchain_stream(w1.data(), w2.data(), d, n2, h->prec, st, 2) != hipSuccess) return fail("row-chain stream packing failed (sliced)");
+    void* dev2 = nullptr;
+    if (hipMalloc(&dev2, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
+    h->weight_allocs.push_back(dev2);
+    if (hipMemcpy(dev2, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
+    *sliced_dev = dev2;
+  }
   const std::vector<float> ws = rounded_rowsum(w2.data(), n2, d, n2, h->prec);
   std::vector<float> cs((size_t)n2 * 2);
   for (int r = 0; r < n2; ++r) { cs[2 * r] = ws[r]; cs[2 * r + 1] = b2[r]; }
@@ -521,7 +533,7 @@ int pack_all(ns2vc_unet* h) {
         for (const char* nm : {"to_q", "to_k", "to_v"}) P.ln_fold(P.T(t + ".attn1." + nm + ".weight"), nullptr, P.T(t + ".norm1.weight"), P.T(t + ".norm1.bias"), rows, bias);
         if (P.err) return 1;
         a.qkv = P.pack(rows, 3 * d, d, bias, true);
-        if (chain_stream(P, P.T(a.prefix + ".proj_in.weight").data, rows, bias, d, 3 * d, a.chain_in, a.chain_in_consts)) return 1;
+        if (chain_stream(P, P.T(a.prefix + ".proj_in.weight").data, rows, bias, d, 3 * d, a.chain_in, a.chain_in_consts, &a.chain_in_s2)) return 1;
       }
       a.o1 = P.pack(P.T(t + ".attn1.to_out.0.weight").data, d, d, P.T(t + ".attn1.to_out.0.bias").data);
       {
@@ -823,7 +835,10 @@ struct Planner {
       if (gn_st) {       // A = GroupNorm(x) built in the kernel's prologue from the producer's epilogue statistics
         c.a_op = nullptr; c.gn_x = x; c.ldx = d; c.gn_stats = gn_st; c.gn_gamma = a.ng; c.gn_beta = a.nb; c.gn_eps = 1e-6f; c.T = Tl; c.G = G;
       }
-      add(nm, [=](hipStream_t s) { return launch_rowchain(c, pr, s); }, 1, 2.0 * M * (double)d * (d + n2),
+      // r4: two N-slices per token block where that still is one round of workgroups (dim 384 at the bench batch: 118 blocks on 256 CUs);
+      // only for the chain without a residual (the second chain reads and rewrites y in place: two slices would race on it)
+      if (!res && stream == a.chain_in && a.chain_in_s2 && h->slice_rows && 2 * ((M + 63) / 64) <= 264) { c.wstream = a.chain_in_s2; c.slices = 2; }
+      add(c.slices == 2 ? nm + "[2 slices]" : nm, [=](hipStream_t s) { return launch_rowchain(c, pr, s); }, 1, 2.0 * M * (double)d * (d + n2),
           (double)M * (d * ((gn_st ? 4.0 : opsz) + 4.0 + (res ? 4.0 : 0.0)) + n2 * opsz) + (double)(d + n2) * d * opsz);
     };
     const bool rows_ok = lin && h->fuse_rows && a.chain_in && a.chain_mid && rowchain_eligible(d, d, Tl, pr);
@@ -1242,6 +1257,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_SLICE_ROWS")) h->slice_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_OPTIMISTIC")) h->attn_optimistic = atoi(e) != 0;
@@ -1325,7 +1341,8 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
   else if (!strcmp(name, "attn_optimistic")) opt = &h->attn_optimistic;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, attn_fp8, attn_optimistic)", name);
+  else if (!strcmp(name, "slice_rows")) opt = &h->slice_rows;
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, slice_rows, attn_fp8, attn_optimistic)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1762,7 +1779,24 @@ int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int
   }
   std::vector<unsigned short> st;
   if (pack_rowchain_stream(w1_host, w2_host, dim, n2, precision, st) != hipSuccess)
-    return fail("rowchain: dim must be 128 or 256, n2 = dim or 3 dim, and the precision 16-bit");
+    return fail("rowchain: dim must be 128, 256 or 384, n2 = dim or 3 dim, and the precision 16-bit");
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, st.size() * 2));
+  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  *out_stream_dev = d;
+  return 0;
+}
+int ns2vc_pack_rowchain_sliced(const float* w1_host, const float* w2_host, int dim, int n2, int slices, int precision, void** out_stream_dev) {
+  if (!w1_host || !w2_host || !out_stream_dev) return fail("null argument");
+  static bool inited = false;
+  if (!inited) {
+    hipError_t e = init_rowchain_attributes();
+    if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
+    inited = true;
+  }
+  std::vector<unsigned short> st;
+  if (pack_rowchain_stream(w1_host, w2_host, dim, n2, precision, st, slices) != hipSuccess)
+    return fail("rowchain (sliced): dim 384, n2 = dim or 3 dim, 2 slices, 16-bit precision");
   void* d = nullptr;
   HIPCHK(hipMalloc(&d, st.size() * 2));
   HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));

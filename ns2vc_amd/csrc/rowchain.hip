@@ -78,10 +78,17 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int sw = (l31 >> 1) & 7;                    // XOR swizzle of every fragment / panel row this lane touches
   const unsigned lds0 = (unsigned)(size_t)smem;
-  const int m0 = blockIdx.x * TOK;
+  // N-sliced stage 2 (r4, dim 384 where 64-token blocks fill less than half of the chip): `S` workgroups per token block, each repeating
+  // stage 1 and taking R2 of the stage-2 row blocks.  Workgroup ids are handed out round-robin over the 8 XCDs, so the S slices of a block
+  // sit 8 ids apart: they run on the same XCD and share the fp32 rows / panel through its L2.
+  const int S = a.slices > 1 ? a.slices : 1;
+  const int sl = S > 1 ? (int)(blockIdx.x % (8 * S)) / 8 : 0;
+  const int blk = S > 1 ? (int)(blockIdx.x / (8 * S)) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+  const int m0 = blk * TOK;
+  if (m0 >= a.M) return;                            // (padding of the sliced grid to whole groups of 8; uniform over the workgroup)
   const int tok0 = 32 * NT * tw + l31;              // this lane's tokens inside the block: tok0 + 32 u (both lane halves)
 
-  const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * RC_PAIR);
+  const i32x4_t rW = make_rsrc(reinterpret_cast<const char*>(a.wstream) + (size_t)sl * NP * RC_PAIR, (unsigned long long)NP * RC_PAIR);
   const unsigned lane16 = (unsigned)(lane * 16);
   // ---- token panel.  Plain case: LDS-DMA of the operand rows (source-side swizzle, rows past M read as zeros).
   // GroupNorm case (a.gn_x: the panel is GroupNorm(x), the `norm` of Transformer2DModel, transformer_1d.py:268): the fp32 rows
@@ -101,11 +108,12 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
     }
   }
   {
-    const i32x4_t rC = make_rsrc(a.consts2, (unsigned long long)G::CONSTS);
+    // (rowsum, bias) of this slice's stage-2 rows; rows past n2 (the short last slice) lie outside the descriptor and arrive as zeros
+    const i32x4_t rC = make_rsrc(a.consts2, (unsigned long long)a.n2 * 8ull);
 #pragma unroll
     for (int pc = 0; pc < (G::CONSTS / 1024 + 7) / 8; ++pc)
       if (8 * pc + wave < G::CONSTS / 1024)
-        blds16(rC, lane16, (unsigned)((8 * pc + wave) * 1024), lds0 + RING * RC_PAIR + G::PANEL + (8 * pc + wave) * 1024);
+        blds16(rC, lane16 + (unsigned)(sl * G::CONSTS), (unsigned)((8 * pc + wave) * 1024), lds0 + RING * RC_PAIR + G::PANEL + (8 * pc + wave) * 1024);
   }
   static_assert(G::CONSTS % 1024 == 0, "constants are whole DMA pieces");
   auto issue_pair = [&](int p) __attribute__((always_inline)) {
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
         char* dst = panel + (n >> 6) * PTILE + tok * 128 + ((((n & 63) >> 3) ^ sw) * 16) + 8 * hi;
         *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(v.x, v.y), Op16<TM>::pack(v.z, v.w));
       }
-      if (a.out1_f32) {
+      if (a.out1_f32 && sl == 0) {                  // (every slice computes the same y: the first one stores it)
 #pragma unroll
         for (int g = 0; g < 4; ++g) *reinterpret_cast<float4*>(wscr + l31 * 128 + (((2 * g + hi) ^ (l31 & 7)) * 16)) = vq[g];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -346,7 +354,7 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       rstd[u] = 1.0f / sqrtf((float)var + a.ln_eps);
       if (m0 + tok < a.M) ratio = fmaxf(ratio, fabsf(mean[u]) * rstd[u]);
     }
-    if (a.ln_health && cg == 0) {          // same health report as the LayerNorm-consumer GEMMs (gemm.hip ln_row_finish)
+    if (a.ln_health && cg == 0 && sl == 0) {          // same health report as the LayerNorm-consumer GEMMs (gemm.hip ln_row_finish)
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
       if (lane == 0 && ratio > __uint_as_float(__hip_atomic_load(a.ln_health, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
@@ -406,8 +414,8 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
       for (int gp = 0; gp < 2; ++gp) {         // groups (2 gp, 2 gp + 1): lower half ends up with group 2 gp, upper half with 2 gp + 1
         const auto x0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
         const auto x1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
-        const int n = 128 * rb + 32 * cg + 8 * (2 * gp + hi);
-        if (mtok < a.M) *reinterpret_cast<u32x4_t*>(oo + (size_t)mtok * a.ldo2 + n) = u32x4_t{x0[0], x1[0], x0[1], x1[1]};
+        const int n = 128 * (rb + sl * R2) + 32 * cg + 8 * (2 * gp + hi);
+        if (mtok < a.M && n < a.n2) *reinterpret_cast<u32x4_t*>(oo + (size_t)mtok * a.ldo2 + n) = u32x4_t{x0[0], x1[0], x0[1], x1[1]};
       }
     }
   }
@@ -431,15 +439,25 @@ static void rc_append_tile(std::vector<unsigned short>& out, const float* mat, s
 }
 
 // w1 [dim][dim], w2 [n2][dim] (LayerNorm-folded), both fp32 host row-major (K contiguous)
-hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out) {
-  if (!rowchain_eligible(dim, n2, 64, prec)) return hipErrorInvalidValue;
-  const int KT = dim / 64;
+// stage-2 row blocks per slice of the N-sliced launch (r4): q|k|v at dim 384 as 5 + 4, to_q as 2 + 1
+int rowchain_slice_blocks(int n2, int slices) { return (n2 / 128 + slices - 1) / slices; }
+
+hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out, int slices) {
+  if (!rowchain_eligible(dim, n2, 64, prec) || slices < 1 || (slices > 1 && dim != 384)) return hipErrorInvalidValue;
+  const int KT = dim / 64, nb2 = n2 / 128, r2s = rowchain_slice_blocks(n2, slices);
   out.clear();
-  out.reserve((size_t)(dim + n2) * dim);
-  for (int kt = 0; kt < KT; ++kt)
-    for (int rb = 0; rb < dim / 128; ++rb) rc_append_tile(out, w1, dim, 128 * rb, 64 * kt, prec);
-  for (int kt = 0; kt < KT; ++kt)
-    for (int rb = 0; rb < n2 / 128; ++rb) rc_append_tile(out, w2, dim, 128 * rb, 64 * kt, prec);
+  out.reserve((size_t)slices * (dim + r2s * 128) * dim);
+  std::vector<float> zero((size_t)128 * dim, 0.f);
+  for (int sl = 0; sl < slices; ++sl) {            // every slice: the whole of stage 1, then its own stage-2 rows (a missing block = zero tiles)
+    for (int kt = 0; kt < KT; ++kt)
+      for (int rb = 0; rb < dim / 128; ++rb) rc_append_tile(out, w1, dim, 128 * rb, 64 * kt, prec);
+    for (int kt = 0; kt < KT; ++kt)
+      for (int j = 0; j < r2s; ++j) {
+        const int rb = sl * r2s + j;
+        if (rb < nb2) rc_append_tile(out, w2, dim, 128 * rb, 64 * kt, prec);
+        else rc_append_tile(out, zero.data(), dim, 0, 64 * kt, prec);
+      }
+  }
   return hipSuccess;
 }
 
@@ -450,7 +468,8 @@ bool rowchain_eligible(int dim, int n2, int T, int prec) {
 template <typename TM, int D, int R2, int NT> static hipError_t launch_rc(const RowchainArgs& a, hipStream_t s) {
   const size_t lds = RowchainGeom<D, R2, NT>::LDS;
   constexpr int TOK = RowchainGeom<D, R2, NT>::TOK;
-  hipLaunchKernelGGL((rowchain_kernel<TM, D, R2, NT>), dim3((a.M + TOK - 1) / TOK), dim3(512), lds, s, a);
+  const int nblk = (a.M + TOK - 1) / TOK, S = a.slices > 1 ? a.slices : 1;
+  hipLaunchKernelGGL((rowchain_kernel<TM, D, R2, NT>), dim3(S > 1 ? ((nblk + 7) / 8) * 8 * S : nblk), dim3(512), lds, s, a);
   return hipGetLastError();
 }
 // 64-token workgroups by default.  At dim 128 a workgroup's weights are small and M is large: when 64-token blocks would not
@@ -463,12 +482,14 @@ template <typename TM> static hipError_t launch_rc_tm(const RowchainArgs& a, hip
     if (big) return a.n2 == 128 ? launch_rc<TM, 128, 1, 2>(a, s) : launch_rc<TM, 128, 3, 2>(a, s);
     return a.n2 == 128 ? launch_rc<TM, 128, 1, 1>(a, s) : launch_rc<TM, 128, 3, 1>(a, s);
   }
+  if (a.dim == 384 && a.slices == 2) return a.n2 == 384 ? launch_rc<TM, 384, 2, 1>(a, s) : launch_rc<TM, 384, 5, 1>(a, s);
   if (a.dim == 384) return a.n2 == 384 ? launch_rc<TM, 384, 3, 1>(a, s) : launch_rc<TM, 384, 9, 1>(a, s);
   return a.n2 == 256 ? launch_rc<TM, 256, 2, 1>(a, s) : launch_rc<TM, 256, 6, 1>(a, s);
 }
 
 hipError_t launch_rowchain(const RowchainArgs& a, int prec, hipStream_t s) {
   if (!rowchain_eligible(a.dim, a.n2, 64, prec) || a.M <= 0) return hipErrorInvalidValue;
+  if (a.slices > 1 && (a.slices != 2 || a.dim != 384 || (a.res && (const void*)a.res == (const void*)a.out1_f32))) return hipErrorInvalidValue;   // (in-place residual: the slices would race on y)
   if ((!a.a_op && !a.gn_x) || !a.wstream || !a.bias1 || !a.consts2 || !a.out2_op) return hipErrorInvalidValue;
   if (a.gn_x) {      // GroupNorm prologue: per-16-channel-block statistics, groups of whole blocks, <= 4 batch items per 128 tokens
     if (!a.gn_stats || !a.gn_gamma || !a.gn_beta || a.G < 1 || a.G > 8 || a.T < 64 || (a.dim % a.G) || ((a.dim / a.G) & 15) || (a.ldx & 3))
@@ -488,6 +509,7 @@ hipError_t init_rowchain_attributes() {
   NS2VC_RC_ATTR(f16_t, 128, 1, 1); NS2VC_RC_ATTR(f16_t, 128, 3, 1); NS2VC_RC_ATTR(f16_t, 256, 2, 1); NS2VC_RC_ATTR(f16_t, 256, 6, 1);
   NS2VC_RC_ATTR(bf16_t, 128, 1, 2); NS2VC_RC_ATTR(bf16_t, 128, 3, 2); NS2VC_RC_ATTR(f16_t, 128, 1, 2); NS2VC_RC_ATTR(f16_t, 128, 3, 2);
   NS2VC_RC_ATTR(bf16_t, 384, 3, 1); NS2VC_RC_ATTR(bf16_t, 384, 9, 1); NS2VC_RC_ATTR(f16_t, 384, 3, 1); NS2VC_RC_ATTR(f16_t, 384, 9, 1);
+  NS2VC_RC_ATTR(bf16_t, 384, 2, 1); NS2VC_RC_ATTR(bf16_t, 384, 5, 1); NS2VC_RC_ATTR(f16_t, 384, 2, 1); NS2VC_RC_ATTR(f16_t, 384, 5, 1);
 #undef NS2VC_RC_ATTR
   return hipSuccess;
 }

@@ -1059,14 +1059,16 @@ def test_layout_roundtrip(diag):
 @pytest.mark.parametrize("dim,mult,M,res,nt", [(128, 3, 450, False, 1), (128, 1, 450, True, 1), (256, 3, 194, False, 1), (256, 1, 1000, True, 1),
                                                (128, 3, 64, False, 1), (256, 1, 5, True, 1), (128, 3, 450, False, 2), (128, 1, 333, True, 2),
                                                (128, 1, 70, True, 2), (128, 3, 18000, False, 0), (384, 3, 194, False, 1), (384, 1, 450, True, 1),
-                                               (384, 3, 7520, False, 0), (384, 1, 7, True, 0)], ids=str)
+                                               (384, 3, 7520, False, 0), (384, 1, 7, True, 0), (384, 3, 450, False, -2), (384, 1, 194, False, -2),
+                                               (384, 3, 7520, False, -2), (384, 3, 7, False, -2)], ids=str)
 def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
     """Two token-local GEMMs with a LayerNorm in between in one launch (csrc/rowchain.hip) against numpy fp64 of
         y = A W1^T + b1 (+ res);   z = LayerNorm(y) W2^T + b2
     with the engine's pack-time fold (gamma/beta into W2/b2), the kernel's rounding points modelled (A, the weights and y's
     operand copy are rounded to the operand type; statistics from the fp32 y), rows with a common offset (LayerNorm by
     linearity), row counts that are no multiple of 64, res aliasing out1 (as the engine uses it), NaN-filled outputs, and
-    both workgroup sizes (nt = 1: 64 tokens, 2: 128 tokens, 0: the launcher's choice -- 128 once M > 256 x 64 at dim 128)."""
+    both workgroup sizes (nt = 1: 64 tokens, 2: 128 tokens, 0: the launcher's choice -- 128 once M > 256 x 64 at dim 128); nt = -2 (r4):
+    TWO N-slices per token block (dim 384: each workgroup repeats stage 1 and takes 5 + 4 / 2 + 1 of the stage-2 row blocks)."""
     from ns2vc_amd._lib import RowchainArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
@@ -1089,7 +1091,12 @@ def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
     z = rstd * (yr @ W2r.T - mean * consts[:, 0].astype(np.float64)[None, :]) + b2f.astype(np.float64)[None, :]
     # ---- device
     stream = C.c_void_p()
-    check(lib.ns2vc_pack_rowchain(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, prec, C.byref(stream)), "pack_rowchain")
+    slices = 2 if nt == -2 else 0
+    nt = max(nt, 0)
+    if slices:
+        check(lib.ns2vc_pack_rowchain_sliced(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, slices, prec, C.byref(stream)), "pack_rowchain_sliced")
+    else:
+        check(lib.ns2vc_pack_rowchain(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, prec, C.byref(stream)), "pack_rowchain")
     d_a, d_b1, d_c = OpBuf(A, prec), _dev(b1), _dev(consts)
     d_y = DevBuf(M * d * 4)
     d_y.upload(R if res else np.full((M, d), np.nan, dtype=np.float32))          # res aliases out1 (in-place residual stream)
@@ -1100,12 +1107,16 @@ def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
     f.res = d_y.ptr if res else None; f.ldres = d
     f.out1_f32 = d_y.ptr; f.ldo1 = d; f.out2_op = d_z.ptr; f.ldo2 = n2
     f.ln_eps = 1e-5; f.M = M; f.dim = d; f.n2 = n2; f.ln_health = d_health.ptr
+    f.slices = slices
     check(lib.ns2vc_debug_set_rowchain_tokens(nt), "set_rowchain_tokens")
     try:
         check(lib.ns2vc_k_rowchain(C.byref(f), prec, None), "k_rowchain")
         sync()
     finally:
         lib.ns2vc_debug_set_rowchain_tokens(0)
+    if slices:          # an in-place residual (res aliasing out1) is refused: two slices would race on y
+        f.res = d_y.ptr
+        assert lib.ns2vc_k_rowchain(C.byref(f), prec, None) != 0
     yo, zo = d_y.to_numpy((M, d)), d_z.read()
     e_y, e_z = rel_l2(yo, y), rel_l2(zo, z)
     ratio = float(d_health.to_numpy((16,), dtype=np.uint32)[:1].view(np.float32)[0])
@@ -1123,7 +1134,7 @@ def test_rowchain_fused(dim, mult, M, res, nt, prec, diag):
 
 @pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("dim,B,T,nt", [(128, 3, 150, 1), (128, 5, 64, 2), (256, 2, 97, 1), (128, 2, 300, 2), (256, 4, 64, 1), (384, 3, 97, 1),
-                                        (384, 2, 235, 1)], ids=str)
+                                        (384, 2, 235, 1), (384, 3, 235, -2)], ids=str)
 def test_rowchain_groupnorm_prologue(dim, B, T, nt, prec, diag):
     """The row-chain kernel with the transformer's GroupNorm in its prologue: A = GroupNorm(x) (8 groups, affine, eps 1e-6) is
     built inside the kernel from the fp32 rows and the int64 per-(item, 16-channel block) statistics a producer's epilogue
@@ -1160,7 +1171,11 @@ def test_rowchain_groupnorm_prologue(dim, B, T, nt, prec, diag):
         mu, vv = y.mean(1, keepdims=True), y.var(1, keepdims=True)
         z = (yr @ W2r.T - mu * consts[:, 0].astype(np.float64)[None, :]) / np.sqrt(vv + 1e-5) + b2f.astype(np.float64)[None, :]
         stream = C.c_void_p()
-        check(lib.ns2vc_pack_rowchain(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, prec, C.byref(stream)), "pack_rowchain")
+        slices = 2 if nt == -2 else 0
+        if slices:
+            check(lib.ns2vc_pack_rowchain_sliced(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, slices, prec, C.byref(stream)), "pack_rowchain_sliced")
+        else:
+            check(lib.ns2vc_pack_rowchain(np.ascontiguousarray(W1).ctypes.data, np.ascontiguousarray(W2f).ctypes.data, d, n2, prec, C.byref(stream)), "pack_rowchain")
         d_b1, d_c, d_st, d_g, d_b = _dev(b1), _dev(consts), DevBuf.from_numpy(st), _dev(gam), _dev(bet)
         d_y = DevBuf(M * d * 4)
         d_y.upload(np.full((M, d), np.nan, dtype=np.float32))
@@ -1170,7 +1185,8 @@ def test_rowchain_groupnorm_prologue(dim, B, T, nt, prec, diag):
         f.res = None; f.ldres = d; f.out1_f32 = d_y.ptr; f.ldo1 = d; f.out2_op = d_z.ptr; f.ldo2 = n2
         f.ln_eps = 1e-5; f.M = M; f.dim = d; f.n2 = n2; f.ln_health = None
         f.gn_x = d_x.ptr; f.ldx = d; f.gn_stats = d_st.ptr; f.gn_gamma = d_g.ptr; f.gn_beta = d_b.ptr; f.gn_eps = 1e-6; f.T = T; f.G = Gn
-        check(lib.ns2vc_debug_set_rowchain_tokens(nt), "set_rowchain_tokens")
+        f.slices = slices
+        check(lib.ns2vc_debug_set_rowchain_tokens(max(nt, 0)), "set_rowchain_tokens")
         try:
             check(lib.ns2vc_k_rowchain(C.byref(f), prec, None), "k_rowchain")
             sync()
