@@ -532,6 +532,7 @@ def main():
     # the timed (captured-graph) loop must return exactly what the same loop launched eagerly returns
     loop_check = None
     attn_fb = None if dry else eng.attn_fallbacks(reset=True, stream=stream)          # workgroups that paid an attention kernel twice, all jobs so far
+    gn_alone = None if dry else eng.gn_coop_alone(reset=True, stream=stream)         # cooperative GroupNorm prologue: workgroups that waited in vain for a sibling, all jobs so far
     if use_graph and not dry:
         with torch.cuda.stream(stream):
             x.copy_(io["noise"])
@@ -734,6 +735,7 @@ def main():
             "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
             "launches_per_step": launches, "workspace_gb": workspace_gb, "device": "none (dry run)" if dry else E.device_info(),
             "attention_fallback_workgroups": attn_fb,
+            "gn_prologue_workgroups_alone": gn_alone,
             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
             "roofline": roof, "parity": parity, "self_check": self_check, "fp32_parity_mode": fp32_block, "other_configs": others, "strong_scaling": None,
             "cpu_baseline": cpu,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NS2VC_ABI_VERSION 4
+#define NS2VC_ABI_VERSION 5
 #define NS2VC_MAX_LEVELS 8
 #define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
 
@@ -141,6 +141,10 @@ int ns2vc_sampler_peek(ns2vc_unet* h, float* x_out_bct, void* stream);
 /* workgroups of the attention launches of this engine whose optimistic pass (no per-tile maximum; r3) had to be repeated by the
  * exact pass since the last reset -- each of them paid the kernel twice.  Synchronises `stream`. */
 int ns2vc_unet_attn_fallbacks(ns2vc_unet* h, unsigned long long* count, int reset, void* stream);
+/* ABI v5.  Workgroups of the cooperative GroupNorm prologue (ns2vc_gemm_args.gnp_sync, option `gn_coop`) that waited in vain for a
+ * sibling since the plan was built (or the last reset) and built all their rows themselves: a performance counter -- the results do
+ * not depend on it.  Synchronises `stream`. */
+int ns2vc_unet_gn_coop_alone(ns2vc_unet* h, unsigned long long* count, int reset, void* stream);
 
 /* ---- introspection for tests / profiling -------------------------------------------- */
 int ns2vc_unet_set_debug(ns2vc_unet* h, int enable);  /* keep a copy of every block output; drops the plan: call before prepare() */
@@ -212,6 +216,13 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   const long long* gnp_stats; const float* gnp_gamma; const float* gnp_beta;
   const float* gnp_temb; int32_t gnp_ldtemb;
   float gnp_eps; int32_t gnp_G, gnp_silu;
+  /* ABI v5, optional: [ceil(M / 64)] 64-bit arrival counts (8-byte aligned), zero before the FIRST launch that uses them and owned
+   * by this call site from then on (they only grow: every launch adds N / 128 to a row block's count).  With it (and N > 128)
+   * the N / 128 column tiles of a row block -- neighbours on one XCD -- build a share of the block's rows each and wait for
+   * the others' (bounded: a workgroup that waits in vain builds every row itself), instead of each building all of them.
+   * Same values either way. */
+  unsigned* gnp_sync;
+  unsigned* gnp_alone;            /* optional: += 1 per workgroup that waited in vain and built every row itself */
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
 NCOEF = 12
 MAX_LEVELS = 8
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Ns2vcError(RuntimeError):
@@ -50,6 +50,7 @@ class GemmArgs(C.Structure):
         ("gnp_stats", C.c_void_p), ("gnp_gamma", C.c_void_p), ("gnp_beta", C.c_void_p),
         ("gnp_temb", C.c_void_p), ("gnp_ldtemb", C.c_int32),
         ("gnp_eps", C.c_float), ("gnp_G", C.c_int32), ("gnp_silu", C.c_int32),
+        ("gnp_sync", C.c_void_p), ("gnp_alone", C.c_void_p),
     ]
 
 
@@ -127,6 +128,7 @@ PROTOTYPES = {
     "ns2vc_sampler_handoff": (_I, [_P, _P, _P]),
     "ns2vc_sampler_peek": (_I, [_P, _P, _P]),
     "ns2vc_unet_attn_fallbacks": (_I, [_P, C.POINTER(C.c_ulonglong), _I, _P]),
+    "ns2vc_unet_gn_coop_alone": (_I, [_P, C.POINTER(C.c_ulonglong), _I, _P]),
     "ns2vc_unet_set_debug": (_I, [_P, _I]),
     "ns2vc_unet_set_option": (_I, [_P, C.c_char_p, _I]),
     "ns2vc_unet_ln_ratio": (_I, [_P, C.POINTER(C.c_float), _P]),

@@ -154,6 +154,7 @@ struct ns2vc_unet {
   // launches it removes (210 -> 174 launches at the bench shape).  NS2VC_FUSE_GN_GEMM=0 restores them.  (r3 had this off: not
   // run-to-run deterministic; root cause and fix in r4, profiles/r04_gn_prologue_rootcause.txt.)
   bool fuse_gn_gemm = true;
+  bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool slice_rows = true;      // first row chain of a dim-384 block as two N-slices per token block (r4; see Planner::transformer)
   unsigned* ln_health = nullptr;
   bool attn_optimistic = true;   // attention without the per-tile maximum + exact fallback (attn.hip OPT); 0 = exact pass only, on every device
@@ -730,11 +731,12 @@ struct Planner {
   // `consumer_n` > 0: `dst` has exactly one reader, a GEMM with that many output columns that is planned next -- where the
   // norm qualifies (see fuse_gn_gemm) no launch is added and the returned GnPro is handed to that GEMM with gn_fuse().
   struct GnPro { const float* x = nullptr; int ldx = 0; const long long* st = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
-                 const float* temb = nullptr; int ldtemb = 0; float eps = 0.f; int G = 0, silu = 0; };
+                 const float* temb = nullptr; int ldtemb = 0; float eps = 0.f; int G = 0, silu = 0; unsigned* sync = nullptr; unsigned* alone = nullptr; };
   static void gn_fuse(GemmArgs& g, const GnPro& p) {
     if (!p.x) return;
     g.gnp_x = p.x; g.gnp_ldx = p.ldx; g.gnp_stats = p.st; g.gnp_gamma = p.gamma; g.gnp_beta = p.beta;
     g.gnp_temb = p.temb; g.gnp_ldtemb = p.ldtemb; g.gnp_eps = p.eps; g.gnp_G = p.G; g.gnp_silu = p.silu;
+    g.gnp_sync = p.sync; g.gnp_alone = p.alone;
   }
   GnPro groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
                   const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw,
@@ -751,6 +753,8 @@ struct Planner {
       GnPro p;
       p.x = a0; p.ldx = lda0; p.st = st0; p.gamma = gamma; p.beta = beta; p.temb = temb ? temb + temb_off : nullptr; p.ldtemb = ldt;
       p.eps = eps; p.G = Gq; p.silu = silu;
+      // wider than one column tile: the column tiles of a row block share the prologue's rows (one 64-bit count per 64-row block, zeroed with the arena)
+      if (h->gn_coop && consumer_n > 128) { p.sync = alloc<unsigned>(2 * ((size_t)(Bq * Tl + 63) / 64)); p.alone = h->ln_health ? h->ln_health + 48 : nullptr; }
       return p;
     }
     if (!epi) {
@@ -984,7 +988,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   h->t_dev = P.alloc<float>((size_t)B);
   h->step_dev = P.alloc<int>(64);
   h->ln_health = P.alloc<unsigned>(64);
-  h->attn_fallbacks = h->ln_health + 32;          // (same zero-initialised block; the LayerNorm read-out uses words 0 and 16)
+  h->attn_fallbacks = h->ln_health + 32;          // (same zero-initialised block; the LayerNorm read-out uses words 0 and 16, the cooperative GroupNorm prologue's counter word 48)
   // ---- shared scratch
   P.gn_rows = 32;
   P.gn_partial = P.alloc<double>((size_t)B * ((T + P.gn_rows - 1) / P.gn_rows) * c.norm_num_groups * 2);
@@ -1195,7 +1199,8 @@ void drop_plan(ns2vc_unet* h) {
   h->arena_bytes = h->arena_used = 0;
   h->next_step = -1;           // the solver state lived in the arena
   h->ln_posted = false;
-  h->attn_fallbacks = nullptr; // (the counter lived in the arena too)
+  h->attn_fallbacks = nullptr; // (the counters lived in the arena too)
+  h->ln_health = nullptr;
 }
 
 }  // namespace
@@ -1257,6 +1262,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_GN_COOP")) h->gn_coop = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_SLICE_ROWS")) h->slice_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
@@ -1338,11 +1344,12 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
   else if (!strcmp(name, "fuse_gn_gemm")) opt = &h->fuse_gn_gemm;
+  else if (!strcmp(name, "gn_coop")) opt = &h->gn_coop;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
   else if (!strcmp(name, "attn_optimistic")) opt = &h->attn_optimistic;
   else if (!strcmp(name, "slice_rows")) opt = &h->slice_rows;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, slice_rows, attn_fp8, attn_optimistic)", name);
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, gn_coop, slice_rows, attn_fp8, attn_optimistic)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1594,6 +1601,18 @@ int ns2vc_unet_attn_fallbacks(ns2vc_unet* h, unsigned long long* count, int rese
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   *count = v;
   if (reset) HIPCHK(launch_zero(h->attn_fallbacks, 16, (hipStream_t)stream));
+  return 0;
+}
+
+int ns2vc_unet_gn_coop_alone(ns2vc_unet* h, unsigned long long* count, int reset, void* stream) {
+  if (!h || !count) return fail("null argument");
+  *count = 0;
+  if (!h->ln_health) return 0;                  // no plan yet
+  unsigned v = 0;
+  HIPCHK(hipMemcpyAsync(&v, h->ln_health + 48, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  *count = v;
+  if (reset) HIPCHK(launch_zero(h->ln_health + 48, 16, (hipStream_t)stream));
   return 0;
 }
 

@@ -267,7 +267,16 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
   const int nb_m = (g.M + BM - 1) / BM;
   const int nwg = nb_n * nb_m;
   int tm, tn;
-  {
+  const bool coop = g.gnp_x != nullptr && g.gnp_sync != nullptr && nb_n > 1;     // (uniform over the grid; the launcher pads the grid for it)
+  if (coop) {
+    // cooperative GroupNorm prologue: whole row blocks per XCD, so that the column tiles that share a row block's rows also share an L2
+    const int bid = blockIdx.x;
+    const int q = nb_m >> 3, r = nb_m & 7, xcd = bid & 7, idx = bid >> 3;
+    const int tml = idx / nb_n;
+    if (tml >= q + (xcd < r ? 1 : 0)) return;                                      // padding of the last row block slot
+    tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + tml;
+    tn = idx - tml * nb_n;
+  } else {
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -643,8 +652,21 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 // pairs this tile touches, gamma / beta and the time scale / shift rows --, `finish` does the arithmetic and the stores.  (They run back to
 // back: hoisting `begin` above the kernel's row-offset set-up was measured and lost, see NS2VC_GNP_SPLIT.)
 template <typename TM> struct GnPrologue {
-  static constexpr int XB = 6;                                              // rows in flight per thread (1: no gain in the loop, 6: -1 %)
-  int rlo, rhi, b_lo, nbi, rl, r0, c, cq, Cg;
+#ifndef NS2VC_GNP_XB
+#define NS2VC_GNP_XB 6
+#endif
+#ifndef NS2VC_GNP_NODB
+#define NS2VC_GNP_NODB 0
+#endif
+#ifndef NS2VC_GNP_SPIN
+#define NS2VC_GNP_SPIN 256           // polls (~0.5 us each) before a workgroup stops waiting for its siblings and builds every row itself
+#endif
+#ifndef NS2VC_GNP_SELECT
+#define NS2VC_GNP_SELECT 0            // 1: r4's first form, every row selects its item's (scale, shift) among three
+#endif
+  static constexpr int XB = NS2VC_GNP_XB;                                   // rows in flight per thread (1: no gain in the loop, 6: -1 %)
+  int rlo, rhi, olo, ohi, lim, rln, b_lo, nbi, rl, r0, c, cq, Cg, nshare_;
+  unsigned long long* cnt_;
   bool active;
   float4 ga, be, t1[3], t2[3], xb[XB];
   long long sv[8];                                                          // (sum, sum of squares) of up to four 16-channel blocks of one (item, group)
@@ -652,11 +674,11 @@ template <typename TM> struct GnPrologue {
   __device__ __forceinline__ void fetch(const GemmArgs& g, int rb) {        // (every lane loads, from a clamped row: a straight-line batch of plain loads)
 #pragma unroll
     for (int k = 0; k < XB; ++k) {
-      const int r = min(rb + k * rl, rhi - 1);
+      const int r = max(min(rb + k * rl, lim - 1), rlo);                       // (an empty share still loads a valid row)
       xb[k] = *reinterpret_cast<const float4*>(g.gnp_x + (size_t)r * g.gnp_ldx + cq);
     }
   }
-  __device__ __forceinline__ void begin(const GemmArgs& g, int m0, int BM, int tid, int nth) {
+  __device__ __forceinline__ void begin(const GemmArgs& g, int m0, int BM, int tid, int nth, int share, int nshare) {
     const int C = g.c0, T = g.Tin, G = g.gnp_G;
     Cg = C / G;
     const int toff = g.taps >> 1;
@@ -668,8 +690,16 @@ template <typename TM> struct GnPrologue {
     const int quad = tid % nq, rlane = tid / nq;
     c = quad * 4;
     active = rlane < rl;
-    r0 = rlo + rlane;
+    // cooperative form (gnp_sync): the nshare workgroups that share these rows (the column tiles of one row block, neighbours on one
+    // XCD) build a contiguous share each; [olo, ohi) is mine
+    nshare_ = nshare;
+    cnt_ = nshare > 1 ? reinterpret_cast<unsigned long long*>(g.gnp_sync) + m0 / BM : nullptr;
+    const int per = (rhi - rlo + nshare - 1) / nshare;
+    olo = min(rlo + share * per, rhi); ohi = min(olo + per, rhi);
+    rln = rlane;
+    r0 = olo + rlane;
     cq = active ? c : 0;
+    lim = ohi;
     fetch(g, r0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) sv[j] = 0;
@@ -699,8 +729,64 @@ template <typename TM> struct GnPrologue {
       }
     }
   }
+  // rows [lo, hi) of this thread's column quad: act(x * scale + shift) -> operand type, written through to L2
+  __device__ __forceinline__ void rows(const GemmArgs& g, const float (&sc)[3][4], const float (&sh)[3][4], int lo, int hi, bool fetched) {
+    const int T = g.Tin;
+    const int rs = lo + rln;
+    lim = hi;
+    if (!fetched) fetch(g, rs);
+    TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
+#if NS2VC_GNP_SELECT == 0
+    // a thread's rows ascend, so the item they belong to changes at most twice: the current item's (scale, shift) quad is kept and
+    // re-selected behind a branch that is almost never taken (r4: the per-row selects among three items were 16 v_cndmask per quad,
+    // a third of the prologue's VALU work -- and the prologue is VALU-bound, tools/gnp_trace.py)
+    int cur = (rs >= (b_lo + 1) * T ? 1 : 0) + (rs >= (b_lo + 2) * T ? 1 : 0);
+    int nxt = (b_lo + cur + 1) * T;
+    float a[4], b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = cur == 0 ? sc[0][e] : (cur == 1 ? sc[1][e] : sc[2][e]); b[e] = cur == 0 ? sh[0][e] : (cur == 1 ? sh[1][e] : sh[2][e]); }
+#endif
+    for (int rb = rs; rb < hi; rb += XB * rl) {
+#if NS2VC_GNP_NODB
+      float4 (&w)[XB] = xb;                                               // one batch covers (nearly) every row: no second buffer; a rare second batch is loaded after the stores
+#else
+      float4 w[XB];
+#pragma unroll
+      for (int k = 0; k < XB; ++k) w[k] = xb[k];
+      fetch(g, rb + XB * rl);                               // next batch before this one is stored (clamped: the last one is a dummy)
+#endif
+#pragma unroll
+      for (int k = 0; k < XB; ++k) {
+        const int r = rb + k * rl;
+        if (r < hi) {
+#if NS2VC_GNP_SELECT == 0
+          if (r >= nxt) {                                                 // (rows per pass <= 16 < T: never more than one item further)
+            ++cur; nxt += T;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] = cur == 1 ? sc[1][e] : sc[2][e]; b[e] = cur == 1 ? sh[1][e] : sh[2][e]; }
+          }
+#else
+          const int bi = (r >= (b_lo + 1) * T ? 1 : 0) + (r >= (b_lo + 2) * T ? 1 : 0);
+          float a[4], b[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
+#endif
+          float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
+          if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
+#if NS2VC_GNP_WT
+          out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
+#else
+          store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);    // only this workgroup reads these rows back (through the same L2): no need to push them to memory now
+#endif
+        }
+      }
+#if NS2VC_GNP_NODB
+      if (rb + XB * rl < hi) fetch(g, rb + XB * rl);
+#endif
+    }
+  }
   __device__ __forceinline__ void finish(const GemmArgs& g, int tid, char* smem) {
-    const int C = g.c0, T = g.Tin, G = g.gnp_G;
+    const int T = g.Tin, G = g.gnp_G;
     float2* const gtab = reinterpret_cast<float2*>(smem);                   // (mean, rstd) of (item - b_lo, group): <= 3 x 8
     if (tid < nbi * G) {                                                    // same finalisation as gn_apply_kernel (misc.hip)
       const int bi = tid / G, gg = tid - bi * G;
@@ -720,9 +806,9 @@ template <typename TM> struct GnPrologue {
       gtab[bi * 8 + gg] = make_float2((float)mean, r);
     }
     __syncthreads();
+    float sc[3][4], sh[3][4];
     if (active) {
       const int gg = c / Cg;
-      float sc[3][4], sh[3][4];
       const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
       float2 mrs[3];
 #pragma unroll
@@ -750,33 +836,45 @@ template <typename TM> struct GnPrologue {
           }
         }
       }
-      TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
-      for (int rb = r0; rb < rhi; rb += XB * rl) {
-        float4 w[XB];
-#pragma unroll
-        for (int k = 0; k < XB; ++k) w[k] = xb[k];
-        fetch(g, min(rb + XB * rl, rhi - 1));                               // next batch before this one is stored (clamped: the last one is a dummy)
-#pragma unroll
-        for (int k = 0; k < XB; ++k) {
-          const int r = rb + k * rl;
-          if (r < rhi) {
-            const int bi = (r >= (b_lo + 1) * T ? 1 : 0) + (r >= (b_lo + 2) * T ? 1 : 0);
-            float a[4], b[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
-            float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
-            if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-#if NS2VC_GNP_WT
-            out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
-#else
-            store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);    // only this workgroup reads these rows back (through the same L2): no need to push them to memory now
-#endif
-          }
-        }
-      }
+      rows(g, sc, sh, olo, ohi, true);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
     __syncthreads();                                        // ... and so are everybody else's: the DMA may read them (and smem is free)
+    if (nshare_ > 1) {
+      // Cooperative form: publish my share, wait (bounded) for the others'.  One 64-bit arrival count per row block that only ever
+      // grows (every launch adds nshare to it; 64 bits never wrap), so it needs no reset between launches or graph replays: the value
+      // my arrival finds tells which multiple of nshare completes THIS launch.  A sibling that does not show up in time (not resident
+      // yet: nothing guarantees co-scheduling) costs a repeat of the whole range by this workgroup; the values are the same whoever
+      // writes them, so the result does not depend on which way it went.
+      int* const okf = reinterpret_cast<int*>(smem);
+      if (tid == 0) {
+        // The siblings run on ONE XCD (the cooperative tile order), so its L2 is the point of coherence: the rows were written through
+        // and acknowledged (vmcnt(0) above), and the count is only ever touched by read-modify-writes, which execute in that L2.
+        // (Agent-scope fences / atomics would be correct too, but on this multi-XCD part they cost an L2 write-back and a trip to the
+        // memory side per workgroup: measured, the prologue got slower than the redundant form.)
+        unsigned long long old, v, one = 1ull, zero = 0ull;
+        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(cnt_), "v"(one) : "memory");
+        const unsigned long long target = (old / (unsigned)nshare_ + 1ull) * (unsigned)nshare_;
+        int ok = old + 1ull == target;
+        const int spins = (old >> 62) ? 0 : NS2VC_GNP_SPIN;                  // (a count with bit 62 set: "do not wait" -- how the tests reach the path below)
+        if (old >> 62) ok = 0;
+        for (int it = 0; !ok && it < spins; ++it) {
+          asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(cnt_), "v"(zero) : "memory");
+          ok = v >= target;
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        okf[0] = ok;
+      }
+      __syncthreads();
+      const int ok = okf[0];
+      __syncthreads();
+      if (!ok) {
+        if (tid == 0 && g.gnp_alone) atomicAdd(g.gnp_alone, 1u);
+        if (active) rows(g, sc, sh, rlo, rhi, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    }
   }
 };
 
@@ -828,7 +926,16 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
   const int nb_m = (g.M + BM - 1) / BM;
   const int nwg = nb_n * nb_m;
   int tm, tn;
-  {
+  const bool coop = g.gnp_x != nullptr && g.gnp_sync != nullptr && nb_n > 1;     // (uniform over the grid; the launcher pads the grid for it)
+  if (coop) {
+    // cooperative GroupNorm prologue: whole row blocks per XCD, so that the column tiles that share a row block's rows also share an L2
+    const int bid = blockIdx.x;
+    const int q = nb_m >> 3, r = nb_m & 7, xcd = bid & 7, idx = bid >> 3;
+    const int tml = idx / nb_n;
+    if (tml >= q + (xcd < r ? 1 : 0)) return;                                      // padding of the last row block slot
+    tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + tml;
+    tn = idx - tml * nb_n;
+  } else {
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -871,7 +978,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 #ifndef NS2VC_GNP_SPLIT
 #define NS2VC_GNP_SPLIT 0
 #endif
-  if (NS2VC_GNP_SPLIT && gnp) gpro.begin(g, m0, BM, tid, 64 * NW);
+  if (NS2VC_GNP_SPLIT && gnp) gpro.begin(g, m0, BM, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
   const int Ctot = g.c0 + g.c1;
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
@@ -977,7 +1084,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue_b(s, s);
     }
-    if (!NS2VC_GNP_SPLIT) gpro.begin(g, m0, BM, tid, 64 * NW);
+    if (!NS2VC_GNP_SPLIT) gpro.begin(g, m0, BM, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
     gpro.finish(g, tid, smem + (STAGES - 1) * STAGE);
   }
 #pragma unroll
@@ -1095,7 +1202,8 @@ static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
 }
 template <typename TM, int BM, int BN, int STAGES, int SPEC = 0>
 static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
-  const int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
+  int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
+  if (g.gnp_x && g.gnp_sync && g.N / BN > 1) nb = 8 * (((g.M + BM - 1) / BM + 7) / 8) * (g.N / BN);   // cooperative prologue: row blocks per XCD, padded
 #if NS2VC_GEMM_ABLATE
   if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
   else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);

@@ -333,6 +333,13 @@ class Engine:
         check(self.lib.ns2vc_unet_attn_fallbacks(self.h, C.byref(n), int(reset), _stream_ptr(stream)), "attn_fallbacks")
         return int(n.value)
 
+    def gn_coop_alone(self, reset: bool = True, stream=None) -> int:
+        """workgroups of the cooperative GroupNorm prologue that waited in vain for a sibling and built every row themselves since
+        the last reset (a performance counter: the values are the same either way).  Waits for ``stream``."""
+        n = C.c_ulonglong()
+        check(self.lib.ns2vc_unet_gn_coop_alone(self.h, C.byref(n), int(reset), _stream_ptr(stream)), "gn_coop_alone")
+        return int(n.value)
+
     # -- profiling --------------------------------------------------------------------
     def op_info(self, which: int = 0) -> List[Tuple[str, int, float, float]]:
         """[(name, kind, algorithmic flops, algorithmic bytes)] of the per-step (0) / condition (1) plan."""

@@ -241,7 +241,14 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         d_w, d_bias = _pack(W, prec), _dev(bias)
         t_ptr = (d_t.ptr + 4 * toff) if temb_on else None
         outs, ops = [], []
-        for fused in (0, 1):
+        # 2: the cooperative form (gnp_sync: the column tiles of a row block build a share of its rows each), twice on the same arrival
+        # counts (they only grow); 3: counts with bit 62 set = "do not wait" -- every workgroup takes the path of one that waited in
+        # vain for a sibling and builds all its rows itself
+        nsync = (M + 63) // 64
+        d_sync = DevBuf.from_numpy(np.zeros(nsync, dtype=np.uint64))
+        d_poison = DevBuf.from_numpy(np.full(nsync, 1 << 62, dtype=np.uint64))
+        d_alone = DevBuf.from_numpy(np.zeros(2, dtype=np.uint32))       # workgroups that waited in vain: [cooperative runs, poisoned run]
+        for fused in (0, 1, 2, 2, 3):
             d_a = OpBuf(np.full((M, Cc), np.nan, dtype=np.float32), prec)
             d_o = DevBuf(M * N * 4)
             d_o.upload(np.full((M, N), np.nan, dtype=np.float32))
@@ -254,6 +261,8 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
             if fused:
                 g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_st.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
                 g.gnp_temb = t_ptr; g.gnp_ldtemb = ldt; g.gnp_eps = 1e-5; g.gnp_G = Gn; g.gnp_silu = silu
+                g.gnp_sync = d_sync.ptr if fused == 2 else (d_poison.ptr if fused == 3 else None)
+                g.gnp_alone = d_alone.ptr + 4 * (fused == 3)
             else:
                 check(lib.ns2vc_k_groupnorm_stats(d_x.ptr, Cc, Cc, d_st.ptr, B, T, Gn, 1e-5, d_g.ptr, d_b.ptr, d_t.ptr if temb_on else None, ldt, toff, silu,
                                                   d_a.ptr, prec, None), "groupnorm_stats")
@@ -277,7 +286,12 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         e_op = rel_l2(ops[1], y.reshape(M, Cc))
         Gr = gather_rows(ops[1].astype(np.float64).reshape(B, T, Cc), B, T, T, taps, 0).reshape(M, K)
         e_out = rel_l2(outs[1], Gr @ W.astype(np.float64).T + bias)
-        same_op, same_out = np.array_equal(ops[0], ops[1]), np.array_equal(outs[0], outs[1])
+        same_op, same_out = all(np.array_equal(ops[0], o) for o in ops[1:]), all(np.array_equal(outs[0], o) for o in outs[1:])
+        counts = d_sync.to_numpy((nsync,), dtype=np.uint64)
+        alone = d_alone.to_numpy((2,), dtype=np.uint32)
+        assert alone[0] == 0 and (alone[1] > 0) == (N > 128), f"workgroups that waited in vain: {alone}"
+        per = 2 * (N // 128) if N > 128 else 0
+        assert np.isin(counts, (0, per)).all() and counts[0] == per, "every cooperative launch adds N / 128 arrivals to a row block's count"
         diag(f"gemm+GroupNorm prologue tile={tile} prec={prec} B={B} T={T} C={Cc} N={N} taps={taps} temb={temb_on} silu={silu}: "
              f"rows vs fp64 {e_op:.2e}  result vs fp64 {e_out:.2e}  rows==two-launch {same_op}  result==two-launch {same_out}")
         assert np.isfinite(ops[1]).all() and np.isfinite(outs[1]).all()          # every row the tiles read was produced
@@ -285,17 +299,20 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         assert e_op < (1e-6 if prec == 0 else eps16(prec)) and e_out < TOL[prec]
 
 
+@pytest.mark.parametrize("level", [(938, 128, 128), (235, 384, 384), (118, 512, 512)], ids=lambda l: f"T{l[0]}c{l[1]}")
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, diag):
+def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, level, diag):
     """The fused launch at the bench shape (32 x 938 rows, 128 -> 128 channels, k = 3; the loader / consumer tiles), eight times:
     operand rows and results equal the two-launch path bit for bit EVERY time.  This is the probe that showed round 3's
     "gamma reads zero" failure (a packed fp32 product formed under outstanding LDS reads came back as 0.0 for lanes 48-63 of a
     few waves per launch; tools/gnp_probe.py, profiles/r04_gn_prologue_rootcause.txt): it failed 22 of 22 launches before the
-    fix and must stay at zero."""
+    fix and must stay at zero.  The coarser levels (384 / 512 channels: 3 / 4 column tiles per row block) run the COOPERATIVE form
+    (gnp_sync) on one set of arrival counts for all eight launches: same bits, and no workgroup waits in vain for a sibling."""
     from ns2vc_amd._lib import GemmArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
-    B, T, Cc, N, taps = 32, 938, 128, 128, 3
+    B, taps = 32, 3
+    T, Cc, N = level
     rng = np.random.default_rng(0)
     M, K = B * T, taps * Cc
     x = rng.standard_normal((B, T, Cc)).astype(np.float32)
@@ -304,6 +321,7 @@ def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, diag):
     st = np.stack([np.rint(blk.sum(axis=(1, 3)) * 2.0 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2.0 ** 16)], axis=-1).astype(np.int64)
     W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
     d_x, d_g, d_b, d_st, d_w = _dev(x.reshape(M, Cc)), _dev(gam), _dev(bet), DevBuf.from_numpy(st), _pack(W, prec)
+    d_sync, d_alone = DevBuf.from_numpy(np.zeros((M + 63) // 64, dtype=np.uint64)), DevBuf.from_numpy(np.zeros(1, dtype=np.uint32))
 
     def run(fused, rep):
         d_a = OpBuf(np.full((M, Cc), np.nan, dtype=np.float32), prec)
@@ -318,6 +336,7 @@ def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, diag):
         if fused:
             g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_st.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
             g.gnp_eps = 1e-5; g.gnp_G = 8; g.gnp_silu = 1
+            g.gnp_sync = d_sync.ptr; g.gnp_alone = d_alone.ptr
         else:
             check(lib.ns2vc_k_groupnorm_stats(d_x.ptr, Cc, Cc, d_st.ptr, B, T, 8, 1e-5, d_g.ptr, d_b.ptr, None, 0, 0, 1, d_a.ptr, prec, None), "groupnorm_stats")
         check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
@@ -330,8 +349,10 @@ def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, diag):
         a, o = run(1, rep + 1)
         bad += int(not (np.array_equal(a, ref_a) and np.array_equal(o, ref_o)))
     lib.ns2vc_dev_free(d_w)
-    diag(f"gemm+GroupNorm prologue at the bench shape prec={prec}: {bad} of 8 fused launches differ from the two-launch path")
-    assert bad == 0
+    alone = int(d_alone.to_numpy((1,), dtype=np.uint32)[0])
+    diag(f"gemm+GroupNorm prologue at the bench shape T={T} C={Cc} N={N} prec={prec}: {bad} of 8 fused launches differ from the two-launch path; "
+         f"{alone} workgroups waited in vain for a sibling")
+    assert bad == 0 and alone == 0
 
 
 
