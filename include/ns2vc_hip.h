@@ -209,7 +209,7 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * workgroup FIRST writes act(GroupNorm(gnp_x)) for exactly the rows its tile will read (its output rows, plus one row
    * either side for taps == 3) into a0 -- same arithmetic as ns2vc_k_groupnorm, bit-identical rows -- and then runs as
    * usual, reading them back through its own L2.  a0 must be writable; c1 == 0, tmode == 0, Tin == Tout, N % 128 == 0,
-   * c0 <= 512, (c0 / gnp_G) % 16 == 0, gnp_G <= 8, Tin >= 130.  gnp_x fp32 [B*Tin][gnp_ldx]; gnp_stats = int64
+   * c0 <= 1024, (c0 / gnp_G) % 16 == 0, gnp_G <= 8, Tin >= 66.  gnp_x fp32 [B*Tin][gnp_ldx]; gnp_stats = int64
    * [B][c0/16][2] as left by a producer's `stats`; gnp_gamma / gnp_beta [c0]; gnp_temb (or NULL) points at row 0 of the
    * per-item (scale | shift) pairs: scale at [b*gnp_ldtemb + c], shift at [b*gnp_ldtemb + c0 + c]. */
   const float* gnp_x; int32_t gnp_ldx;
@@ -223,6 +223,14 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * Same values either way. */
   unsigned* gnp_sync;
   unsigned* gnp_alone;            /* optional: += 1 per workgroup that waited in vain and built every row itself */
+  /* ABI v5, optional: the normalised input is the channel concat of TWO tensors (resnet.py:591 on torch.cat([h, skip]) in the up
+   * blocks): the last gnp_c1 of the c0 channels come from gnp_x1 (fp32 [B*Tin][gnp_ldx1], statistics gnp_stats1 [B][gnp_c1/16][2]),
+   * the first c0 - gnp_c1 from gnp_x / gnp_stats; gamma / beta / temb index the concatenated channels; groups may straddle the
+   * two.  c0 <= 1024, gnp_c1 % 16 == 0.  gnp_raw (or NULL): the un-normalised rows in the operand type, same layout as a0 --
+   * the copy a 1x1 shortcut conv reads later. */
+  const float* gnp_x1; int32_t gnp_ldx1, gnp_c1;
+  const long long* gnp_stats1;
+  void* gnp_raw;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {
@@ -319,6 +327,11 @@ int ns2vc_k_groupnorm(const float* a0, int lda0, int c0, const float* a1, int ld
  * (ns2vc_gemm_args.stats, [B][c0/16][2]); one source, asynchronous on `stream`.  What ns2vc_gemm_args.gnp_* reproduces bit for bit. */
 int ns2vc_k_groupnorm_stats(const float* a0, int lda0, int c0, const long long* stats0, int B, int T, int G, float eps, const float* gamma,
                             const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, int precision, void* stream);
+/* ABI v5: the same for the channel concat of two tensors (the up blocks' torch.cat([h, skip])), each with its own statistics, plus the
+ * optional un-normalised operand copy.  What ns2vc_gemm_args.gnp_x1 / gnp_raw reproduce bit for bit. */
+int ns2vc_k_groupnorm_stats2(const float* a0, int lda0, int c0, const long long* stats0, const float* a1, int lda1, int c1, const long long* stats1,
+                             int B, int T, int G, float eps, const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off,
+                             int silu, void* out_op, void* raw_op, int precision, void* stream);
 /* LayerNorm without affine (gamma/beta are folded into the consumer's weights): fp32 rows -> operand rows */
 int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream);
 int ns2vc_k_nct_to_btc(const float* src, int C, int T, int B, float* dst, int ldd, int cpad, void* stream);

@@ -51,6 +51,7 @@ class GemmArgs(C.Structure):
         ("gnp_temb", C.c_void_p), ("gnp_ldtemb", C.c_int32),
         ("gnp_eps", C.c_float), ("gnp_G", C.c_int32), ("gnp_silu", C.c_int32),
         ("gnp_sync", C.c_void_p), ("gnp_alone", C.c_void_p),
+        ("gnp_x1", C.c_void_p), ("gnp_ldx1", C.c_int32), ("gnp_c1", C.c_int32), ("gnp_stats1", C.c_void_p), ("gnp_raw", C.c_void_p),
     ]
 
 
@@ -169,6 +170,7 @@ PROTOTYPES = {
     "ns2vc_debug_set_attn_keys": (_I, [_I]),
     "ns2vc_debug_set_attn_optimistic": (_I, [_I]),
     "ns2vc_k_groupnorm_stats": (_I, [_P, _I, _I, _P, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "ns2vc_k_groupnorm_stats2": (_I, [_P, _I, _I, _P, _P, _I, _I, _P, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_groupnorm": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, C.c_float, _P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "ns2vc_k_layernorm_apply": (_I, [_P, _I, _I, _I, C.c_float, _P, _I, _P]),
     "ns2vc_to_operand": (_I, [_P, C.c_size_t, _I, _PP]),

@@ -225,6 +225,7 @@ constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
+int last_gemm_refusal_line();                                               // gemm.hip line of the argument check that refused the last launch on this thread (0: none), cleared by the call
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
 void set_forced_gemm_tile(int bm, int bn, int stages);

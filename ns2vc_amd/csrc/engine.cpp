@@ -154,6 +154,7 @@ struct ns2vc_unet {
   // launches it removes (210 -> 174 launches at the bench shape).  NS2VC_FUSE_GN_GEMM=0 restores them.  (r3 had this off: not
   // run-to-run deterministic; root cause and fix in r4, profiles/r04_gn_prologue_rootcause.txt.)
   bool fuse_gn_gemm = true;
+  bool fuse_gn_cat = true;                // ... also where the norm's input is a concat of two tensors and / or a raw operand copy is wanted (first resnet of a level, up blocks)
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool slice_rows = true;      // first row chain of a dim-384 block as two N-slices per token block (r4; see Planner::transformer)
   unsigned* ln_health = nullptr;
@@ -711,7 +712,7 @@ struct Planner {
     const double bytes = in_rows * (g.c0 + g.c1 + g.c2) * osz + (double)g.N * g.K * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
                          (g.out_op ? g.M * nout * osz : 0.0) + (g.res ? g.M * nout * 4.0 : 0.0);
     // (a GroupNorm prologue reads the fp32 rows and writes + re-reads the operand rows it builds)
-    const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz) : 0.0;
+    const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz * (g.gnp_raw ? 2.0 : 1.0)) : 0.0;
     add(g.gnp_x ? name + "[+norm]" : name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes + pro);
   }
   // A = operand tensor [B*Tin][c0]; results to out_f32 and/or out_op (row stride = logical width)
@@ -731,12 +732,14 @@ struct Planner {
   // `consumer_n` > 0: `dst` has exactly one reader, a GEMM with that many output columns that is planned next -- where the
   // norm qualifies (see fuse_gn_gemm) no launch is added and the returned GnPro is handed to that GEMM with gn_fuse().
   struct GnPro { const float* x = nullptr; int ldx = 0; const long long* st = nullptr; const float* gamma = nullptr; const float* beta = nullptr;
-                 const float* temb = nullptr; int ldtemb = 0; float eps = 0.f; int G = 0, silu = 0; unsigned* sync = nullptr; unsigned* alone = nullptr; };
+                 const float* temb = nullptr; int ldtemb = 0; float eps = 0.f; int G = 0, silu = 0; unsigned* sync = nullptr; unsigned* alone = nullptr;
+                 const float* x1 = nullptr; int ldx1 = 0, c1 = 0; const long long* st1 = nullptr; void* raw = nullptr; };
   static void gn_fuse(GemmArgs& g, const GnPro& p) {
     if (!p.x) return;
     g.gnp_x = p.x; g.gnp_ldx = p.ldx; g.gnp_stats = p.st; g.gnp_gamma = p.gamma; g.gnp_beta = p.beta;
     g.gnp_temb = p.temb; g.gnp_ldtemb = p.ldtemb; g.gnp_eps = p.eps; g.gnp_G = p.G; g.gnp_silu = p.silu;
     g.gnp_sync = p.sync; g.gnp_alone = p.alone;
+    g.gnp_x1 = p.x1; g.gnp_ldx1 = p.ldx1; g.gnp_c1 = p.c1; g.gnp_stats1 = p.st1; g.gnp_raw = p.raw;
   }
   GnPro groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
                   const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw,
@@ -748,10 +751,13 @@ struct Planner {
     const long long* st0 = find_stats(a0);
     const long long* st1 = a1 ? find_stats(a1) : nullptr;
     const bool epi = st0 && (!a1 || st1) && (((c0 + c1) / Gq) % 16 == 0) && (c0 % 16 == 0);
-    if (epi && h->fuse_gn_gemm && consumer_n > 0 && (consumer_n % 128) == 0 && !a1 && !raw && Tl >= 66 && c0 <= 512 && (c0 % Gq) == 0 &&
-        Gq <= 8 && (lda0 & 3) == 0) {
+    if (epi && h->fuse_gn_gemm && consumer_n > 0 && (consumer_n % 128) == 0 && (h->fuse_gn_cat || (!a1 && !raw)) && Tl >= 66 && c0 + c1 <= 1024 &&
+        ((c0 + c1) % Gq) == 0 && Gq <= 8 && (lda0 & 3) == 0 && (!a1 || ((lda1 & 3) == 0 && (c1 & 15) == 0))) {
       GnPro p;
-      p.x = a0; p.ldx = lda0; p.st = st0; p.gamma = gamma; p.beta = beta; p.temb = temb ? temb + temb_off : nullptr; p.ldtemb = ldt;
+      p.x = a0; p.ldx = lda0; p.st = st0;
+      if (a1) { p.x1 = a1; p.ldx1 = lda1; p.c1 = c1; p.st1 = st1; }      // a concat of two sources (up blocks), normalised as one tensor
+      p.raw = raw;                                                         // ... and the un-normalised operand copy for the 1x1 shortcut
+      p.gamma = gamma; p.beta = beta; p.temb = temb ? temb + temb_off : nullptr; p.ldtemb = ldt;
       p.eps = eps; p.G = Gq; p.silu = silu;
       // wider than one column tile: the column tiles of a row block share the prologue's rows (one 64-bit count per 64-row block, zeroed with the arena)
       if (h->gn_coop && consumer_n > 128) { p.sync = alloc<unsigned>(2 * ((size_t)(Bq * Tl + 63) / 64)); p.alone = h->ln_health ? h->ln_health + 48 : nullptr; }
@@ -1171,7 +1177,11 @@ int build_plan(ns2vc_unet* h, bool sizing) {
 int run_ops(const std::vector<Op>& ops, hipStream_t s, size_t first = 0, size_t last = (size_t)-1) {
   for (size_t i = first; i < std::min(last, ops.size()); ++i) {
     hipError_t e = ops[i].fn(s);
-    if (e != hipSuccess) return fail("launch of '%s' failed: %s", ops[i].name.c_str(), hipGetErrorString(e));
+    if (e != hipSuccess) {
+      const int line = last_gemm_refusal_line();
+      if (line) return fail("launch of '%s' failed: %s (refused by the argument check at gemm.hip:%d)", ops[i].name.c_str(), hipGetErrorString(e), line);
+      return fail("launch of '%s' failed: %s", ops[i].name.c_str(), hipGetErrorString(e));
+    }
   }
   return 0;
 }
@@ -1263,6 +1273,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_GN_COOP")) h->gn_coop = atoi(e) != 0;
+  if (const char* e = getenv("NS2VC_FUSE_GN_CAT")) h->fuse_gn_cat = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_SLICE_ROWS")) h->slice_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
@@ -1345,11 +1356,12 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
   else if (!strcmp(name, "fuse_gn_gemm")) opt = &h->fuse_gn_gemm;
   else if (!strcmp(name, "gn_coop")) opt = &h->gn_coop;
+  else if (!strcmp(name, "fuse_gn_cat")) opt = &h->fuse_gn_cat;
   else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
   else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
   else if (!strcmp(name, "attn_optimistic")) opt = &h->attn_optimistic;
   else if (!strcmp(name, "slice_rows")) opt = &h->slice_rows;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, gn_coop, slice_rows, attn_fp8, attn_optimistic)", name);
+  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic)", name);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1757,7 +1769,11 @@ int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages) { set_forced_gemm_tile
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_gemm(*a, precision, (hipStream_t)stream);
-  if (e != hipSuccess) return fail("launch_gemm: %s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    const int line = last_gemm_refusal_line();
+    if (line) return fail("launch_gemm: %s (refused by the argument check at gemm.hip:%d)", hipGetErrorString(e), line);
+    return fail("launch_gemm: %s", hipGetErrorString(e));
+  }
   return 0;
 }
 int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, int precision, void** out_stream_dev) {
@@ -1872,6 +1888,16 @@ int ns2vc_k_groupnorm_stats(const float* a0, int lda0, int c0, const long long* 
   hipError_t e = launch_gn_apply(a0, lda0, c0, nullptr, 0, 0, B, T, G, eps, nullptr, 0, stats0, nullptr, gamma, beta, temb, ldtemb, temb_off, silu,
                                  out_op, nullptr, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("groupnorm_stats launch: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_k_groupnorm_stats2(const float* a0, int lda0, int c0, const long long* stats0, const float* a1, int lda1, int c1, const long long* stats1,
+                             int B, int T, int G, float eps, const float* gamma, const float* beta, const float* temb, int ldtemb, int temb_off,
+                             int silu, void* out_op, void* raw_op, int precision, void* stream) {
+  if (!stats0 || !a1 || !stats1 || (c0 & 15) || (c1 & 15) || ((c0 + c1) % G) || (((c0 + c1) / G) & 15))
+    return fail("groupnorm_stats2: needs both sources' int64 epilogue statistics, whole 16-channel blocks per source and per group");
+  hipError_t e = launch_gn_apply(a0, lda0, c0, a1, lda1, c1, B, T, G, eps, nullptr, 0, stats0, stats1, gamma, beta, temb, ldtemb, temb_off, silu,
+                                 out_op, raw_op, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("groupnorm_stats2 launch: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_layernorm_apply(const float* x, int ldx, int M, int C, float eps, void* out_op, int precision, void* stream) {

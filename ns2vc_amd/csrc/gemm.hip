@@ -267,16 +267,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(const GemmArgs g, const int 
   const int nb_m = (g.M + BM - 1) / BM;
   const int nwg = nb_n * nb_m;
   int tm, tn;
-  const bool coop = g.gnp_x != nullptr && g.gnp_sync != nullptr && nb_n > 1;     // (uniform over the grid; the launcher pads the grid for it)
-  if (coop) {
-    // cooperative GroupNorm prologue: whole row blocks per XCD, so that the column tiles that share a row block's rows also share an L2
-    const int bid = blockIdx.x;
-    const int q = nb_m >> 3, r = nb_m & 7, xcd = bid & 7, idx = bid >> 3;
-    const int tml = idx / nb_n;
-    if (tml >= q + (xcd < r ? 1 : 0)) return;                                      // padding of the last row block slot
-    tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + tml;
-    tn = idx - tml * nb_n;
-  } else {
+  {
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -655,146 +646,159 @@ template <typename TM> struct GnPrologue {
 #ifndef NS2VC_GNP_XB
 #define NS2VC_GNP_XB 6
 #endif
-#ifndef NS2VC_GNP_NODB
-#define NS2VC_GNP_NODB 0
-#endif
 #ifndef NS2VC_GNP_SPIN
 #define NS2VC_GNP_SPIN 256           // polls (~0.5 us each) before a workgroup stops waiting for its siblings and builds every row itself
 #endif
-#ifndef NS2VC_GNP_SELECT
-#define NS2VC_GNP_SELECT 0            // 1: r4's first form, every row selects its item's (scale, shift) among three
-#endif
-  static constexpr int XB = NS2VC_GNP_XB;                                   // rows in flight per thread (1: no gain in the loop, 6: -1 %)
-  int rlo, rhi, olo, ohi, lim, rln, b_lo, nbi, rl, r0, c, cq, Cg, nshare_;
+  static constexpr int XB = NS2VC_GNP_XB;                                   // rows in flight per thread (1: no gain in the loop, 6: -1 %; 12 / 17 cost the kernel its occupancy)
+  static constexpr int OFF_BSUM = 256, OFF_OK = 3584;                       // table area (the ring stage nobody has been issued into yet): (mean, rstd) pairs | block sums | flag
+  int rlo, rhi, olo, ohi, lim, rln, b_lo, nbi, rl, c, cq, gg, Cg, nshare_, cur;
   unsigned long long* cnt_;
   bool active;
-  float4 ga, be, t1[3], t2[3], xb[XB];
-  long long sv[8];                                                          // (sum, sum of squares) of up to four 16-channel blocks of one (item, group)
+  float4 ga, be, t1, t2, xb[XB];                                            // t1 / t2: the time (scale | shift) quad of item `cur`
+  const float* xsrc;                                                        // this thread's column quad in its source tensor (the input may be a concat of two)
+  int xld;
+  long long sv[2];                                                          // (sum, sum of squares) of ONE 16-channel block of one item (thread = item x block)
+  float a[4], b[4];                                                         // y = x * a + b for this quad, item `cur`
 
   __device__ __forceinline__ void fetch(const GemmArgs& g, int rb) {        // (every lane loads, from a clamped row: a straight-line batch of plain loads)
+    (void)g;
 #pragma unroll
     for (int k = 0; k < XB; ++k) {
-      const int r = max(min(rb + k * rl, lim - 1), rlo);                       // (an empty share still loads a valid row)
-      xb[k] = *reinterpret_cast<const float4*>(g.gnp_x + (size_t)r * g.gnp_ldx + cq);
+      const int r = max(min(rb + k * rl, lim - 1), rlo);                    // (an empty share still loads a valid row)
+      xb[k] = *reinterpret_cast<const float4*>(xsrc + (size_t)r * xld);
+    }
+  }
+  __device__ __forceinline__ int item_of(const GemmArgs& g, int r) const {
+    return min((r >= (b_lo + 1) * g.Tin ? 1 : 0) + (r >= (b_lo + 2) * g.Tin ? 1 : 0), nbi - 1);
+  }
+  __device__ __forceinline__ void load_temb(const GemmArgs& g, int bi) {
+    t1 = t2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.gnp_temb) {
+      const int C = g.c0;
+      const float* tp = g.gnp_temb + (size_t)(b_lo + bi) * g.gnp_ldtemb + cq;
+      if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
+        t1 = *reinterpret_cast<const float4*>(tp);
+        t2 = *reinterpret_cast<const float4*>(tp + C);
+      } else {
+        t1 = make_float4(tp[0], tp[1], tp[2], tp[3]);
+        t2 = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
+      }
+    }
+  }
+  // (scale, shift) of item `cur` for this thread's quad, from the table in LDS and the vectors in registers
+  __device__ __forceinline__ void affine(const GemmArgs& g, const char* smem) {
+    float2 mr = reinterpret_cast<const float2*>(smem)[cur * 8 + gg];
+    // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
+    //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
+    // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
+    // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
+    // "gamma reads zero" non-determinism of round 3.  With the (mean, rstd) pair landed before the first packed product the
+    // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(mr.x), "+v"(mr.y));
+    const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
+    const float ts[4] = {t1.x, t1.y, t1.z, t1.w}, tf[4] = {t2.x, t2.y, t2.z, t2.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      a[e] = mr.y * gam[e];
+      b[e] = bet[e] - mr.x * a[e];
+      if (g.gnp_temb) {
+        const float s1 = 1.0f + ts[e];
+        a[e] *= s1;
+        b[e] = b[e] * s1 + tf[e];
+      }
     }
   }
   __device__ __forceinline__ void begin(const GemmArgs& g, int m0, int BM, int tid, int nth, int share, int nshare) {
-    const int C = g.c0, T = g.Tin, G = g.gnp_G;
-    Cg = C / G;
+    const int C = g.c0, T = g.Tin;
+    Cg = C / g.gnp_G;
     const int toff = g.taps >> 1;
     rlo = max(m0 - toff, 0); rhi = min(m0 + BM + toff, g.M);               // rows [rlo, rhi) of the flattened (item, frame) index
     b_lo = rlo / T;
     nbi = (rhi - 1) / T - b_lo + 1;                                         // <= 3 (the launcher checks T against the tile)
     const int nq = C >> 2;                                                  // float4 quads per row
     rl = nth / nq;                                                          // rows per pass
-    const int quad = tid % nq, rlane = tid / nq;
+    const int quad = tid % nq;
+    rln = tid / nq;
     c = quad * 4;
-    active = rlane < rl;
+    active = rln < rl;
+    cq = active ? c : 0;
+    gg = cq / Cg;
     // cooperative form (gnp_sync): the nshare workgroups that share these rows (the column tiles of one row block, neighbours on one
     // XCD) build a contiguous share each; [olo, ohi) is mine
     nshare_ = nshare;
     cnt_ = nshare > 1 ? reinterpret_cast<unsigned long long*>(g.gnp_sync) + m0 / BM : nullptr;
     const int per = (rhi - rlo + nshare - 1) / nshare;
     olo = min(rlo + share * per, rhi); ohi = min(olo + per, rhi);
-    rln = rlane;
-    r0 = olo + rlane;
-    cq = active ? c : 0;
     lim = ohi;
-    fetch(g, r0);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sv[j] = 0;
-    if (tid < nbi * G) {
-      const int bi = tid / G, gg = tid - bi * G;
-      const int nb = Cg >> 4, nblk = C >> 4;
-      const long long* st = g.gnp_stats + ((size_t)(b_lo + bi) * nblk + (size_t)gg * nb) * 2;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nb) { sv[2 * j] = st[2 * j]; sv[2 * j + 1] = st[2 * j + 1]; }
+    const int c0a = C - g.gnp_c1;                                           // channels of the first source (all of them unless the input is a concat)
+    if (cq < c0a) { xsrc = g.gnp_x + cq; xld = g.gnp_ldx; } else { xsrc = g.gnp_x1 + (cq - c0a); xld = g.gnp_ldx1; }
+    fetch(g, olo + rln);
+    sv[0] = sv[1] = 0;
+    const int nblk = C >> 4;
+    if (tid < nbi * nblk) {                                                 // <= 3 x 64 threads, one 16-channel block of one item each
+      const int bi = tid / nblk, blk = tid - bi * nblk, nblk0 = c0a >> 4;
+      const long long* st = blk < nblk0 ? g.gnp_stats + ((size_t)(b_lo + bi) * nblk0 + blk) * 2
+                                        : g.gnp_stats1 + ((size_t)(b_lo + bi) * (nblk - nblk0) + (blk - nblk0)) * 2;
+      sv[0] = st[0]; sv[1] = st[1];
     }
     ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);                // (unconditional loads: inactive threads read column 0)
     be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
-#pragma unroll
-    for (int bi = 0; bi < 3; ++bi) t1[bi] = t2[bi] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.gnp_temb) {
-#pragma unroll
-      for (int bi = 0; bi < 3; ++bi) {
-        const float* tp = g.gnp_temb + (size_t)(b_lo + min(bi, nbi - 1)) * g.gnp_ldtemb + cq;
-        if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
-          t1[bi] = *reinterpret_cast<const float4*>(tp);
-          t2[bi] = *reinterpret_cast<const float4*>(tp + C);
-        } else {
-          t1[bi] = make_float4(tp[0], tp[1], tp[2], tp[3]);
-          t2[bi] = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
-        }
-      }
-    }
+    cur = item_of(g, olo + rln);
+    load_temb(g, cur);
   }
-  // rows [lo, hi) of this thread's column quad: act(x * scale + shift) -> operand type, written through to L2
-  __device__ __forceinline__ void rows(const GemmArgs& g, const float (&sc)[3][4], const float (&sh)[3][4], int lo, int hi, bool fetched) {
+  // rows [lo, hi) of this thread's column quad: act(x * a + b) -> operand type, written through to L2.  A thread's rows ascend, so the
+  // item they belong to changes at most twice: its (scale, shift) quad is kept and rebuilt behind a branch that is almost never taken
+  // (r4: per-row selects among three items' quads were 16 v_cndmask per quad of a VALU-heavy loop, and 24 registers; tools/gnp_trace.py)
+  __device__ __forceinline__ void rows(const GemmArgs& g, const char* smem, int lo, int hi, bool fetched) {
     const int T = g.Tin;
     const int rs = lo + rln;
     lim = hi;
     if (!fetched) fetch(g, rs);
-    TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
-#if NS2VC_GNP_SELECT == 0
-    // a thread's rows ascend, so the item they belong to changes at most twice: the current item's (scale, shift) quad is kept and
-    // re-selected behind a branch that is almost never taken (r4: the per-row selects among three items were 16 v_cndmask per quad,
-    // a third of the prologue's VALU work -- and the prologue is VALU-bound, tools/gnp_trace.py)
-    int cur = (rs >= (b_lo + 1) * T ? 1 : 0) + (rs >= (b_lo + 2) * T ? 1 : 0);
+    const int it = item_of(g, rs);
+    if (it != cur) { cur = it; load_temb(g, cur); }
+    affine(g, smem);
     int nxt = (b_lo + cur + 1) * T;
-    float a[4], b[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = cur == 0 ? sc[0][e] : (cur == 1 ? sc[1][e] : sc[2][e]); b[e] = cur == 0 ? sh[0][e] : (cur == 1 ? sh[1][e] : sh[2][e]); }
-#endif
+    TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
+    TM* const raw = reinterpret_cast<TM*>(g.gnp_raw);
     for (int rb = rs; rb < hi; rb += XB * rl) {
-#if NS2VC_GNP_NODB
-      float4 (&w)[XB] = xb;                                               // one batch covers (nearly) every row: no second buffer; a rare second batch is loaded after the stores
-#else
       float4 w[XB];
 #pragma unroll
       for (int k = 0; k < XB; ++k) w[k] = xb[k];
-      fetch(g, rb + XB * rl);                               // next batch before this one is stored (clamped: the last one is a dummy)
-#endif
+      fetch(g, rb + XB * rl);                                               // next batch before this one is stored (clamped: the last one is a dummy)
 #pragma unroll
       for (int k = 0; k < XB; ++k) {
         const int r = rb + k * rl;
         if (r < hi) {
-#if NS2VC_GNP_SELECT == 0
-          if (r >= nxt) {                                                 // (rows per pass <= 16 < T: never more than one item further)
+          if (r >= nxt) {                                                   // (rows per pass <= 16 < T: never more than one item further)
             ++cur; nxt += T;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a[e] = cur == 1 ? sc[1][e] : sc[2][e]; b[e] = cur == 1 ? sh[1][e] : sh[2][e]; }
+            load_temb(g, cur);
+            affine(g, smem);
           }
-#else
-          const int bi = (r >= (b_lo + 1) * T ? 1 : 0) + (r >= (b_lo + 2) * T ? 1 : 0);
-          float a[4], b[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { a[e] = bi == 0 ? sc[0][e] : (bi == 1 ? sc[1][e] : sc[2][e]); b[e] = bi == 0 ? sh[0][e] : (bi == 1 ? sh[1][e] : sh[2][e]); }
-#endif
           float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
           if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
 #if NS2VC_GNP_WT
           out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
 #else
-          store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);    // only this workgroup reads these rows back (through the same L2): no need to push them to memory now
+          store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
 #endif
+          if (raw) out_op4<TM>(raw + (size_t)r * g.lda0 + c, w[k].x, w[k].y, w[k].z, w[k].w);   // the un-normalised operand copy a later 1x1 shortcut reads
         }
       }
-#if NS2VC_GNP_NODB
-      if (rb + XB * rl < hi) fetch(g, rb + XB * rl);
-#endif
     }
   }
   __device__ __forceinline__ void finish(const GemmArgs& g, int tid, char* smem) {
     const int T = g.Tin, G = g.gnp_G;
     float2* const gtab = reinterpret_cast<float2*>(smem);                   // (mean, rstd) of (item - b_lo, group): <= 3 x 8
-    if (tid < nbi * G) {                                                    // same finalisation as gn_apply_kernel (misc.hip)
-      const int bi = tid / G, gg = tid - bi * G;
+    double2* const bsum = reinterpret_cast<double2*>(smem + OFF_BSUM);      // per (item - b_lo, 16-channel block): the scaled sums, exact in double
+    const int nblk = g.c0 >> 4;
+    if (tid < nbi * nblk) bsum[tid] = make_double2((double)sv[0] * (1.0 / GN_SUM_SCALE), (double)sv[1] * (1.0 / GN_SQ_SCALE));
+    __syncthreads();
+    if (tid < nbi * G) {                                                    // same finalisation as gn_apply_kernel (misc.hip); the sums are exact, their order is free
+      const int bi = tid / G, gq = tid - bi * G;
       const int nb = Cg >> 4;
       double ds = 0.0, dq = 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (j < nb) { ds += (double)sv[2 * j] * (1.0 / GN_SUM_SCALE); dq += (double)sv[2 * j + 1] * (1.0 / GN_SQ_SCALE); }
+      for (int j = 0; j < nb; ++j) { const double2 e = bsum[bi * nblk + gq * nb + j]; ds += e.x; dq += e.y; }
       const float inv_nf = 1.0f / ((float)T * (float)Cg);
       const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
       const double mean = ds * inv_n;
@@ -803,50 +807,19 @@ template <typename TM> struct GnPrologue {
       const float ve = (float)var + g.gnp_eps;
       float r = rsqrtf(ve);
       r = r * (1.5f - 0.5f * ve * r * r);
-      gtab[bi * 8 + gg] = make_float2((float)mean, r);
+      gtab[bi * 8 + gq] = make_float2((float)mean, r);
     }
     __syncthreads();
-    float sc[3][4], sh[3][4];
-    if (active) {
-      const int gg = c / Cg;
-      const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
-      float2 mrs[3];
-#pragma unroll
-      for (int bi = 0; bi < 3; ++bi) mrs[bi] = gtab[min(bi, nbi - 1) * 8 + gg];
-      // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
-      //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
-      // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
-      // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
-      // "gamma reads zero" non-determinism of round 3.  With every (mean, rstd) pair landed before the first packed product the
-      // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      asm volatile("" : "+v"(mrs[0].x), "+v"(mrs[0].y), "+v"(mrs[1].x), "+v"(mrs[1].y), "+v"(mrs[2].x), "+v"(mrs[2].y));
-#pragma unroll
-      for (int bi = 0; bi < 3; ++bi) {
-        const float2 mr = mrs[bi];
-        const float ts[4] = {t1[bi].x, t1[bi].y, t1[bi].z, t1[bi].w}, tf[4] = {t2[bi].x, t2[bi].y, t2[bi].z, t2[bi].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sc[bi][e] = mr.y * gam[e];
-          sh[bi][e] = bet[e] - mr.x * sc[bi][e];
-          if (g.gnp_temb) {
-            const float s1 = 1.0f + ts[e];
-            sc[bi][e] *= s1;
-            sh[bi][e] = sh[bi][e] * s1 + tf[e];
-          }
-        }
-      }
-      rows(g, sc, sh, olo, ohi, true);
-    }
+    if (active) rows(g, smem, olo, ohi, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
-    __syncthreads();                                        // ... and so are everybody else's: the DMA may read them (and smem is free)
+    __syncthreads();                                        // ... and so are everybody else's: the DMA may read them
     if (nshare_ > 1) {
       // Cooperative form: publish my share, wait (bounded) for the others'.  One 64-bit arrival count per row block that only ever
       // grows (every launch adds nshare to it; 64 bits never wrap), so it needs no reset between launches or graph replays: the value
       // my arrival finds tells which multiple of nshare completes THIS launch.  A sibling that does not show up in time (not resident
       // yet: nothing guarantees co-scheduling) costs a repeat of the whole range by this workgroup; the values are the same whoever
       // writes them, so the result does not depend on which way it went.
-      int* const okf = reinterpret_cast<int*>(smem);
+      int* const okf = reinterpret_cast<int*>(smem + OFF_OK);
       if (tid == 0) {
         // The siblings run on ONE XCD (the cooperative tile order), so its L2 is the point of coherence: the rows were written through
         // and acknowledged (vmcnt(0) above), and the count is only ever touched by read-modify-writes, which execute in that L2.
@@ -867,13 +840,12 @@ template <typename TM> struct GnPrologue {
       }
       __syncthreads();
       const int ok = okf[0];
-      __syncthreads();
       if (!ok) {
         if (tid == 0 && g.gnp_alone) atomicAdd(g.gnp_alone, 1u);
-        if (active) rows(g, sc, sh, rlo, rhi, false);
+        if (active) rows(g, smem, rlo, rhi, false);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
       }
+      __syncthreads();                                      // (the table area is free from here on)
     }
   }
 };
@@ -893,7 +865,9 @@ template <int SPEC> struct G4Waves {
   static constexpr int NC = SPEC == 0 ? 8 : SPEC == 2 ? 8 : 4;       // waves that multiply
   static constexpr int NW = SPEC == 0 ? 8 : NL + NC;
 };
-template <typename TM, int BM, int BN, int STAGES, bool LNC, int SPEC = 0>
+// GNP: the instantiation that carries the GroupNorm prologue (its own kernels: the prologue's registers -- +20 at its peak -- would
+// otherwise cost the 64-row loader / consumer tiles of EVERY GEMM their second workgroup per CU)
+template <typename TM, int BM, int BN, int STAGES, bool LNC, int SPEC = 0, bool GNP = false>
 __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const GemmArgs g NS2VC_G4_FLAGS_PARAM) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
@@ -926,7 +900,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
   const int nb_m = (g.M + BM - 1) / BM;
   const int nwg = nb_n * nb_m;
   int tm, tn;
-  const bool coop = g.gnp_x != nullptr && g.gnp_sync != nullptr && nb_n > 1;     // (uniform over the grid; the launcher pads the grid for it)
+  const bool coop = GNP && g.gnp_x != nullptr && g.gnp_sync != nullptr && nb_n > 1;     // (uniform over the grid; the launcher pads the grid for it)
   if (coop) {
     // cooperative GroupNorm prologue: whole row blocks per XCD, so that the column tiles that share a row block's rows also share an L2
     const int bid = blockIdx.x;
@@ -971,7 +945,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
         for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)(s * BKE) * SZB, lds0 + s * STAGE + wave * 1024 + BM * TROW + j * PASSB);
       }
   }
-  const bool gnp = g.gnp_x != nullptr;             // (uniform over the grid)
+  const bool gnp = GNP && g.gnp_x != nullptr;      // (uniform over the grid)
   GnPrologue<TM> gpro;
   // (measured r4, same box: issuing the prologue's loads up here, before the row-offset set-up, LOSES 1 % -- 3.962 vs 3.921 ms/step -- and
   //  plain instead of write-through stores of the rows change nothing, profiles/r04_ab_gn_prologue_variants.txt; both stay compile-time options)
@@ -1205,14 +1179,21 @@ static hipError_t launch_cfg4(const GemmArgs& g, hipStream_t s) {
   int nb = (g.N / BN) * ((g.M + BM - 1) / BM);
   if (g.gnp_x && g.gnp_sync && g.N / BN > 1) nb = 8 * (((g.M + BM - 1) / BM + 7) / 8) * (g.N / BN);   // cooperative prologue: row blocks per XCD, padded
 #if NS2VC_GEMM_ABLATE
-  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+  if (g.gnp_x) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC, true>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
+  else if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
   else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g, g_gemm_flags);
 #else
-  if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g);
+  if (g.gnp_x) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC, true>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g);   // (never with a LayerNorm consumer epilogue: launch_gemm checks)
+  else if (g.ln_stats) hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, true, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g);
   else hipLaunchKernelGGL((gemm4_kernel<TM, BM, BN, STAGES, false, SPEC>), dim3(nb), dim3(64 * G4Waves<SPEC>::NW), gemm4_lds_bytes(BM, BN, STAGES), s, g);
 #endif
   return hipGetLastError();
 }
+
+// which of the argument checks below refused a launch (the engine and ns2vc_k_gemm append it to their error text)
+static thread_local int g_gemm_fail_line = 0;
+static hipError_t gemm_invalid(int line) { g_gemm_fail_line = line; return hipErrorInvalidValue; }
+int last_gemm_refusal_line() { const int l = g_gemm_fail_line; g_gemm_fail_line = 0; return l; }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
 static int g_spec = 1;   // loader / consumer tiles where the heuristic wants them; tests / tuning: ns2vc_debug_set_gemm_tile(-1, 0, 0) selects the round-2 (plain) tile choice, (-2, 0, 0) restores
@@ -1230,14 +1211,14 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
   const bool n128 = (g.N % 128) == 0;
   if (g_force_bm) {   // test / tuning hook (ns2vc_debug_set_gemm_tile)
     bm = g_force_bm; bn = g_force_bn; st = g_force_st ? g_force_st : 3;
-    if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return hipErrorInvalidValue;
+    if (g.N % bn || ((g.geglu || g.rowstats) && bn != 128)) return gemm_invalid(__LINE__);
   } else {
     // Tuned on MI355X with tools/gemm_sweep.py over the 10 s x batch-32 plan (profiles/gemm_sweep_r01d_bufferdma.txt).
     // The 8-wave K-split kernel wins everywhere except the narrowest GEGLU; 128-row tiles pay off once K is long
     // (>= 12 tiles) or N is wide, and only while the grid still covers the chip (M >= ~7000 rows).
     const bool big_m = g.M >= 7000;
     if (g.geglu) {
-      if (!n128) return hipErrorInvalidValue;
+      if (!n128) return gemm_invalid(__LINE__);
       if (g.N >= 2048) { bm = 128; bn = 128; st = 12; }
       else { bm = 64; bn = 128; st = 2; }
     } else if (n128 && g.N <= 512) {
@@ -1256,59 +1237,61 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
       bm = 64; bn = 64; st = nk >= 32 ? 4 : (nk >= 20 ? 3 : 2);
     }
   }
-  if (g.gnp_x && !((st >= 12 && st <= 13) || (st >= 22 && st <= 44))) return hipErrorInvalidValue;   // the prologue lives in gemm4_kernel
+  if (g.gnp_x && !((st >= 12 && st <= 13) || (st >= 22 && st <= 44))) return gemm_invalid(__LINE__);   // the prologue lives in gemm4_kernel
   if (st >= 22 && st <= 44) {   // loader / consumer specialised kernels: st = 10 * (1 + SPEC) + ring depth
-    if (bn != 128) return hipErrorInvalidValue;
+    if (bn != 128) return gemm_invalid(__LINE__);
 #define NS2VC_CASE4S(BM_, ST_, SP_) if (bm == BM_ && st == 10 * (1 + SP_) + ST_) return launch_cfg4<TM, BM_, 128, ST_, SP_>(g, s)
     // compiled: 4 + 4 waves, ring 3.  Measured and not kept (profiles/r03_gemm_spec.txt): 8 + 8 and 8 + 4 waves (no faster at one
     // workgroup per CU, slower at two: 1024 / 768 threads), ring 2 (+11 % in the captured step) and ring 4 (one workgroup per CU)
     NS2VC_CASE4S(128, 3, 1); NS2VC_CASE4S(64, 3, 1);
 #undef NS2VC_CASE4S
-    return hipErrorInvalidValue;
+    return gemm_invalid(__LINE__);
   }
   if (st == 12 || st == 13) {   // 8-wave K-split kernel, ring depth st - 10
-    if (bn != 128) return hipErrorInvalidValue;
+    if (bn != 128) return gemm_invalid(__LINE__);
 #define NS2VC_CASE4(BM_, ST_) if (bm == BM_ && st == 10 + ST_) return launch_cfg4<TM, BM_, 128, ST_>(g, s)
     NS2VC_CASE4(128, 2); NS2VC_CASE4(128, 3); NS2VC_CASE4(64, 2); NS2VC_CASE4(64, 3);
 #undef NS2VC_CASE4
-    return hipErrorInvalidValue;
+    return gemm_invalid(__LINE__);
   }
 #define NS2VC_CASE(BM_, BN_, ST_) if (bm == BM_ && bn == BN_ && st == ST_) return launch_cfg<TM, BM_, BN_, ST_>(g, s)
   NS2VC_CASE(64, 128, 2);
   NS2VC_CASE(64, 64, 2); NS2VC_CASE(64, 64, 3); NS2VC_CASE(64, 64, 4);
 #undef NS2VC_CASE
-  return hipErrorInvalidValue;
+  return gemm_invalid(__LINE__);
 }
 
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
-  if (g.N % 64 != 0 || g.M <= 0) return hipErrorInvalidValue;
+  if (g.N % 64 != 0 || g.M <= 0) return gemm_invalid(__LINE__);
   const int bke = prec == PREC_F32 ? 32 : 64;
-  if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return hipErrorInvalidValue;
-  if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return hipErrorInvalidValue;
-  if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return hipErrorInvalidValue;    // 16-B aligned rows
-  if (!g.out_f32 && !g.out_op) return hipErrorInvalidValue;
-  if (g.stats && (g.geglu || g.Tout < 64 || (g.N & 15))) return hipErrorInvalidValue;
-  if (g.rowstats && g.geglu) return hipErrorInvalidValue;
-  if (g.ln_stats && (!g.ln_wsum || g.ln_dim <= 0 || (g.ln_dim & 127) || g.ln_dim > 512)) return hipErrorInvalidValue;
-  if (g.rowstats && (g.N & 127)) return hipErrorInvalidValue;
-  if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return hipErrorInvalidValue;   // 16-B row segments
-  if (g.gnp_x) {     // GroupNorm-apply prologue: one source, same-length rows, whole 16-channel blocks per group, <= 3 batch items per tile + halo
-    if (g.c1 || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 512 || (g.c0 & 3) || !g.gnp_stats || !g.gnp_gamma ||
+  if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return gemm_invalid(__LINE__);
+  if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return gemm_invalid(__LINE__);
+  if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return gemm_invalid(__LINE__);    // 16-B aligned rows
+  if (!g.out_f32 && !g.out_op) return gemm_invalid(__LINE__);
+  if (g.stats && (g.geglu || g.Tout < 64 || (g.N & 15))) return gemm_invalid(__LINE__);
+  if (g.rowstats && g.geglu) return gemm_invalid(__LINE__);
+  if (g.ln_stats && (!g.ln_wsum || g.ln_dim <= 0 || (g.ln_dim & 127) || g.ln_dim > 512)) return gemm_invalid(__LINE__);
+  if (g.rowstats && (g.N & 127)) return gemm_invalid(__LINE__);
+  if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return gemm_invalid(__LINE__);   // 16-B row segments
+  if (g.gnp_x) {     // GroupNorm-apply prologue: one or two (concatenated) sources, same-length rows, whole 16-channel blocks per group, <= 3 batch items per tile + halo
+    if (g.c1 || g.ln_stats || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 1024 || (g.c0 & 3) || !g.gnp_stats || !g.gnp_gamma ||
         !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (g.c0 % g.gnp_G) || ((g.c0 / g.gnp_G) & 15) || g.Tin < 66 || (g.gnp_ldx & 3) || (g.lda0 & 3))
-      return hipErrorInvalidValue;
+      return gemm_invalid(__LINE__);
+    if (g.gnp_c1 && (g.gnp_c1 < 0 || g.gnp_c1 >= g.c0 || (g.gnp_c1 & 15) || ((g.c0 - g.gnp_c1) & 15) || !g.gnp_x1 || !g.gnp_stats1 || (g.gnp_ldx1 & 3)))
+      return gemm_invalid(__LINE__);                         // a concat of two sources: whole 16-channel blocks from each
   }
   {   // the DMA addresses rows by 32-bit byte offsets from each tensor's base: every operand must stay below 4 GB
     const unsigned long long sz = operand_bytes(prec), lim = 0xFFF00000ull;
     const unsigned long long rows = (unsigned long long)g.B * g.Tin;
     if (rows * g.lda0 * sz > lim || (g.c1 && rows * g.lda1 * sz > lim) || (g.c2 && rows * g.lda2 * sz > lim) ||
         (unsigned long long)g.N * g.K * sz > lim)
-      return hipErrorInvalidValue;
+      return gemm_invalid(__LINE__);
   }
   switch (prec) {
     case PREC_BF16: return launch_typed<bf16_t>(g, s);
     case PREC_F16: return launch_typed<f16_t>(g, s);
     case PREC_F32: return launch_typed<float>(g, s);
-    default: return hipErrorInvalidValue;
+    default: return gemm_invalid(__LINE__);
   }
 }
 
@@ -1326,12 +1309,14 @@ template <typename K> static hipError_t set_lds(K kern, size_t bytes) {
   do {                                                                                                          \
     hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false>, gemm4_lds_bytes(BM, 128, ST));                 \
     if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true>, gemm4_lds_bytes(BM, 128, ST));        \
+    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, false, 0, true>, gemm4_lds_bytes(BM, 128, ST)); \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 #define NS2VC_SET4S(TM, BM, ST, SP)                                                                             \
   do {                                                                                                          \
     hipError_t e = set_lds(gemm4_kernel<TM, BM, 128, ST, false, SP>, gemm4_lds_bytes(BM, 128, ST));             \
     if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, true, SP>, gemm4_lds_bytes(BM, 128, ST));    \
+    if (e == hipSuccess) e = set_lds(gemm4_kernel<TM, BM, 128, ST, false, SP, true>, gemm4_lds_bytes(BM, 128, ST)); \
     if (e != hipSuccess) return e;                                                                              \
   } while (0)
 template <typename TM> static hipError_t init_typed() {

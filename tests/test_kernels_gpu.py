@@ -299,6 +299,75 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         assert e_op < (1e-6 if prec == 0 else eps16(prec)) and e_out < TOL[prec]
 
 
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 23), (128, 128, 23)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+def test_gemm_groupnorm_prologue_of_a_concat(tile, prec, diag):
+    """The prologue on the channel concat of TWO tensors, each with its own epilogue statistics (resnet.py:591 on torch.cat([h, skip]) in the
+    up blocks: 128+128 ... 512+512 channels, 512+384 with groups that straddle the two sources), plus the un-normalised operand copy the
+    1x1 shortcut reads (gnp_raw) -- against ns2vc_k_groupnorm_stats2 + the same GEMM BIT FOR BIT (normalised rows, raw rows, result), in
+    the redundant and in the cooperative form, and the normalised rows against numpy fp64."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    for (B, T, c0, c1, N, taps) in ((3, 167, 128, 128, 128, 3), (2, 131, 512, 384, 512, 3), (3, 70, 512, 512, 256, 3), (2, 140, 256, 384, 384, 1)):
+        rng = np.random.default_rng(B * 1000 + T + c0 + c1)
+        Cc, Gn = c0 + c1, 8
+        M, K = B * T, taps * Cc
+        x0 = (rng.standard_normal((B, T, c0)) * (1.0 + rng.random((B, 1, c0))) + rng.standard_normal((B, 1, c0))).astype(np.float32)
+        x1 = (rng.standard_normal((B, T, c1)) * 0.5 + rng.standard_normal((B, 1, c1))).astype(np.float32)
+        ld0, ld1 = c0 + 8, c1                                # (the first source sits inside wider rows)
+        x0w = np.zeros((B, T, ld0), np.float32); x0w[..., :c0] = x0
+        gam, bet = (1.0 + 0.2 * rng.standard_normal(Cc)).astype(np.float32), (0.2 * rng.standard_normal(Cc)).astype(np.float32)
+
+        def stats(x):
+            blk = x.astype(np.float64).reshape(B, T, x.shape[-1] // 16, 16)
+            return np.stack([np.rint(blk.sum(axis=(1, 3)) * 2.0 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2.0 ** 16)], axis=-1).astype(np.int64)
+        W = rnd(rng.standard_normal((N, K)) / np.sqrt(K), prec)
+        d_x0, d_x1, d_g, d_b = _dev(x0w.reshape(M, ld0)), _dev(x1.reshape(M, c1)), _dev(gam), _dev(bet)
+        d_s0, d_s1, d_w = DevBuf.from_numpy(stats(x0)), DevBuf.from_numpy(stats(x1)), _pack(W, prec)
+        d_sync = DevBuf.from_numpy(np.zeros((M + 63) // 64, dtype=np.uint64))
+        outs, ops, raws = [], [], []
+        for fused in (0, 1, 2, 2):
+            d_a, d_r = OpBuf(np.full((M, Cc), np.nan, dtype=np.float32), prec), OpBuf(np.full((M, Cc), np.nan, dtype=np.float32), prec)
+            d_o = DevBuf(M * N * 4)
+            d_o.upload(np.full((M, N), np.nan, dtype=np.float32))
+            g = GemmArgs()
+            g.a0 = d_a.ptr; g.lda0 = Cc; g.c0 = Cc
+            g.B, g.Tin, g.Tout, g.M = B, T, T, M
+            g.taps, g.tmode = taps, 0
+            g.w = d_w.value; g.K = K; g.N = N
+            g.out_f32 = d_o.ptr; g.ldo_f32 = N
+            if fused:
+                g.gnp_x = d_x0.ptr; g.gnp_ldx = ld0; g.gnp_stats = d_s0.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
+                g.gnp_eps = 1e-5; g.gnp_G = Gn; g.gnp_silu = 1
+                g.gnp_x1 = d_x1.ptr; g.gnp_ldx1 = ld1; g.gnp_c1 = c1; g.gnp_stats1 = d_s1.ptr; g.gnp_raw = d_r.ptr
+                g.gnp_sync = d_sync.ptr if fused == 2 else None
+            else:
+                check(lib.ns2vc_k_groupnorm_stats2(d_x0.ptr, ld0, c0, d_s0.ptr, d_x1.ptr, ld1, c1, d_s1.ptr, B, T, Gn, 1e-5, d_g.ptr, d_b.ptr, None, 0, 0, 1,
+                                                   d_a.ptr, d_r.ptr, prec, None), "groupnorm_stats2")
+            check(lib.ns2vc_debug_set_gemm_tile(*tile), "set tile")
+            try:
+                check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+                sync()
+            finally:
+                lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+            outs.append(d_o.to_numpy((M, N))); ops.append(d_a.read()); raws.append(d_r.read())
+        lib.ns2vc_dev_free(d_w)
+        x = np.concatenate([x0, x1], axis=-1)
+        xg = x.astype(np.float64).reshape(B, T, Gn, Cc // Gn)
+        mean, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+        y = ((xg - mean) / np.sqrt(var + 1e-5)).reshape(B, T, Cc) * gam.astype(np.float64) + bet.astype(np.float64)
+        y = y / (1.0 + np.exp(-y))
+        e_op, e_raw = rel_l2(ops[1], y.reshape(M, Cc)), rel_l2(raws[1], x.reshape(M, Cc))
+        same = all(np.array_equal(ops[0], o) for o in ops[1:]) and all(np.array_equal(raws[0], o) for o in raws[1:]) and \
+            all(np.array_equal(outs[0], o) for o in outs[1:])
+        diag(f"gemm+GroupNorm prologue of a concat tile={tile} prec={prec} B={B} T={T} C={c0}+{c1} N={N} taps={taps}: rows vs fp64 {e_op:.2e}  raw copy vs input "
+             f"{e_raw:.2e}  rows, raw rows and result == two-launch path (redundant, cooperative x2): {same}")
+        assert np.isfinite(ops[1]).all() and np.isfinite(raws[1]).all() and np.isfinite(outs[1]).all()
+        assert same
+        assert e_op < (1e-6 if prec == 0 else eps16(prec)) and e_raw < (1e-7 if prec == 0 else eps16(prec))
+
+
 @pytest.mark.parametrize("level", [(938, 128, 128), (235, 384, 384), (118, 512, 512)], ids=lambda l: f"T{l[0]}c{l[1]}")
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, level, diag):
