@@ -46,8 +46,9 @@ for r in csv.DictReader(open(f_stats)):
     f = family(k)
     tot[f] = tot.get(f, 0.0) + float(r["TotalDurationNs"])
     calls[f] = calls.get(f, 0) + int(r["Calls"])
-# forward-equivalents in the trace: the norm family is launched only by the per-step plan
-n_fwd = calls.get("norm_stats", 0) / max(per_step.get("norm_stats", 1), 1)
+# forward-equivalents in the trace: attn_kernel is launched only by the per-step plan (the condition pass pools with its own kernel);
+# r4's last builds have no norm family left to count by
+n_fwd = calls.get("attention", 0) / max(per_step.get("attention", 1), 1)
 out = {"source": "rocprofv3 --kernel-trace --stats -- " + " ".join(["python bench.py"] + [f"--{k.replace('_', '-')} {v}" for k, v in (("steps", bench["steps"]), ("warmup", bench["warmup"]))])
                  + " --skip-cpu --skip-fp32 --skip-others --skip-strong",
        "precision": bench["dtype"], "shape": [bench["config"]["global_batch"], bench["config"]["frames"], bench["config"]["prompt_frames"]],
