@@ -632,9 +632,13 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 // statistic (r2 gn_producer, r3 convgn).  This one keeps the K loop and its LDS-DMA untouched: every workgroup first
 // materialises the operand rows ITS tile will read -- its BM output rows plus one halo row either side for k = 3, all c0
 // channels -- in the operand tensor a0, with exactly gn_apply_kernel's arithmetic (bit-identical rows), waits for its own
-// stores, and then runs as before: the DMA reads the rows back from the L2 they were just written through.  Halo rows and the
-// column tiles of one row panel are produced redundantly with identical bytes (no ordering between workgroups needed; the
-// XCD-aware tile mapping keeps a row panel's column tiles on one L2, so the repeated fp32 reads hit it).
+// stores, and then runs as before: the DMA reads the rows back from the L2 they were just written through.  Halo rows are
+// produced redundantly by the two neighbouring row blocks with identical bytes.  The column tiles of one row block either do the
+// same (no ordering between workgroups needed) or -- with GemmArgs.gnp_sync, the engine's default -- build a SHARE of the block's
+// rows each and wait for the others' behind an arrival count in the L2 of the XCD they all run on (`finish`; r4, -1 .. -2 % of the
+// step: the redundant form spent 3x / 4x the SiLU work at 384 / 512 channels).  The input may be the channel concat of two tensors
+// with their own statistics (gnp_x1), and the un-normalised operand copy a 1x1 shortcut reads later can be written along (gnp_raw):
+// with those, every GroupNorm of the bench plan is a prologue (r3: 51 gn_apply launches, r4: none).
 // ---------------------------------------------------------------------------
 #ifndef NS2VC_GNP_WT
 #define NS2VC_GNP_WT 1
@@ -642,14 +646,14 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 // In two halves: `begin` issues EVERY load of the prologue -- the first batch of fp32 rows, the int64 statistics of the (item, group)
 // pairs this tile touches, gamma / beta and the time scale / shift rows --, `finish` does the arithmetic and the stores.  (They run back to
 // back: hoisting `begin` above the kernel's row-offset set-up was measured and lost, see NS2VC_GNP_SPLIT.)
-template <typename TM> struct GnPrologue {
+template <typename TM, int XB_> struct GnPrologue {
 #ifndef NS2VC_GNP_XB
 #define NS2VC_GNP_XB 6
 #endif
 #ifndef NS2VC_GNP_SPIN
 #define NS2VC_GNP_SPIN 256           // polls (~0.5 us each) before a workgroup stops waiting for its siblings and builds every row itself
 #endif
-  static constexpr int XB = NS2VC_GNP_XB;                                   // rows in flight per thread (1: no gain in the loop, 6: -1 %; 12 / 17 cost the kernel its occupancy)
+  static constexpr int XB = XB_;                                            // rows in flight per thread (1: no gain in the loop, 6: -1 %); more only where the tile is alone on its CU anyway
   static constexpr int OFF_BSUM = 256, OFF_OK = 3584;                       // table area (the ring stage nobody has been issued into yet): (mean, rstd) pairs | block sums | flag
   int rlo, rhi, olo, ohi, lim, rln, b_lo, nbi, rl, c, cq, gg, Cg, nshare_, cur;
   unsigned long long* cnt_;
@@ -946,7 +950,10 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       }
   }
   const bool gnp = GNP && g.gnp_x != nullptr;      // (uniform over the grid)
-  GnPrologue<TM> gpro;
+#ifndef NS2VC_GNP_XB128
+#define NS2VC_GNP_XB128 NS2VC_GNP_XB
+#endif
+  GnPrologue<TM, (BM == 128 ? NS2VC_GNP_XB128 : NS2VC_GNP_XB)> gpro;     // (128-row tiles: one workgroup per CU by their LDS, so registers are free)
   // (measured r4, same box: issuing the prologue's loads up here, before the row-offset set-up, LOSES 1 % -- 3.962 vs 3.921 ms/step -- and
   //  plain instead of write-through stores of the rows change nothing, profiles/r04_ab_gn_prologue_variants.txt; both stay compile-time options)
 #ifndef NS2VC_GNP_SPLIT
