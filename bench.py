@@ -736,6 +736,7 @@ def main():
             "launches_per_step": launches, "workspace_gb": workspace_gb, "device": "none (dry run)" if dry else E.device_info(),
             "attention_fallback_workgroups": attn_fb,
             "gn_prologue_workgroups_alone": gn_alone,
+            "xcd_round_robin": (None if dry else E.xcd_round_robin()),
             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
             "roofline": roof, "parity": parity, "self_check": self_check, "fp32_parity_mode": fp32_block, "other_configs": others, "strong_scaling": None,
             "cpu_baseline": cpu,

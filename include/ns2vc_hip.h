@@ -63,6 +63,11 @@ const char* ns2vc_last_error(void);
 int ns2vc_device_count(int* out_count);
 int ns2vc_set_device(int device);               /* one process per GPU: call with LOCAL_RANK */
 int ns2vc_device_name(char* buf, int buflen);
+/* ABI v5.  1 when workgroup ids that differ by a multiple of 8 run on one XCD of the current device (the dispatcher's round robin;
+ * probed once per device with HW_REG_XCC_ID), 0 when they do not, -1 when the probe could not run.  ns2vc_gemm_args.gnp_sync -- rows
+ * exchanged between such workgroups through the L2 they share -- is only valid where this is 1; the engine's `gn_coop` option
+ * defaults to it. */
+int ns2vc_device_xcd_round_robin(int* out);
 
 /* ---- engine lifetime (replaces UNet1DConditionModel.__init__, unet_1d_condition.py:151-607) */
 int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out);

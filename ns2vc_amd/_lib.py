@@ -108,6 +108,7 @@ PROTOTYPES = {
     "ns2vc_last_error": (C.c_char_p, []),
     "ns2vc_device_count": (_I, [C.POINTER(_I)]),
     "ns2vc_set_device": (_I, [_I]),
+    "ns2vc_device_xcd_round_robin": (_I, [C.POINTER(_I)]),
     "ns2vc_device_name": (_I, [C.c_char_p, _I]),
     "ns2vc_unet_create": (_I, [C.POINTER(UnetCfg), _PP]),
     "ns2vc_unet_destroy": (_I, [_P]),

@@ -18,6 +18,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include <mutex>
 
 using namespace ns2vc;
 
@@ -1241,6 +1242,25 @@ int ns2vc_device_name(char* buf, int buflen) {
   return 0;
 }
 
+// per device (the process may serve several): the result of misc.hip's placement probe, taken at the first engine of a device
+static int xcd_round_robin_of_current_device() {
+  static std::mutex mu;
+  static std::map<int, int> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = seen.find(dev);
+  if (it != seen.end()) return it->second;
+  const int r = probe_xcd_round_robin();
+  seen[dev] = r;
+  return r;
+}
+int ns2vc_device_xcd_round_robin(int* out) {
+  if (!out) return fail("null argument");
+  *out = xcd_round_robin_of_current_device();
+  return 0;
+}
+
 int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (!cfg || !out) return fail("null argument");
   if (cfg->n_levels < 2 || cfg->n_levels > NS2VC_MAX_LEVELS) return fail("n_levels out of range");
@@ -1272,6 +1292,9 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
+  // rows shared between workgroups through an XCD's L2 only where the placement probe has SEEN ids 8 apart on one XCD (an explicit
+  // NS2VC_GN_COOP / set_option still decides, e.g. to measure)
+  h->gn_coop = xcd_round_robin_of_current_device() == 1;
   if (const char* e = getenv("NS2VC_GN_COOP")) h->gn_coop = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_FUSE_GN_CAT")) h->fuse_gn_cat = atoi(e) != 0;
   if (const char* e = getenv("NS2VC_SLICE_ROWS")) h->slice_rows = atoi(e) != 0;

@@ -3,6 +3,7 @@
 // layout changes at the API boundary and the fused solver update.  All fp32,
 // wave64, vectorised 16-B accesses on the channels-last activation layout.
 #include "common.h"
+#include <vector>
 
 namespace ns2vc {
 
@@ -730,6 +731,35 @@ hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s
   hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16);
   return hipGetLastError();
 }
+// ---------------------------------------------------------------------------
+// Placement probe.  The cooperative GroupNorm prologue (gemm.hip, GemmArgs.gnp_sync) lets workgroups whose ids differ by a multiple
+// of 8 exchange rows through "the L2 they share": that is the dispatcher's round robin over the XCDs (workgroup id i -> XCD i mod
+// #XCDs; one XCD per partition in CPX mode), and it is a matter of CORRECTNESS there, not only of speed as for the tile orders.  So it
+// is checked once per device: every workgroup of a 2048-block launch reports HW_REG_XCC_ID, and ids 8 apart must agree.
+// ---------------------------------------------------------------------------
+__global__ void xcc_probe_kernel(unsigned* out) {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  if (threadIdx.x == 0) out[blockIdx.x] = v & 15u;
+}
+int probe_xcd_round_robin() {           // 1 = ids 8 apart share an XCD, 0 = they do not, -1 = the probe could not run
+  constexpr int N = 2048;
+  unsigned* d = nullptr;
+  if (hipMalloc((void**)&d, N * sizeof(unsigned)) != hipSuccess) return -1;
+  int ok = -1;
+  std::vector<unsigned> h(N, 0xFFu);
+  if (hipMemset(d, 0xFF, N * sizeof(unsigned)) == hipSuccess) {
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(N), dim3(64), 0, 0, d);
+    if (hipGetLastError() == hipSuccess && hipMemcpy(h.data(), d, N * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+      ok = 1;
+      for (int i = 0; i < N; ++i)
+        if (h[i] > 15u || h[i] != h[i & 7]) { ok = 0; break; }
+    }
+  }
+  (void)hipFree(d);
+  return ok;
+}
+
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s) {
   hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, p, v);
   return hipGetLastError();

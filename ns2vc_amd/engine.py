@@ -143,6 +143,14 @@ def set_device(index: int) -> None:
     check(_lib.load().ns2vc_set_device(int(index)), "set_device")
 
 
+def xcd_round_robin() -> int:
+    """1 when workgroup ids 8 apart share an XCD on the current device (probed once; what the cooperative GroupNorm prologue relies
+    on, its default), 0 when not, -1 when the probe could not run."""
+    n = C.c_int(0)
+    check(_lib.load().ns2vc_device_xcd_round_robin(C.byref(n)), "xcd_round_robin")
+    return int(n.value)
+
+
 def device_count() -> int:
     lib = _lib.load()
     n = C.c_int()
