@@ -36,6 +36,7 @@ Prints ONE JSON line on rank 0 (see the driver contract in the task statement), 
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import math
 import os
@@ -418,7 +419,7 @@ def main():
     if dry:
         torch.set_num_threads(1)
         if world > 1:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         dev = torch.device("cpu")
     else:
         if not torch.cuda.is_available() or E.device_count() == 0:
@@ -428,7 +429,7 @@ def main():
         torch.cuda.set_device(local)
         E.set_device(local)
         if world > 1:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         dev = torch.device("cuda", local)
 
     cfg = UNetConfig()
@@ -777,12 +778,26 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             ok = int(tt.item())
         if ok:
-            ws, _, tg = timed_jobs(es, ios, K, K, min(reps, 3), world > 1, None, 0, GB)
-            wm = statistics.median(ws)
-            strong = {"global_batch": GB, "per_rank_batch": hi - lo, "n_gpus": world, "steps": K, "solver": solver, "ms_per_step": wm * 1e3 / K,
-                      "value": K / wm, "unit": f"denoiser-steps/s at global batch {GB} (strong scaling: the batch is split over the ranks)",
-                      "sample_steps_per_s": GB * K / wm, "jobs_ms": [w * 1e3 for w in ws], "all_gather_ms": tg * 1e3 if world > 1 else 0.0,
-                      "scaling": "strong"}
+            # never take the headline down (round-4 advice): a failure inside the timed jobs becomes an error entry of the one JSON line.
+            # (A rank that raises in here leaves the others in a collective; they are released by the process group's timeout, and the
+            # second agreement below turns "somebody failed" into an error entry on every rank instead of a half-reported number.)
+            try:
+                ws, _, tg = timed_jobs(es, ios, K, K, min(reps, 3), world > 1, None, 0, GB)
+                wm = statistics.median(ws)
+                strong = {"global_batch": GB, "per_rank_batch": hi - lo, "n_gpus": world, "steps": K, "solver": solver, "ms_per_step": wm * 1e3 / K,
+                          "value": K / wm, "unit": f"denoiser-steps/s at global batch {GB} (strong scaling: the batch is split over the ranks)",
+                          "sample_steps_per_s": GB * K / wm, "jobs_ms": [w * 1e3 for w in ws], "all_gather_ms": tg * 1e3 if world > 1 else 0.0,
+                          "scaling": "strong"}
+            except Exception as ex:
+                strong = {"error": repr(ex), "global_batch": GB}
+            if world > 1:
+                try:
+                    tt = torch.tensor([0 if "error" in strong else 1], device=dev, dtype=torch.int32)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+                    if int(tt.item()) == 0 and "error" not in strong:
+                        strong = {"error": "another rank failed inside the strong-scaling jobs", "global_batch": GB}
+                except Exception as ex:
+                    strong = {"error": "agreement after the strong-scaling jobs failed: " + repr(ex), "global_batch": GB}
         else:
             strong = {"error": err or "another rank could not build its shard engine", "global_batch": GB}
         if es is not None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NS2VC_ABI_VERSION 5
+#define NS2VC_ABI_VERSION 6
 #define NS2VC_MAX_LEVELS 8
 #define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
 
@@ -65,8 +65,10 @@ int ns2vc_set_device(int device);               /* one process per GPU: call wit
 int ns2vc_device_name(char* buf, int buflen);
 /* ABI v5.  1 when workgroup ids that differ by a multiple of 8 run on one XCD of the current device (the dispatcher's round robin;
  * probed once per device with HW_REG_XCC_ID), 0 when they do not, -1 when the probe could not run.  ns2vc_gemm_args.gnp_sync -- rows
- * exchanged between such workgroups through the L2 they share -- is only valid where this is 1; the engine's `gn_coop` option
- * defaults to it. */
+ * exchanged between such workgroups through the L2 they share -- is only FAST where this is 1; the engine's `gn_coop` option
+ * defaults to it and cannot be switched on elsewhere.  ABI v6: correctness no longer rests on the probe -- every workgroup of the
+ * cooperative prologue compares HW_REG_XCC_ID with the XCD its slot stands for and builds all its rows itself on a mismatch
+ * (a CU-masked stream, another partition mode), counted in ns2vc_unet_gn_coop_alone. */
 int ns2vc_device_xcd_round_robin(int* out);
 
 /* ---- engine lifetime (replaces UNet1DConditionModel.__init__, unet_1d_condition.py:151-607) */
@@ -173,6 +175,10 @@ int ns2vc_dev_sync(void);
 int ns2vc_stream_create(void** out);
 int ns2vc_stream_destroy(void* stream);
 int ns2vc_stream_sync(void* stream);
+/* ABI v6: a stream whose kernels only run on the CUs whose bit is set (hipExtStreamCreateWithCUMask: bit i % 32 of word i / 32 = CU i of the
+ * device's enumeration, XCD-interleaved on MI355X).  For partitioning the chip between the denoiser and the PyTorch stages of a pipeline
+ * (ns2vc_amd/pipeline.py) and for the placement tests of the cooperative GroupNorm prologue. */
+int ns2vc_stream_create_cu_mask(void** out, const uint32_t* mask_words, int n_words);
 int ns2vc_event_create(void** out);
 int ns2vc_event_destroy(void* ev);
 int ns2vc_event_record(void* ev, void* stream);
@@ -221,11 +227,13 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   const long long* gnp_stats; const float* gnp_gamma; const float* gnp_beta;
   const float* gnp_temb; int32_t gnp_ldtemb;
   float gnp_eps; int32_t gnp_G, gnp_silu;
-  /* ABI v5, optional: [ceil(M / 64)] 64-bit arrival counts (8-byte aligned), zero before the FIRST launch that uses them and owned
-   * by this call site from then on (they only grow: every launch adds N / 128 to a row block's count).  With it (and N > 128)
-   * the N / 128 column tiles of a row block -- neighbours on one XCD -- build a share of the block's rows each and wait for
-   * the others' (bounded: a workgroup that waits in vain builds every row itself), instead of each building all of them.
-   * Same values either way. */
+  /* ABI v5, optional: [ceil(M / 64)] 64-bit arrival counts (8-byte aligned), owned by this call site; every count must be a multiple of
+   * the number of column tiles when a launch starts (zero is: a complete launch adds exactly that number to the count of each row block
+   * it has -- the engine zeroes them at the start of every forward all the same, so that a launch that was cut short cannot hand a
+   * remainder to the next one).  With it (and more than one column tile) the column tiles of a row block -- neighbours on one XCD --
+   * build a share of the block's rows each and wait for the others' (bounded: a workgroup that waits in vain, or finds itself on
+   * another XCD than its slot stands for, builds every row itself), instead of each building all of them.  Same values either way.
+   * Needs a0 128-byte aligned and whole 128-byte lines per row (lda0 * operand size % 128 == 0). */
   unsigned* gnp_sync;
   unsigned* gnp_alone;            /* optional: += 1 per workgroup that waited in vain and built every row itself */
   /* ABI v5, optional: the normalised input is the channel concat of TWO tensors (resnet.py:591 on torch.cat([h, skip]) in the up
@@ -236,6 +244,9 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   const float* gnp_x1; int32_t gnp_ldx1, gnp_c1;
   const long long* gnp_stats1;
   void* gnp_raw;
+  /* ABI v6: kernel choice.  0 = automatic (k = 3 / stride-1 convolutions with Tin >= 66 run on the tap-sharing kernel, convts.hip: the
+   * activation chunk of the three taps is loaded once; same result to fp32 rounding, another summation order over K), 1 = never that kernel. */
+  int32_t algo;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

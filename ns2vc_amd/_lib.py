@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
 NCOEF = 12
 MAX_LEVELS = 8
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Ns2vcError(RuntimeError):
@@ -52,6 +52,7 @@ class GemmArgs(C.Structure):
         ("gnp_eps", C.c_float), ("gnp_G", C.c_int32), ("gnp_silu", C.c_int32),
         ("gnp_sync", C.c_void_p), ("gnp_alone", C.c_void_p),
         ("gnp_x1", C.c_void_p), ("gnp_ldx1", C.c_int32), ("gnp_c1", C.c_int32), ("gnp_stats1", C.c_void_p), ("gnp_raw", C.c_void_p),
+        ("algo", C.c_int32),
     ]
 
 
@@ -148,6 +149,7 @@ PROTOTYPES = {
     "ns2vc_memcpy_d2h": (_I, [_P, _P, C.c_size_t]),
     "ns2vc_dev_sync": (_I, []),
     "ns2vc_stream_create": (_I, [_PP]),
+    "ns2vc_stream_create_cu_mask": (_I, [_PP, C.POINTER(C.c_uint32), _I]),
     "ns2vc_stream_destroy": (_I, [_P]),
     "ns2vc_stream_sync": (_I, [_P]),
     "ns2vc_event_create": (_I, [_PP]),

@@ -228,6 +228,13 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
 int last_gemm_refusal_line();                                               // gemm.hip line of the argument check that refused the last launch on this thread (0: none), cleared by the call
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();
+// tap-sharing k = 3 conv kernel (convts.hip)
+bool convts_eligible(const GemmArgs& g, int prec);
+int convts_default_bn(const GemmArgs& g);
+void set_convts_bn128_min(int wgs);
+int convts_row_blocks(const GemmArgs& g);
+hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, hipStream_t s);
+hipError_t init_convts_attributes();
 void set_forced_gemm_tile(int bm, int bn, int stages);
 void set_gemm_trace(unsigned long long* p);
 hipError_t init_attn_attributes();
@@ -255,7 +262,10 @@ hipError_t init_rowchain_attributes();
 void set_forced_rowchain_tokens(int nt);        // test hook: 0 = heuristic, 1 = 64-token blocks, 2 = 128-token blocks (dim 128 only)
 hipError_t launch_emb_from_table(const float* table, const int* step_ptr, const float* aug, float* emb, void* emb_act_op, int prec, int B,
                                  int edim, hipStream_t s);
-int probe_xcd_round_robin();                                              // misc.hip: 1 = workgroup ids 8 apart share an XCD (what gnp_sync relies on), 0 = not, -1 = probe failed
+int probe_xcd_round_robin(unsigned* map8 = nullptr);
+hipError_t set_gnp_xcc_map_gemm(const unsigned* map8);       // gemm.hip / convts.hip: the XCC id each workgroup slot (id mod 8) stands for, as probed
+hipError_t set_gnp_xcc_map_convts(const unsigned* map8);
+//                                             // misc.hip: 1 = workgroup ids 8 apart share an XCD (what gnp_sync relies on), 0 = not, -1 = probe failed
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s, int* counter = nullptr);                                  // bytes: any; p 16-byte aligned
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);           // bytes % 16 == 0
 hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStream_t s);

@@ -1,0 +1,390 @@
+// Tap-sharing implicit-GEMM kernel for the k = 3, stride-1 Conv1d of the NS2VC denoiser, CDNA4 (gfx950).  Round 5.
+//
+// Replaces gemm4_kernel for the 46 `F.conv1d(k=3, padding=1)` call sites of a step (unet1d/resnet.py:591-641 conv1 / conv2 of
+// every ResnetBlock2D incl. the concat inputs of the up blocks and the fused 1x1 shortcut; unet_1d_condition.py:943,1032
+// conv_in / conv_out) -- 35 % of the step's time in round 4, at 12 % MFMA utilisation.
+//
+// What bounded gemm4_kernel there (profiles/r03_gemm_spec.txt, r04_pmc_*): its K loop streams (BM + BN) x 128 B per 64-wide
+// K tile from L2 into LDS -- 24.5 KB per 1.05 MFLOP with the 64 x 128 tiles the coarse levels need to fill the chip -- at the
+// ~31 B/clk/CU the L2 -> LDS path delivers, against the 96 B/clk the MFMAs of such a tile could eat.  For a k = 3 convolution a
+// third of those bytes is the SAME activation rows fetched three times: tap tau of output row r reads input row r + tau - 1, so
+// the three taps' A tiles are one another shifted by a row.  This kernel loads an activation chunk ONCE:
+//
+//   * rows live in a PADDED row space of period P = T + 1 per batch item (index q = b P + t; t == T is a pad row: its input is
+//     zero -- an out-of-range DMA offset -- and its output is never stored), so "the row above / below" is always q -/+ 1 and
+//     the zero padding at both ends of every item is simply there;
+//   * a tile is 128 panel rows x BN columns: the panel holds padded input rows q0-1 .. q0+126 of one 64-channel chunk (16 KB),
+//     the MFMAs of tap tau read panel rows r + tau, r = 0 .. 127, and the tile OWNS output rows q0 .. q0+125 (rows 126 / 127
+//     read two rows past the panel: computed, never stored) -- 126 / 128 of the MFMA work is useful, no halo DMA pass;
+//   * per 64-channel chunk: ONE 16-KB activation chunk + three (BN x 128 B) weight tiles (k offset tau * Ctot + c: the packed
+//     [N][K] layout already has them, just in another order).  BN = 64: 13.3 KB per 1.05 MFLOP (gemm4: 24.5), BN = 128:
+//     21.3 KB per 2.1 MFLOP (gemm4 128 x 128: 32) -- and the 128 x 64 tile gives as many workgroups as gemm4's 64 x 128;
+//   * activation chunks and weight tiles ride separate 3-deep rings (a chunk is issued two chunks ahead, a weight tile two
+//     steps ahead), counted s_waitcnt vmcnt, one s_barrier per step; loader / consumer wave specialisation as in gemm4's
+//     SPEC kernels: NL loader waves issue every LDS-DMA piece, 4 consumer waves own the MFMAs;
+//   * the concat of the up blocks is a chunk walk over two descriptors, the fused 1x1 shortcut (K segment c2) a run of
+//     single-tap chunks (tau = 1: the centre rows) behind the main ones;
+//   * the GroupNorm-apply prologue (gnpro.h) builds exactly the real rows the panel will read; its cooperative form shares them
+//     between the N / BN column tiles of a row block;
+//   * epilogue as gemm4's (LDS-staged transpose, whole-row stores, bias, fp32 residual, fp32 + operand stores, int64 fixed-point
+//     GroupNorm statistics), with the padded -> real row map applied per stored row.
+//
+// The summation order over K differs from gemm4_kernel's (chunk-major instead of tap-major), so results agree with it to fp32
+// rounding, not bitwise; within this kernel everything is deterministic.
+#include "common.h"
+#include "mma.h"
+#include "gnpro.h"
+
+namespace ns2vc {
+
+constexpr int TS_ROW = 128;    // bytes of K per tile row (64 x 16 bit / 32 fp32)
+constexpr int TS_BM = 128;     // panel rows
+constexpr int TS_BMO = 126;    // output rows a tile owns
+constexpr int TS_ASLOT = TS_BM * TS_ROW;
+
+template <int N> struct TsWait { static __device__ __forceinline__ void run(int n) { if (n >= N) wait_vmcnt<N>(); else TsWait<N - 1>::run(n); } };
+template <> struct TsWait<0> { static __device__ __forceinline__ void run(int) { wait_vmcnt<0>(); } };
+
+template <typename TM, int BN, int NL, bool GNP>
+__global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g) {
+  op_mode_init<TM>();
+  constexpr int EPC = MmaT<TM>::EPC;
+  constexpr int BKE = 8 * EPC;                                   // channels per chunk
+  constexpr int NW = NL + 4, EOFF = NW - 8;                      // waves; first wave with a role in the 8-wave epilogue
+  constexpr int LTH = NL * 64, RPP = LTH / 8, PASSB = RPP * TS_ROW;
+  constexpr int LA = TS_BM / RPP, LB = BN / RPP;                 // 16-B DMA pieces per loading thread: activation chunk / weight tile
+  constexpr int WGN = BN / 64, WGM = 4 / WGN, WM = TS_BM / WGM, MT = WM / 32, NT = 2;
+  constexpr int WSLOT = BN * TS_ROW;
+  constexpr unsigned SZB = sizeof(TM);
+  static_assert(BN == 64 || BN == 128, "BN");
+  static_assert(LA >= 1 && LB >= 1 && LA + LB <= 8, "pieces");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const aring = smem;                                      // 3 activation chunks
+  char* const wring = smem + 3 * TS_ASLOT;                       // 3 weight tiles
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave < NL, consumer = wave >= NL;
+  const int ewave = wave - EOFF;                                 // role in the epilogue (< 0: none)
+  const int cw = consumer ? wave - NL : 0;                       // consumer wave: its wave tile
+  const int wm = cw / WGN, wn = cw % WGN;
+  const unsigned lds0 = (unsigned)(size_t)smem;
+
+  // ---- tile in the padded row space
+  const int T = g.Tin, P = T + 1, MP = g.B * P;
+  const int nb_n = g.N / BN;
+  const int nb_m = (MP + TS_BMO - 1) / TS_BMO;
+  int tm, tn;
+  const bool coop = GNP && g.gnp_x != nullptr && g.gnp_sync != nullptr && nb_n > 1;     // (uniform over the grid; the launcher pads the grid for it)
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    if (coop) {           // whole row blocks per XCD: the column tiles that share a row block's rows share an L2
+      const int q = nb_m >> 3, r = nb_m & 7;
+      const int tml = idx / nb_n;
+      if (tml >= q + (xcd < r ? 1 : 0)) return;
+      tm = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + tml;
+      tn = idx - tml * nb_n;
+    } else {
+      const int nwg = nb_n * nb_m;
+      const int q = nwg >> 3, r = nwg & 7;
+      const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      tm = swz / nb_n;
+      tn = swz - tm * nb_n;
+    }
+  }
+  const int q0 = tm * TS_BMO, n0 = tn * BN;
+
+  // ---- step list: ncm main chunks of three steps (tau = 0, 1, 2), then ncs single-step chunks of the fused 1x1 segment (tau = 1)
+  const int Ctot = g.c0 + g.c1;
+  const int ncm = Ctot / BKE, ncs = g.c2 / BKE, NCH = ncm + ncs;
+  const int K1 = 3 * Ctot;
+  const int S = 3 * ncm + ncs;
+
+  // ---- DMA coordinates.  Piece j of a loading thread = panel / weight row j*RPP + tid/8, physical 16-B chunk tid%8 (source-side
+  // swizzle: physical chunk c of row r holds logical chunk c ^ ((r>>1)&7)).
+  const int prow = (tid & (LTH - 1)) >> 3, pchunk = tid & 7;
+  const unsigned acolb = (unsigned)((pchunk ^ ((prow >> 1) & 7)) * EPC) * SZB;
+  unsigned vw[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * RPP + prow) * (unsigned)g.K) * SZB + acolb;
+  const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
+  int wc_ch = 0, wc_tau = 0;                                     // issue cursor of the weight stream (step order)
+  auto issue_w = [&](int slot) __attribute__((always_inline)) {
+    const int koff = wc_ch < ncm ? wc_tau * Ctot + wc_ch * BKE : K1 + (wc_ch - ncm) * BKE;
+    if (loader) {
+      const unsigned base = lds0 + 3 * TS_ASLOT + slot * WSLOT + wave * 1024;
+#pragma unroll
+      for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)koff * SZB, base + j * PASSB);
+    }
+    if (wc_ch < ncm && wc_tau < 2) ++wc_tau;
+    else { ++wc_ch; wc_tau = wc_ch < ncm ? 0 : 1; }
+  };
+  // the first two weight tiles depend on nothing but the tile's column: in flight while the row offsets (a division per piece) and
+  // the GroupNorm prologue are still being worked out
+  if (S > 0) issue_w(0);
+  if (S > 1) issue_w(1);
+
+  unsigned off0[LA], off1[LA], off2[LA];
+#pragma unroll
+  for (int j = 0; j < LA; ++j) {
+    const int qi = q0 - 1 + j * RPP + prow;                      // padded input row of this panel row
+    const int b = qi > 0 ? qi / P : 0;
+    const int t = qi - b * P;
+    const bool ok = qi >= 0 && qi < MP && t < T;
+    const unsigned row = (unsigned)(qi - b);                     // = b T + t
+    off0[j] = ok ? row * (unsigned)g.lda0 * SZB + acolb : DMA_OOB;
+    off1[j] = (ok && g.c1) ? row * (unsigned)g.lda1 * SZB + acolb : DMA_OOB;
+    off2[j] = (ok && g.c2) ? row * (unsigned)g.lda2 * SZB + acolb : DMA_OOB;
+  }
+  const unsigned long long rowsA = (unsigned long long)g.B * T;
+  const i32x4_t rA0 = make_rsrc(g.a0, rowsA * g.lda0 * SZB);
+  const i32x4_t rA1 = make_rsrc(g.c1 ? g.a1 : g.a0, rowsA * (g.c1 ? g.lda1 : g.lda0) * SZB);
+  const i32x4_t rA2 = make_rsrc(g.c2 ? g.a2 : g.a0, rowsA * (g.c2 ? g.lda2 : g.lda0) * SZB);
+  auto issue_a = [&](int ch, int slot) __attribute__((always_inline)) {      // (every branch wave-uniform)
+    if (!loader) return;
+    const unsigned base = lds0 + slot * TS_ASLOT + wave * 1024;
+    if (ch >= ncm) {
+      const unsigned so = (unsigned)((ch - ncm) * BKE) * SZB;
+#pragma unroll
+      for (int j = 0; j < LA; ++j) blds16(rA2, off2[j], so, base + j * PASSB);
+    } else if (ch * BKE < g.c0) {
+      const unsigned so = (unsigned)(ch * BKE) * SZB;
+#pragma unroll
+      for (int j = 0; j < LA; ++j) blds16(rA0, off0[j], so, base + j * PASSB);
+    } else {
+      const unsigned so = (unsigned)(ch * BKE - g.c0) * SZB;
+#pragma unroll
+      for (int j = 0; j < LA; ++j) blds16(rA1, off1[j], so, base + j * PASSB);
+    }
+  };
+
+  if constexpr (GNP) {
+    if (g.gnp_x != nullptr) {
+      // the real rows behind padded rows [q0 - 1, q0 + 127): f(q) = number of real rows with a padded index below q
+      auto real_below = [&](int q) __attribute__((always_inline)) { const int b = q / P; return b * T + min(q - b * P, T); };
+      const int rlo = real_below(max(q0 - 1, 0)), rhi = real_below(min(q0 + TS_BM - 1, MP));
+      GnPrologue<TM, NS2VC_GNP_XB> gpro;
+      gpro.begin(g, rlo, rhi, tm, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
+      gpro.finish(g, tid, aring);                                // (its table lives in the activation ring: nothing has been issued into it yet)
+    }
+  }
+  issue_a(0, 0);
+  if (NCH > 1) issue_a(1, 1);
+
+  f32x16_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int swb = (l31 >> 1) & 7;
+  // ---- steps.  Invariant: at step s everything issued before step s-1 has landed -- the weight tile of step s was issued at step
+  // s-2 (or above), the activation chunk of a chunk's first step at the first step of the chunk two before it.  So the wait allows
+  // exactly the pieces this thread issued during step s-1 (`ip`).
+  int s = 0, aslot = 0, wslot = 0;
+  int ip = (loader && NCH > 1) ? LA : 0;
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int ntau = ch < ncm ? 3 : 1;
+    for (int ti = 0; ti < ntau; ++ti, ++s) {
+      const int tau = ch < ncm ? ti : 1;
+      TsWait<LA + LB>::run(ip);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my fragment reads of the slots about to be refilled are done
+      __builtin_amdgcn_s_barrier();
+      ip = 0;
+      if (ti == 0 && ch + 2 < NCH) {                             // chunk ch+2 -> the slot chunk ch-1 just left
+        issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
+        if (loader) ip += LA;
+      }
+      if (s + 2 < S) {                                           // weight tile s+2 -> the slot tile s-1 just left
+        issue_w(wslot == 0 ? 2 : wslot - 1);
+        if (loader) ip += LB;
+      }
+      if (consumer) {
+        const char* ap = aring + aslot * TS_ASLOT + (wm * WM + l31 + tau) * TS_ROW;
+        const char* bp = wring + wslot * WSLOT + (wn * 64 + l31) * TS_ROW;
+        const int swa = ((l31 + tau) >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
+          u32x4_t af[MT], bf[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TS_ROW + coffa);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TS_ROW + coffb);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
+        }
+      }
+      if (++wslot == 3) wslot = 0;
+    }
+    if (++aslot == 3) aslot = 0;
+  }
+
+  if (ewave < 0) return;                                         // loaders beyond the epilogue's eight waves (s_barrier counts live waves only)
+  // ---- epilogue: per 32-row slab the four consumer waves stage their 32 x 64 tile in LDS (re-using the rings), then each of the
+  // eight waves moves 16 whole rows out (16-B fp32 / 8-B 16-bit stores, coalesced); bias, residual, statistics; padded -> real rows
+  const int kg = ewave >> 2, wq = ewave & 3;                     // row half inside a slab, wave tile
+  const int em = wq / WGN, en = wq % WGN;
+  constexpr int EP = 64 + 4, SLAB = 32 * EP;
+  float* const et = reinterpret_cast<float*>(smem) + wq * SLAB;
+  float* of = g.out_f32;
+  TM* oo = reinterpret_cast<TM*>(g.out_op);
+  constexpr int LPR = 16, RPI = 4, NIT = 4;
+  const int rsub = lane / LPR, cq = lane % LPR;
+  const int ncol = n0 + en * 64 + cq * 4;
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
+  const int qw0 = q0 + em * WM;                                  // first padded row of the wave tile
+  const int b0 = min(qw0 / P, g.B - 1);                          // its batch item; T >= 66 > WM: the tile touches b0 and at most b0 + 1
+  float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    lds_barrier();                                               // rings (or the previous slab) are free
+    if (kg == 1) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) et[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
+    }
+    lds_barrier();
+    int mrow[NIT];
+    bool okr[NIT], first[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int rl = mt * 32 + kg * 16 + k * RPI + rsub;         // row inside the wave tile
+      const int rt = em * WM + rl;                               // row inside the tile
+      const int q = q0 + rt;
+      const int b = q / P, t = q - b * P;
+      okr[k] = rt < TS_BMO && q < MP && t < T;
+      mrow[k] = okr[k] ? q - b : 0;
+      first[k] = b == b0;
+    }
+    float4 rr[NIT];
+    if (g.res) {                                                 // residual rows first (res may alias out_f32 element-for-element)
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) rr[k] = *reinterpret_cast<const float4*>(g.res + (size_t)mrow[k] * g.ldres + ncol);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) rr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 vv[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int row = kg * 16 + k * RPI + rsub;
+      const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (okr[k]) {
+        v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
+        const float ps = (v.x + v.y) + (v.z + v.w), pq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (first[k]) { gs0 += ps; gq0 += pq; } else { gs1 += ps; gq1 += pq; }
+      }
+      vv[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      if (okr[k]) {
+        if (of) out_f4(of + (size_t)mrow[k] * g.ldo_f32 + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
+        if (oo) out_op4<TM>(oo + (size_t)mrow[k] * g.ldo_op + ncol, vv[k].x, vv[k].y, vv[k].z, vv[k].w);
+      }
+    }
+  }
+  if (g.stats) {
+    // fixed shuffle tree over the lanes that share a 16-channel block (4 column quads x the row lanes), then ONE int64 fixed-point
+    // atomic per (batch item, block, moment): order-independent => deterministic
+    double d0 = gs0, d1 = gq0, d2 = gs1, d3 = gq1;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); d2 += __shfl_xor(d2, o); d3 += __shfl_xor(d3, o); }
+    if (rsub == 0 && (cq & 3) == 0 && qw0 < MP) {
+      const int blk = ncol >> 4, nblk = g.N >> 4;
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
+      atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
+      atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
+      if (b0 + 1 < g.B && (b0 + 1) * P < qw0 + WM) {
+        atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
+        atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+hipError_t set_gnp_xcc_map_convts(const unsigned* map8) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gnp_xcc_of_slot), map8, 8 * sizeof(unsigned)); }
+
+static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)3 * bn * TS_ROW; }
+
+bool convts_eligible(const GemmArgs& g, int prec) {
+  const int bke = prec == PREC_F32 ? 32 : 64;
+  if (g.taps != 3 || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.Tin < 66 || g.geglu || g.rowstats || g.ln_stats) return false;
+  if ((g.N % 64) || (g.c0 % bke) || (g.c1 % bke) || (g.c2 % bke) || g.c0 + g.c1 < bke) return false;
+  if ((unsigned long long)g.B * (g.Tin + 1) > 0x7fff0000ull) return false;
+  return true;
+}
+// BN: 128-column tiles where they still give the chip one round of workgroups, 64 otherwise (and for N that is no multiple of 128)
+static int g_bn128_min = 160;
+void set_convts_bn128_min(int wgs) { g_bn128_min = wgs > 0 ? wgs : 160; }
+int convts_default_bn(const GemmArgs& g) {
+  const long long nbm = ((long long)g.B * (g.Tin + 1) + TS_BMO - 1) / TS_BMO;
+  return ((g.N % 128) == 0 && nbm * (g.N / 128) >= g_bn128_min) ? 128 : 64;
+}
+int convts_row_blocks(const GemmArgs& g) { return (int)(((long long)g.B * (g.Tin + 1) + TS_BMO - 1) / TS_BMO); }
+
+template <typename TM, int BN, int NL> static hipError_t launch_ts_cfg(const GemmArgs& g, hipStream_t s) {
+  const int nbm = convts_row_blocks(g), nbn = g.N / BN;
+  int nb = nbm * nbn;
+  if (g.gnp_x && g.gnp_sync && nbn > 1) nb = 8 * ((nbm + 7) / 8) * nbn;      // cooperative prologue: row blocks per XCD, padded
+  if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, true>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  else hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, false>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  return hipGetLastError();
+}
+template <typename TM> static hipError_t launch_ts_typed(const GemmArgs& g, int bn, int nl, hipStream_t s) {
+  if (bn == 64 && nl == 4) return launch_ts_cfg<TM, 64, 4>(g, s);
+  if (bn == 128 && nl == 4) return launch_ts_cfg<TM, 128, 4>(g, s);
+  if (bn == 64 && nl == 8) return launch_ts_cfg<TM, 64, 8>(g, s);
+  if (bn == 128 && nl == 8) return launch_ts_cfg<TM, 128, 8>(g, s);
+  return hipErrorInvalidValue;
+}
+// bn 64 | 128 (0: heuristic), nl 4 | 8 loader waves (0: default)
+hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, hipStream_t s) {
+  if (!convts_eligible(g, prec)) return hipErrorInvalidValue;
+  if (!bn) bn = convts_default_bn(g);
+  if (!nl) nl = 4;
+  if (g.N % bn) return hipErrorInvalidValue;
+  switch (prec) {
+    case PREC_BF16: return launch_ts_typed<bf16_t>(g, bn, nl, s);
+    case PREC_F16: return launch_ts_typed<f16_t>(g, bn, nl, s);
+    case PREC_F32: return launch_ts_typed<float>(g, bn, nl, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <typename K> static hipError_t ts_set_lds(K kern, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+template <typename TM> static hipError_t ts_init_typed() {
+  hipError_t e = hipSuccess;
+#define NS2VC_TS_SET(BN_, NL_)                                                                      \
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, false>, ts_lds_bytes(BN_));     \
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, true>, ts_lds_bytes(BN_))
+  NS2VC_TS_SET(64, 4); NS2VC_TS_SET(128, 4); NS2VC_TS_SET(64, 8); NS2VC_TS_SET(128, 8);
+#undef NS2VC_TS_SET
+  return e;
+}
+hipError_t init_convts_attributes() {
+  hipError_t e = ts_init_typed<float>();
+  if (e == hipSuccess) e = ts_init_typed<bf16_t>();
+  if (e == hipSuccess) e = ts_init_typed<f16_t>();
+  return e;
+}
+
+}  // namespace ns2vc

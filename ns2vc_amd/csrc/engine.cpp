@@ -157,6 +157,8 @@ struct ns2vc_unet {
   bool fuse_gn_gemm = true;
   bool fuse_gn_cat = true;                // ... also where the norm's input is a concat of two tensors and / or a raw operand copy is wanted (first resnet of a level, up blocks)
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
+  bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
+  int xcd_probe = -1;          // misc.hip's placement probe of this device: 1 = workgroup ids 8 apart share an XCD
   bool slice_rows = true;      // first row chain of a dim-384 block as two N-slices per token block (r4; see Planner::transformer)
   unsigned* ln_health = nullptr;
   bool attn_optimistic = true;   // attention without the per-tile maximum + exact fallback (attn.hip OPT); 0 = exact pass only, on every device
@@ -674,6 +676,12 @@ struct Planner {
     stats_of[tensor] = p;
     return p;
   }
+  unsigned* new_sync(size_t nblocks) {       // 64-bit arrival counts of a cooperative GroupNorm prologue, one per row block
+    if (stats_used + nblocks > stats_cap) return nullptr;
+    long long* p = stats_pool ? stats_pool + stats_used : reinterpret_cast<long long*>(sizeof(long long) * (stats_used + 1));
+    stats_used += nblocks;
+    return reinterpret_cast<unsigned*>(p);
+  }
   long long* find_stats(const float* tensor) const {
     auto it = stats_of.find(tensor);
     return it == stats_of.end() ? nullptr : it->second;
@@ -726,6 +734,7 @@ struct Planner {
     g.w = w.w; g.K = w.K; g.N = w.N; g.bias = w.bias;
     g.out_f32 = out_f32; g.ldo_f32 = ldo;
     g.out_op = out_op; g.ldo_op = ldo;
+    g.algo = h->conv_ts ? 0 : 1;
     return g;
   }
   // GroupNorm of a (possibly concatenated) fp32 input: statistics -> per-(b,c) affine -> operand tensor `dst`
@@ -761,7 +770,9 @@ struct Planner {
       p.gamma = gamma; p.beta = beta; p.temb = temb ? temb + temb_off : nullptr; p.ldtemb = ldt;
       p.eps = eps; p.G = Gq; p.silu = silu;
       // wider than one column tile: the column tiles of a row block share the prologue's rows (one 64-bit count per 64-row block, zeroed with the arena)
-      if (h->gn_coop && consumer_n > 128) { p.sync = alloc<unsigned>(2 * ((size_t)(Bq * Tl + 63) / 64)); p.alone = h->ln_health ? h->ln_health + 48 : nullptr; }
+      // (r5: the counts live in the statistics pool, so the forward's one clear launch also zeroes them: a launch that was cut short cannot
+      //  leave a remainder behind for the next forward)
+      if (h->gn_coop && consumer_n > 128) { p.sync = new_sync(((size_t)Bq * Tl + 63) / 64); p.alone = (p.sync && h->ln_health) ? h->ln_health + 48 : nullptr; }
       return p;
     }
     if (!epi) {
@@ -1219,6 +1230,23 @@ void drop_plan(ns2vc_unet* h) {
 // ====================================================================================
 // C ABI
 // ====================================================================================
+static bool* option_ptr(ns2vc_unet* h, const char* name) {
+  if (!strcmp(name, "ln_linear")) return &h->ln_linear;
+  if (!strcmp(name, "fold_ff")) return &h->fold_ff;
+  if (!strcmp(name, "fuse_ffn")) return &h->fuse_ffn;
+  if (!strcmp(name, "fuse_rows")) return &h->fuse_rows;
+  if (!strcmp(name, "fuse_rows_gn")) return &h->fuse_rows_gn;
+  if (!strcmp(name, "fuse_gn_gemm")) return &h->fuse_gn_gemm;
+  if (!strcmp(name, "gn_coop")) return &h->gn_coop;
+  if (!strcmp(name, "fuse_gn_cat")) return &h->fuse_gn_cat;
+  if (!strcmp(name, "fuse_ffn_pre")) return &h->fuse_ffn_pre;
+  if (!strcmp(name, "attn_fp8")) return &h->attn_fp8;
+  if (!strcmp(name, "attn_optimistic")) return &h->attn_optimistic;
+  if (!strcmp(name, "slice_rows")) return &h->slice_rows;
+  if (!strcmp(name, "conv_ts")) return &h->conv_ts;
+  return nullptr;
+}
+
 extern "C" {
 
 int ns2vc_abi_version(void) { return NS2VC_ABI_VERSION; }
@@ -1251,7 +1279,10 @@ static int xcd_round_robin_of_current_device() {
   std::lock_guard<std::mutex> lock(mu);
   auto it = seen.find(dev);
   if (it != seen.end()) return it->second;
-  const int r = probe_xcd_round_robin();
+  unsigned map8[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+  int r = probe_xcd_round_robin(map8);
+  // the cooperative prologue compares HW_REG_XCC_ID with this table in every workgroup (gnpro.h): a consistent permutation keeps the fast path
+  if (r == 1 && (set_gnp_xcc_map_gemm(map8) != hipSuccess || set_gnp_xcc_map_convts(map8) != hipSuccess)) r = -1;
   seen[dev] = r;
   return r;
 }
@@ -1279,6 +1310,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (cfg->norm_num_groups < 1 || cfg->norm_num_groups > 8) return fail("norm_num_groups=%d unsupported (1..8)", cfg->norm_num_groups);
   if (cfg->cross_attention_dim % cfg->pool_heads || cfg->cross_attention_dim / cfg->pool_heads > 8) return fail("pool heads unsupported");
   hipError_t e = init_gemm_attributes();
+  if (e == hipSuccess) e = init_convts_attributes();
   if (e == hipSuccess) e = init_attn_attributes();
   if (e == hipSuccess) e = init_ffn_attributes();
   if (e == hipSuccess) e = init_rowchain_attributes();
@@ -1286,21 +1318,26 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail("hipGetDevice failed"); }
-  if (const char* e = getenv("NS2VC_LN_LINEAR")) h->ln_linear = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FOLD_FF")) h->fold_ff = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_FFN")) h->fuse_ffn = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_ROWS")) h->fuse_rows = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_ROWS_GN")) h->fuse_rows_gn = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_GN_GEMM")) h->fuse_gn_gemm = atoi(e) != 0;
-  // rows shared between workgroups through an XCD's L2 only where the placement probe has SEEN ids 8 apart on one XCD (an explicit
-  // NS2VC_GN_COOP / set_option still decides, e.g. to measure)
-  h->gn_coop = xcd_round_robin_of_current_device() == 1;
-  if (const char* e = getenv("NS2VC_GN_COOP")) h->gn_coop = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_GN_CAT")) h->fuse_gn_cat = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_SLICE_ROWS")) h->slice_rows = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_FUSE_FFN_PRE")) h->fuse_ffn_pre = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_ATTN_FP8")) h->attn_fp8 = atoi(e) != 0;
-  if (const char* e = getenv("NS2VC_ATTN_OPTIMISTIC")) h->attn_optimistic = atoi(e) != 0;
+  // rows shared between workgroups through an XCD's L2 only where the placement probe has SEEN ids 8 apart on one XCD (and even then
+  // every workgroup checks its own placement, gnpro.h)
+  h->xcd_probe = xcd_round_robin_of_current_device();
+  h->gn_coop = h->xcd_probe == 1;
+  // plan switches from the environment: tuning / A-B runs only (tools/ab_libs.sh), honoured when NS2VC_DEBUG_ENV=1 -- a served engine's
+  // launch plan is set through ns2vc_unet_set_option and never changes behind the caller's back
+  if (const char* dbg = getenv("NS2VC_DEBUG_ENV"); dbg && atoi(dbg) != 0) {
+    static const struct { const char* env; const char* opt; } sw[] = {
+      {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
+      {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
+      {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
+      {"NS2VC_CONV_TS", "conv_ts"}};
+    for (const auto& s : sw)
+      if (const char* v = getenv(s.env)) {
+        if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
+      }
+    if (h->xcd_probe != 1) h->gn_coop = false;
+    if (const char* v = getenv("NS2VC_TS_NL")) set_forced_gemm_tile(-4, 0, atoi(v));      // loader waves of the tap-sharing conv kernel (4 | 8), process-wide
+    if (const char* v = getenv("NS2VC_TS_BN128_MIN")) set_convts_bn128_min(atoi(v));        // workgroups a 128-column tiling must still give to be chosen
+  }
   h->blocks = make_topology(*cfg);
   build_expected(h);
   *out = h;
@@ -1371,20 +1408,10 @@ int ns2vc_unet_set_debug(ns2vc_unet* h, int enable) {
 int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
-  bool* opt = nullptr;
-  if (!strcmp(name, "ln_linear")) opt = &h->ln_linear;
-  else if (!strcmp(name, "fold_ff")) opt = &h->fold_ff;
-  else if (!strcmp(name, "fuse_ffn")) opt = &h->fuse_ffn;
-  else if (!strcmp(name, "fuse_rows")) opt = &h->fuse_rows;
-  else if (!strcmp(name, "fuse_rows_gn")) opt = &h->fuse_rows_gn;
-  else if (!strcmp(name, "fuse_gn_gemm")) opt = &h->fuse_gn_gemm;
-  else if (!strcmp(name, "gn_coop")) opt = &h->gn_coop;
-  else if (!strcmp(name, "fuse_gn_cat")) opt = &h->fuse_gn_cat;
-  else if (!strcmp(name, "fuse_ffn_pre")) opt = &h->fuse_ffn_pre;
-  else if (!strcmp(name, "attn_fp8")) opt = &h->attn_fp8;
-  else if (!strcmp(name, "attn_optimistic")) opt = &h->attn_optimistic;
-  else if (!strcmp(name, "slice_rows")) opt = &h->slice_rows;
-  else return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic)", name);
+  bool* opt = option_ptr(h, name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts)", name);
+  // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
+  if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
   return 0;
 }
@@ -1725,6 +1752,13 @@ int ns2vc_memcpy_h2d(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcp
 int ns2vc_memcpy_d2h(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
 int ns2vc_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return 0; }
 int ns2vc_stream_create(void** out) { hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *out = s; return 0; }
+int ns2vc_stream_create_cu_mask(void** out, const uint32_t* mask_words, int n_words) {
+  if (!out || !mask_words || n_words <= 0) return fail("null argument");
+  hipStream_t s;
+  HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words));
+  *out = s;
+  return 0;
+}
 int ns2vc_stream_destroy(void* s) { HIPCHK(hipStreamDestroy((hipStream_t)s)); return 0; }
 int ns2vc_stream_sync(void* s) { HIPCHK(hipStreamSynchronize((hipStream_t)s)); return 0; }
 int ns2vc_event_create(void** out) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); *out = e; return 0; }
@@ -1742,6 +1776,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
   static bool inited = false;
   if (!inited) {
     hipError_t e = init_gemm_attributes();
+  if (e == hipSuccess) e = init_convts_attributes();
     if (e == hipSuccess) e = init_attn_attributes();
     if (e == hipSuccess) e = init_ffn_attributes();
     if (e == hipSuccess) e = init_rowchain_attributes();

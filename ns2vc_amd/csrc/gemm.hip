@@ -625,234 +625,9 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #define NS2VC_G4_FLAGS_PARAM
 #define NS2VC_G4_FLAG(b) false
 #endif
-// ---------------------------------------------------------------------------
-// GroupNorm-apply prologue (built in r3, shipped in r4; GemmArgs.gnp_*).  The step had 51 gn_apply launches whose only job is to turn fp32 rows into
-// the operand rows ONE following GEMM reads.  A consumer-side fusion that normalises while it loads (r1 conv3gn) pays the
-// normalisation once per tap and column tile on the MFMA waves' critical path; a producer-side fusion needs the whole-item
-// statistic (r2 gn_producer, r3 convgn).  This one keeps the K loop and its LDS-DMA untouched: every workgroup first
-// materialises the operand rows ITS tile will read -- its BM output rows plus one halo row either side for k = 3, all c0
-// channels -- in the operand tensor a0, with exactly gn_apply_kernel's arithmetic (bit-identical rows), waits for its own
-// stores, and then runs as before: the DMA reads the rows back from the L2 they were just written through.  Halo rows are
-// produced redundantly by the two neighbouring row blocks with identical bytes.  The column tiles of one row block either do the
-// same (no ordering between workgroups needed) or -- with GemmArgs.gnp_sync, the engine's default -- build a SHARE of the block's
-// rows each and wait for the others' behind an arrival count in the L2 of the XCD they all run on (`finish`; r4, -1 .. -2 % of the
-// step: the redundant form spent 3x / 4x the SiLU work at 384 / 512 channels).  The input may be the channel concat of two tensors
-// with their own statistics (gnp_x1), and the un-normalised operand copy a 1x1 shortcut reads later can be written along (gnp_raw):
-// with those, every GroupNorm of the bench plan is a prologue (r3: 51 gn_apply launches, r4: none).
-// ---------------------------------------------------------------------------
-#ifndef NS2VC_GNP_WT
-#define NS2VC_GNP_WT 1
-#endif
-// In two halves: `begin` issues EVERY load of the prologue -- the first batch of fp32 rows, the int64 statistics of the (item, group)
-// pairs this tile touches, gamma / beta and the time scale / shift rows --, `finish` does the arithmetic and the stores.  (They run back to
-// back: hoisting `begin` above the kernel's row-offset set-up was measured and lost, see NS2VC_GNP_SPLIT.)
-template <typename TM, int XB_> struct GnPrologue {
-#ifndef NS2VC_GNP_XB
-#define NS2VC_GNP_XB 6
-#endif
-#ifndef NS2VC_GNP_SPIN
-#define NS2VC_GNP_SPIN 256           // polls (~0.5 us each) before a workgroup stops waiting for its siblings and builds every row itself
-#endif
-  static constexpr int XB = XB_;                                            // rows in flight per thread (1: no gain in the loop, 6: -1 %); more only where the tile is alone on its CU anyway
-  static constexpr int OFF_BSUM = 256, OFF_OK = 3584;                       // table area (the ring stage nobody has been issued into yet): (mean, rstd) pairs | block sums | flag
-  int rlo, rhi, olo, ohi, lim, rln, b_lo, nbi, rl, c, cq, gg, Cg, nshare_, cur;
-  unsigned long long* cnt_;
-  bool active;
-  float4 ga, be, t1, t2, xb[XB];                                            // t1 / t2: the time (scale | shift) quad of item `cur`
-  const float* xsrc;                                                        // this thread's column quad in its source tensor (the input may be a concat of two)
-  int xld;
-  long long sv[2];                                                          // (sum, sum of squares) of ONE 16-channel block of one item (thread = item x block)
-  float a[4], b[4];                                                         // y = x * a + b for this quad, item `cur`
-
-  __device__ __forceinline__ void fetch(const GemmArgs& g, int rb) {        // (every lane loads, from a clamped row: a straight-line batch of plain loads)
-    (void)g;
-#pragma unroll
-    for (int k = 0; k < XB; ++k) {
-      const int r = max(min(rb + k * rl, lim - 1), rlo);                    // (an empty share still loads a valid row)
-      xb[k] = *reinterpret_cast<const float4*>(xsrc + (size_t)r * xld);
-    }
-  }
-  __device__ __forceinline__ int item_of(const GemmArgs& g, int r) const {
-    return min((r >= (b_lo + 1) * g.Tin ? 1 : 0) + (r >= (b_lo + 2) * g.Tin ? 1 : 0), nbi - 1);
-  }
-  __device__ __forceinline__ void load_temb(const GemmArgs& g, int bi) {
-    t1 = t2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g.gnp_temb) {
-      const int C = g.c0;
-      const float* tp = g.gnp_temb + (size_t)(b_lo + bi) * g.gnp_ldtemb + cq;
-      if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
-        t1 = *reinterpret_cast<const float4*>(tp);
-        t2 = *reinterpret_cast<const float4*>(tp + C);
-      } else {
-        t1 = make_float4(tp[0], tp[1], tp[2], tp[3]);
-        t2 = make_float4(tp[C], tp[C + 1], tp[C + 2], tp[C + 3]);
-      }
-    }
-  }
-  // (scale, shift) of item `cur` for this thread's quad, from the table in LDS and the vectors in registers
-  __device__ __forceinline__ void affine(const GemmArgs& g, const char* smem) {
-    float2 mr = reinterpret_cast<const float2*>(smem)[cur * 8 + gg];
-    // gfx950 hazard guard (r4, profiles/r04_gn_prologue_rootcause.txt).  Left to the compiler this spot became
-    //   ds_read_b64 x3 ; s_waitcnt vmcnt(1) lgkmcnt(2) ; v_pk_mul_f32 v[..], gamma.xy, v[mean:rstd] op_sel:[0,1]
-    // and, in kernels running beside the LDS-DMA traffic of the loader waves, the packed product came back as 0.0 in its LOW half
-    // for lanes 48-63 of a few waves per launch (inputs verified intact by a scalar recompute of the same registers): the
-    // "gamma reads zero" non-determinism of round 3.  With the (mean, rstd) pair landed before the first packed product the
-    // launch is bit-reproducible (gnp_probe 10 / 10, 10 captured / eager loops, 12 forwards at the bench shape).
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(mr.x), "+v"(mr.y));
-    const float gam[4] = {ga.x, ga.y, ga.z, ga.w}, bet[4] = {be.x, be.y, be.z, be.w};
-    const float ts[4] = {t1.x, t1.y, t1.z, t1.w}, tf[4] = {t2.x, t2.y, t2.z, t2.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      a[e] = mr.y * gam[e];
-      b[e] = bet[e] - mr.x * a[e];
-      if (g.gnp_temb) {
-        const float s1 = 1.0f + ts[e];
-        a[e] *= s1;
-        b[e] = b[e] * s1 + tf[e];
-      }
-    }
-  }
-  __device__ __forceinline__ void begin(const GemmArgs& g, int m0, int BM, int tid, int nth, int share, int nshare) {
-    const int C = g.c0, T = g.Tin;
-    Cg = C / g.gnp_G;
-    const int toff = g.taps >> 1;
-    rlo = max(m0 - toff, 0); rhi = min(m0 + BM + toff, g.M);               // rows [rlo, rhi) of the flattened (item, frame) index
-    b_lo = rlo / T;
-    nbi = (rhi - 1) / T - b_lo + 1;                                         // <= 3 (the launcher checks T against the tile)
-    const int nq = C >> 2;                                                  // float4 quads per row
-    rl = nth / nq;                                                          // rows per pass
-    const int quad = tid % nq;
-    rln = tid / nq;
-    c = quad * 4;
-    active = rln < rl;
-    cq = active ? c : 0;
-    gg = cq / Cg;
-    // cooperative form (gnp_sync): the nshare workgroups that share these rows (the column tiles of one row block, neighbours on one
-    // XCD) build a contiguous share each; [olo, ohi) is mine
-    nshare_ = nshare;
-    cnt_ = nshare > 1 ? reinterpret_cast<unsigned long long*>(g.gnp_sync) + m0 / BM : nullptr;
-    const int per = (rhi - rlo + nshare - 1) / nshare;
-    olo = min(rlo + share * per, rhi); ohi = min(olo + per, rhi);
-    lim = ohi;
-    const int c0a = C - g.gnp_c1;                                           // channels of the first source (all of them unless the input is a concat)
-    if (cq < c0a) { xsrc = g.gnp_x + cq; xld = g.gnp_ldx; } else { xsrc = g.gnp_x1 + (cq - c0a); xld = g.gnp_ldx1; }
-    fetch(g, olo + rln);
-    sv[0] = sv[1] = 0;
-    const int nblk = C >> 4;
-    if (tid < nbi * nblk) {                                                 // <= 3 x 64 threads, one 16-channel block of one item each
-      const int bi = tid / nblk, blk = tid - bi * nblk, nblk0 = c0a >> 4;
-      const long long* st = blk < nblk0 ? g.gnp_stats + ((size_t)(b_lo + bi) * nblk0 + blk) * 2
-                                        : g.gnp_stats1 + ((size_t)(b_lo + bi) * (nblk - nblk0) + (blk - nblk0)) * 2;
-      sv[0] = st[0]; sv[1] = st[1];
-    }
-    ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);                // (unconditional loads: inactive threads read column 0)
-    be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
-    cur = item_of(g, olo + rln);
-    load_temb(g, cur);
-  }
-  // rows [lo, hi) of this thread's column quad: act(x * a + b) -> operand type, written through to L2.  A thread's rows ascend, so the
-  // item they belong to changes at most twice: its (scale, shift) quad is kept and rebuilt behind a branch that is almost never taken
-  // (r4: per-row selects among three items' quads were 16 v_cndmask per quad of a VALU-heavy loop, and 24 registers; tools/gnp_trace.py)
-  __device__ __forceinline__ void rows(const GemmArgs& g, const char* smem, int lo, int hi, bool fetched) {
-    const int T = g.Tin;
-    const int rs = lo + rln;
-    lim = hi;
-    if (!fetched) fetch(g, rs);
-    const int it = item_of(g, rs);
-    if (it != cur) { cur = it; load_temb(g, cur); }
-    affine(g, smem);
-    int nxt = (b_lo + cur + 1) * T;
-    TM* const dst = reinterpret_cast<TM*>(const_cast<void*>(g.a0));
-    TM* const raw = reinterpret_cast<TM*>(g.gnp_raw);
-    for (int rb = rs; rb < hi; rb += XB * rl) {
-      float4 w[XB];
-#pragma unroll
-      for (int k = 0; k < XB; ++k) w[k] = xb[k];
-      fetch(g, rb + XB * rl);                                               // next batch before this one is stored (clamped: the last one is a dummy)
-#pragma unroll
-      for (int k = 0; k < XB; ++k) {
-        const int r = rb + k * rl;
-        if (r < hi) {
-          if (r >= nxt) {                                                   // (rows per pass <= 16 < T: never more than one item further)
-            ++cur; nxt += T;
-            load_temb(g, cur);
-            affine(g, smem);
-          }
-          float y0 = w[k].x * a[0] + b[0], y1 = w[k].y * a[1] + b[1], y2 = w[k].z * a[2] + b[2], y3 = w[k].w * a[3] + b[3];
-          if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-#if NS2VC_GNP_WT
-          out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
-#else
-          store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
-#endif
-          if (raw) out_op4<TM>(raw + (size_t)r * g.lda0 + c, w[k].x, w[k].y, w[k].z, w[k].w);   // the un-normalised operand copy a later 1x1 shortcut reads
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void finish(const GemmArgs& g, int tid, char* smem) {
-    const int T = g.Tin, G = g.gnp_G;
-    float2* const gtab = reinterpret_cast<float2*>(smem);                   // (mean, rstd) of (item - b_lo, group): <= 3 x 8
-    double2* const bsum = reinterpret_cast<double2*>(smem + OFF_BSUM);      // per (item - b_lo, 16-channel block): the scaled sums, exact in double
-    const int nblk = g.c0 >> 4;
-    if (tid < nbi * nblk) bsum[tid] = make_double2((double)sv[0] * (1.0 / GN_SUM_SCALE), (double)sv[1] * (1.0 / GN_SQ_SCALE));
-    __syncthreads();
-    if (tid < nbi * G) {                                                    // same finalisation as gn_apply_kernel (misc.hip); the sums are exact, their order is free
-      const int bi = tid / G, gq = tid - bi * G;
-      const int nb = Cg >> 4;
-      double ds = 0.0, dq = 0.0;
-      for (int j = 0; j < nb; ++j) { const double2 e = bsum[bi * nblk + gq * nb + j]; ds += e.x; dq += e.y; }
-      const float inv_nf = 1.0f / ((float)T * (float)Cg);
-      const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
-      const double mean = ds * inv_n;
-      double var = dq * inv_n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      const float ve = (float)var + g.gnp_eps;
-      float r = rsqrtf(ve);
-      r = r * (1.5f - 0.5f * ve * r * r);
-      gtab[bi * 8 + gq] = make_float2((float)mean, r);
-    }
-    __syncthreads();
-    if (active) rows(g, smem, olo, ohi, true);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
-    __syncthreads();                                        // ... and so are everybody else's: the DMA may read them
-    if (nshare_ > 1) {
-      // Cooperative form: publish my share, wait (bounded) for the others'.  One 64-bit arrival count per row block that only ever
-      // grows (every launch adds nshare to it; 64 bits never wrap), so it needs no reset between launches or graph replays: the value
-      // my arrival finds tells which multiple of nshare completes THIS launch.  A sibling that does not show up in time (not resident
-      // yet: nothing guarantees co-scheduling) costs a repeat of the whole range by this workgroup; the values are the same whoever
-      // writes them, so the result does not depend on which way it went.
-      int* const okf = reinterpret_cast<int*>(smem + OFF_OK);
-      if (tid == 0) {
-        // The siblings run on ONE XCD (the cooperative tile order), so its L2 is the point of coherence: the rows were written through
-        // and acknowledged (vmcnt(0) above), and the count is only ever touched by read-modify-writes, which execute in that L2.
-        // (Agent-scope fences / atomics would be correct too, but on this multi-XCD part they cost an L2 write-back and a trip to the
-        // memory side per workgroup: measured, the prologue got slower than the redundant form.)
-        unsigned long long old, v, one = 1ull, zero = 0ull;
-        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(cnt_), "v"(one) : "memory");
-        const unsigned long long target = (old / (unsigned)nshare_ + 1ull) * (unsigned)nshare_;
-        int ok = old + 1ull == target;
-        const int spins = (old >> 62) ? 0 : NS2VC_GNP_SPIN;                  // (a count with bit 62 set: "do not wait" -- how the tests reach the path below)
-        if (old >> 62) ok = 0;
-        for (int it = 0; !ok && it < spins; ++it) {
-          asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(cnt_), "v"(zero) : "memory");
-          ok = v >= target;
-          if (!ok) __builtin_amdgcn_s_sleep(2);
-        }
-        okf[0] = ok;
-      }
-      __syncthreads();
-      const int ok = okf[0];
-      if (!ok) {
-        if (tid == 0 && g.gnp_alone) atomicAdd(g.gnp_alone, 1u);
-        if (active) rows(g, smem, rlo, rhi, false);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();                                      // (the table area is free from here on)
-    }
-  }
-};
+}  // namespace ns2vc
+#include "gnpro.h"   // GnPrologue: act(GroupNorm(x)) of the rows a tile reads, built in front of its K loop
+namespace ns2vc {
 
 // SPEC (r3): loader / consumer wave specialisation.  profiles/r03_gemm_ablate4.txt: the DMA stream alone and the reads + MFMAs
 // alone each take about half of the full loop's time -- they do not overlap, because every wave issues its DMA pieces (an
@@ -959,7 +734,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
 #ifndef NS2VC_GNP_SPLIT
 #define NS2VC_GNP_SPLIT 0
 #endif
-  if (NS2VC_GNP_SPLIT && gnp) gpro.begin(g, m0, BM, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
+  if (NS2VC_GNP_SPLIT && gnp) gpro.begin(g, max(m0 - (g.taps >> 1), 0), min(m0 + BM + (g.taps >> 1), g.M), tm, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
   const int Ctot = g.c0 + g.c1;
   const int smul = g.tmode == TMODE_DOWN2 ? 2 : 1;
   const int toff = g.taps >> 1;
@@ -1065,7 +840,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) issue_b(s, s);
     }
-    if (!NS2VC_GNP_SPLIT) gpro.begin(g, m0, BM, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
+    if (!NS2VC_GNP_SPLIT) gpro.begin(g, max(m0 - toff, 0), min(m0 + BM + toff, g.M), tm, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
     gpro.finish(g, tid, smem + (STAGES - 1) * STAGE);
   }
 #pragma unroll
@@ -1174,6 +949,7 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t set_gnp_xcc_map_gemm(const unsigned* map8) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gnp_xcc_of_slot), map8, 8 * sizeof(unsigned)); }
 void set_gemm_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &p, sizeof(p)); }
 
 static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
@@ -1203,9 +979,11 @@ static hipError_t gemm_invalid(int line) { g_gemm_fail_line = line; return hipEr
 int last_gemm_refusal_line() { const int l = g_gemm_fail_line; g_gemm_fail_line = 0; return l; }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
+static int g_ts = 1, g_ts_nl = 0;   // tap-sharing conv kernel on / off (tests / tuning: ns2vc_debug_set_gemm_tile(-3, 0, 0) off, (-4, 0, nl) on with nl loader waves, 0 = default)
 static int g_spec = 1;   // loader / consumer tiles where the heuristic wants them; tests / tuning: ns2vc_debug_set_gemm_tile(-1, 0, 0) selects the round-2 (plain) tile choice, (-2, 0, 0) restores
 void set_forced_gemm_tile(int bm, int bn, int stages) {
-  if (bm == -1 || bm == -2) { g_spec = bm == -2 ? 1 : 0; return; } g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
+  if (bm == -1 || bm == -2) { g_spec = bm == -2 ? 1 : 0; return; }
+  if (bm == -3 || bm == -4) { g_ts = bm == -4 ? 1 : 0; g_ts_nl = (bm == -4 && (stages == 4 || stages == 8)) ? stages : 0; return; } g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
 // Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
 // The compiled set is exactly what this function can return:
@@ -1284,6 +1062,10 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
     if (g.c1 || g.ln_stats || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 1024 || (g.c0 & 3) || !g.gnp_stats || !g.gnp_gamma ||
         !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (g.c0 % g.gnp_G) || ((g.c0 / g.gnp_G) & 15) || g.Tin < 66 || (g.gnp_ldx & 3) || (g.lda0 & 3))
       return gemm_invalid(__LINE__);
+    // cooperative form: rows written by other CUs are read back without an L1 invalidate, which is only sound while no cache line holds
+    // rows of two row blocks -- whole 128-byte lines per row
+    if (g.gnp_sync && ((reinterpret_cast<uintptr_t>(g.a0) & 127) || (((size_t)g.lda0 * operand_bytes(prec)) & 127) || (reinterpret_cast<uintptr_t>(g.gnp_sync) & 7)))
+      return gemm_invalid(__LINE__);
     if (g.gnp_c1 && (g.gnp_c1 < 0 || g.gnp_c1 >= g.c0 || (g.gnp_c1 & 15) || ((g.c0 - g.gnp_c1) & 15) || !g.gnp_x1 || !g.gnp_stats1 || (g.gnp_ldx1 & 3)))
       return gemm_invalid(__LINE__);                         // a concat of two sources: whole 16-channel blocks from each
   }
@@ -1293,6 +1075,14 @@ hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
     if (rows * g.lda0 * sz > lim || (g.c1 && rows * g.lda1 * sz > lim) || (g.c2 && rows * g.lda2 * sz > lim) ||
         (unsigned long long)g.N * g.K * sz > lim)
       return gemm_invalid(__LINE__);
+  }
+  // k = 3 / stride 1: the tap-sharing kernel (convts.hip) unless the caller (algo = 1), the global switch or a forced gemm4 / gemm2 tile says otherwise;
+  // a forced tile (128, 64 | 128, 54 | 58) selects its BN and loader-wave count
+  {
+    const bool forced_ts = g_force_bm == 128 && (g_force_st == 54 || g_force_st == 58);
+    if (g.algo != 1 && (forced_ts || (g_ts && !g_force_bm)) && convts_eligible(g, prec))
+      return launch_convts(g, prec, forced_ts ? g_force_bn : 0, forced_ts ? g_force_st - 50 : g_ts_nl, s);
+    if (forced_ts) return gemm_invalid(__LINE__);
   }
   switch (prec) {
     case PREC_BF16: return launch_typed<bf16_t>(g, s);

@@ -742,7 +742,7 @@ __global__ void xcc_probe_kernel(unsigned* out) {
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
   if (threadIdx.x == 0) out[blockIdx.x] = v & 15u;
 }
-int probe_xcd_round_robin() {           // 1 = ids 8 apart share an XCD, 0 = they do not, -1 = the probe could not run
+int probe_xcd_round_robin(unsigned* map8) {   // 1 = ids 8 apart share an XCD, 0 = they do not, -1 = the probe could not run; map8[i] = XCC id of ids = i mod 8
   constexpr int N = 2048;
   unsigned* d = nullptr;
   if (hipMalloc((void**)&d, N * sizeof(unsigned)) != hipSuccess) return -1;
@@ -754,6 +754,8 @@ int probe_xcd_round_robin() {           // 1 = ids 8 apart share an XCD, 0 = the
       ok = 1;
       for (int i = 0; i < N; ++i)
         if (h[i] > 15u || h[i] != h[i & 7]) { ok = 0; break; }
+      if (ok == 1 && map8)
+        for (int i = 0; i < 8; ++i) map8[i] = h[i];
     }
   }
   (void)hipFree(d);

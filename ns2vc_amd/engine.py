@@ -80,10 +80,23 @@ def _ptr(x) -> int:
 
 
 class Stream:
-    def __init__(self):
+    """A non-blocking HIP stream.  ``cu_mask`` (an iterable of CU indices, or None): restrict the stream's kernels to those CUs
+    (``hipExtStreamCreateWithCUMask``) -- how a pipeline gives the PyTorch stages a slice of the chip beside the denoiser."""
+
+    def __init__(self, cu_mask=None):
         self.lib = _lib.load()
         p = C.c_void_p()
-        check(self.lib.ns2vc_stream_create(C.byref(p)), "stream_create")
+        if cu_mask is None:
+            check(self.lib.ns2vc_stream_create(C.byref(p)), "stream_create")
+        else:
+            cus = sorted(set(int(c) for c in cu_mask))
+            if not cus or cus[0] < 0:
+                raise ValueError("cu_mask must name at least one CU")
+            nw = cus[-1] // 32 + 1
+            words = (C.c_uint32 * nw)()
+            for c in cus:
+                words[c // 32] |= 1 << (c % 32)
+            check(self.lib.ns2vc_stream_create_cu_mask(C.byref(p), words, nw), "stream_create_cu_mask")
         self.ptr = p.value
 
     def sync(self):

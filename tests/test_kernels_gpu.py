@@ -145,6 +145,10 @@ GEMM_CASES = [
     ("conv3", 2, 37, 37, 128, 0, 128, 3, 0, 1, 0, 0, 0),
     ("conv3_concat_res", 2, 37, 37, 128, 64, 128, 3, 0, 1, 1, 0, 1),
     ("conv1_concat_shortcut", 2, 37, 37, 192, 128, 256, 1, 0, 1, 0, 0, 0),
+    # T >= 66: the tap-sharing kernel (convts.hip) under the default heuristic; N = 192 only has 64-column tiles
+    ("conv3_ts", 2, 70, 70, 128, 0, 128, 3, 0, 1, 0, 0, 0),
+    ("conv3_ts_concat_res_dual", 3, 131, 131, 128, 64, 192, 3, 0, 1, 1, 0, 1),
+    ("conv3_ts_long", 2, 300, 300, 256, 128, 256, 3, 0, 1, 1, 0, 1),
     ("down2_odd", 2, 37, 19, 128, 0, 128, 3, 1, 1, 0, 0, 0),
     ("down2_even", 2, 38, 19, 128, 0, 128, 3, 1, 1, 0, 0, 0),
     ("up2_odd", 2, 19, 37, 128, 0, 128, 3, 2, 1, 0, 0, 0),
@@ -214,8 +218,75 @@ def test_gemm_every_tile(tile, prec, diag):
         assert e < TOL[prec]
 
 
+TS_STAGES = (54, 58)     # ns2vc_debug_set_gemm_tile(128, BN, 50 + loader waves): the tap-sharing conv kernel (convts.hip), BN 64 | 128
+
+
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 13), (128, 128, 13), (64, 128, 23), (128, 128, 23)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+def test_conv_tapshare_kernel(tile, prec, diag):
+    """conv3ts_kernel (k = 3, stride 1: resnet.py:591-641 conv1 / conv2, unet_1d_condition.py:943,1032) against numpy fp64 AND against
+    gemm4_kernel on the same operands: every tile (BN 64 / 128, 4 / 8 loader waves); items shorter, equal to and longer than a 126-row tile
+    (T = 66, 70, 125, 126, 127, 300: pad rows at every position of a tile, tiles inside one item, items inside one tile); 1, 2, 3 and many
+    channel chunks; the concat of two sources; the fused 1x1 segment (single-tap chunks behind the main ones); bias, residual that aliases
+    nothing, fp32 + operand outputs; NaN-prefilled outputs (every row written exactly where it belongs, nothing else touched)."""
+    lib = _lib()
+    rng = np.random.default_rng(tile[1] * 7 + tile[2])
+    ck = 64 if prec else 32
+    cases = [(B, T, ck * nc, 0) for (B, T, nc) in ((3, 66, 1), (2, 70, 2), (3, 125, 3), (2, 126, 4), (3, 127, 2), (2, 300, 6), (5, 67, 2))]
+    cases += [(3, 131, 2 * ck, ck), (2, 90, ck, 3 * ck), (4, 70, 4 * ck, 4 * ck)]
+    for (B, T, c0, c1) in cases:
+        for N in (128, 256):
+            out, ref, out_op = run_gemm(rng, prec, B, T, T, c0, c1, N, 3, 0, 1, 1, 0, 1, tile=tile)
+            e = rel_l2(out, ref)
+            out4, _, _ = run_gemm(np.random.default_rng(1), prec, B, T, T, c0, c1, N, 3, 0, 1, 1, 0, 0, tile=(64, 128, 23))
+            outs, _, _ = run_gemm(np.random.default_rng(1), prec, B, T, T, c0, c1, N, 3, 0, 1, 1, 0, 0, tile=tile)
+            e4 = rel_l2(outs, out4)
+            diag(f"conv3ts tile={tile} prec={prec} B={B} T={T} c={c0}+{c1} N={N}: vs fp64 {e:.3e}  vs gemm4_kernel {e4:.3e}  nan={int(np.isnan(out).sum())}")
+            assert e < TOL[prec] and e4 < (1e-5 if prec == 0 else 1e-5), (B, T, c0, c1, N, e, e4)
+            assert np.array_equal(out_op, rnd(out, prec))
+    # the fused 1x1 segment on a third operand tensor (resnet conv2 + conv_shortcut), with epilogue statistics
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    for (B, T, c0, c2, N) in ((3, 70, 4 * ck, 10 * ck, 256), (2, 131, 2 * ck, ck, 128), (3, 97, 8 * ck, 16 * ck, 512)):
+        M = B * T
+        hn, x = rnd(rng.standard_normal((B, T, c0)), prec), rnd(rng.standard_normal((B, T, c2)), prec)
+        W = rnd(rng.standard_normal((N, 3 * c0 + c2)) / np.sqrt(3 * c0 + c2), prec)
+        bias = rng.standard_normal(N).astype(np.float32)
+        G = gather_rows(hn.astype(np.float64), B, T, T, 3, 0).reshape(M, 3 * c0)
+        ref = G @ W[:, :3 * c0].astype(np.float64).T + x.reshape(M, c2).astype(np.float64) @ W[:, 3 * c0:].astype(np.float64).T + bias
+        d_h, d_x, d_w, d_b = OpBuf(hn, prec), OpBuf(x, prec), _pack(W, prec), _dev(bias)
+        d_o = DevBuf(M * N * 4)
+        d_o.upload(np.full((M, N), np.nan, dtype=np.float32))
+        d_s = DevBuf.from_numpy(np.zeros((B, N // 16, 2), dtype=np.int64))
+        g = GemmArgs()
+        g.a0 = d_h.ptr; g.lda0 = c0; g.c0 = c0
+        g.a2 = d_x.ptr; g.lda2 = c2; g.c2 = c2
+        g.B, g.Tin, g.Tout, g.M = B, T, T, M
+        g.taps, g.tmode = 3, 0
+        g.w = d_w.value; g.K = 3 * c0 + c2; g.N = N; g.bias = d_b.ptr
+        g.out_f32 = d_o.ptr; g.ldo_f32 = N
+        g.stats = d_s.ptr
+        check(lib.ns2vc_debug_set_gemm_tile(*tile), "tile")
+        try:
+            check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+            sync()
+        finally:
+            lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+        out = d_o.to_numpy((M, N))
+        e = rel_l2(out, ref)
+        st = d_s.to_numpy((B, N // 16, 2), dtype=np.int64).astype(np.float64)
+        blk = out.astype(np.float64).reshape(B, T, N // 16, 16)
+        ref_s, ref_q = blk.sum(axis=(1, 3)), (blk ** 2).sum(axis=(1, 3))
+        e_s = np.abs(st[..., 0] / 2 ** 28 - ref_s).max() / np.abs(ref_s).max()
+        e_q = np.abs(st[..., 1] / 2 ** 16 - ref_q).max() / np.abs(ref_q).max()
+        diag(f"conv3ts + 1x1 segment tile={tile} prec={prec} {(B, T, c0, c2, N)}: {e:.3e}  statistics {e_s:.1e} / {e_q:.1e}")
+        assert e < TOL[prec] and e_s < 1e-5 and e_q < 1e-5
+        lib.ns2vc_dev_free(d_w)
+
+
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 13), (128, 128, 13), (64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58)],
+                         ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_groupnorm_prologue(tile, prec, diag):
     """ns2vc_gemm_args.gnp_*: the GEMM writes act(GroupNorm(x)) for the rows its tiles read into its own A operand and then runs as
     usual (resnet.py:606-629 norm -> act -> conv, transformer_1d.py:268 norm -> proj_in) -- against the two-launch path
@@ -227,6 +298,8 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
     lib = _lib()
     for (B, T, Cc, N, taps, temb_on, silu, Gn) in ((3, 167, 128, 128, 3, 1, 1, 8), (2, 131, 256, 384, 3, 0, 1, 8), (3, 140, 384, 384, 1, 0, 0, 8),
                                                    (4, 131, 512, 256, 3, 1, 1, 8), (5, 70, 256, 256, 3, 1, 1, 8)):
+        if tile[2] in TS_STAGES and (taps != 3 or N % tile[1]):
+            continue                                     # (a forced tap-sharing tile only takes k = 3)
         rng = np.random.default_rng(B * 1000 + T + Cc + taps)
         M, K = B * T, taps * Cc
         x = (rng.standard_normal((B, T, Cc)) * (1.0 + rng.random((B, 1, Cc))) + rng.standard_normal((B, 1, Cc))).astype(np.float32)
@@ -289,9 +362,12 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         same_op, same_out = all(np.array_equal(ops[0], o) for o in ops[1:]), all(np.array_equal(outs[0], o) for o in outs[1:])
         counts = d_sync.to_numpy((nsync,), dtype=np.uint64)
         alone = d_alone.to_numpy((2,), dtype=np.uint32)
-        assert alone[0] == 0 and (alone[1] > 0) == (N > 128), f"workgroups that waited in vain: {alone}"
-        per = 2 * (N // 128) if N > 128 else 0
-        assert np.isin(counts, (0, per)).all() and counts[0] == per, "every cooperative launch adds N / 128 arrivals to a row block's count"
+        # column tiles that share a row block: N / 128 in gemm4_kernel, N / BN in the tap-sharing kernel (k = 3; BN = 64 at these sizes by default)
+        ts = taps == 3 and (tile == (0, 0, 0) or tile[2] in TS_STAGES)
+        nshare = N // (tile[1] if tile[2] in TS_STAGES else 64) if ts else N // 128
+        assert alone[0] == 0 and (alone[1] > 0) == (nshare > 1), f"workgroups that waited in vain: {alone}"
+        per = 2 * nshare if nshare > 1 else 0
+        assert np.isin(counts, (0, per)).all() and counts[0] == per, "every cooperative launch adds one arrival per column tile to a row block's count"
         diag(f"gemm+GroupNorm prologue tile={tile} prec={prec} B={B} T={T} C={Cc} N={N} taps={taps} temb={temb_on} silu={silu}: "
              f"rows vs fp64 {e_op:.2e}  result vs fp64 {e_out:.2e}  rows==two-launch {same_op}  result==two-launch {same_out}")
         assert np.isfinite(ops[1]).all() and np.isfinite(outs[1]).all()          # every row the tiles read was produced
@@ -300,7 +376,7 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 23), (128, 128, 23)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 128, 58)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_groupnorm_prologue_of_a_concat(tile, prec, diag):
     """The prologue on the channel concat of TWO tensors, each with its own epilogue statistics (resnet.py:591 on torch.cat([h, skip]) in the
     up blocks: 128+128 ... 512+512 channels, 512+384 with groups that straddle the two sources), plus the un-normalised operand copy the
@@ -310,6 +386,8 @@ def test_gemm_groupnorm_prologue_of_a_concat(tile, prec, diag):
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
     for (B, T, c0, c1, N, taps) in ((3, 167, 128, 128, 128, 3), (2, 131, 512, 384, 512, 3), (3, 70, 512, 512, 256, 3), (2, 140, 256, 384, 384, 1)):
+        if tile[2] in TS_STAGES and (taps != 3 or N % tile[1]):
+            continue
         rng = np.random.default_rng(B * 1000 + T + c0 + c1)
         Cc, Gn = c0 + c1, 8
         M, K = B * T, taps * Cc
@@ -434,7 +512,7 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
     lib = _lib()
     rng = np.random.default_rng(5)
     B, T, c0, N = 3, 167, 128, 256
-    for tile in [(0, 0, 0), (64, 128, 2), (64, 64, 2), (128, 128, 13), (64, 128, 13), (128, 128, 23), (64, 128, 23)]:
+    for tile in [(0, 0, 0), (64, 128, 2), (64, 64, 2), (128, 128, 13), (64, 128, 13), (128, 128, 23), (64, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58)]:
         a0 = rnd(rng.standard_normal((B, T, c0)), prec)
         W = rnd(rng.standard_normal((N, 3 * c0)) / np.sqrt(3 * c0), prec)
         bias = rng.standard_normal(N).astype(np.float32)

@@ -3,6 +3,7 @@
 #   make -C ns2vc_amd/csrc OUT=../lib/variants/x -j4     # variant build from a patched source tree at the same depth
 #   gpurun -- 'bash tools/ab_bench.sh ns2vc_amd/lib/variants/x/libns2vc_hip.so'
 # alternates the default library (A) and the variant (B, via NS2VC_LIB) three times.
+export NS2VC_DEBUG_ENV=1   # the plan switches (NS2VC_FUSE_*, NS2VC_CONV_TS, ...) are only read under this (r5)
 VAR=${1:?path of the variant libns2vc_hip.so}
 for i in 1 2 3; do
   for v in A B; do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # same-box A/B of library builds / plan switches inside the captured bench loop:  bash tools/ab_libs.sh "<lib|default> [ENV=VAL ...]" ...
 # each argument is one configuration: a variant name under ns2vc_amd/lib/variants (or `default`) followed by environment assignments
+export NS2VC_DEBUG_ENV=1   # the plan switches (NS2VC_FUSE_*, NS2VC_CONV_TS, ...) are only read under this (r5)
 cd "$(dirname "$0")/.."
 CFGS=("$@")
 for r in 1 2; do

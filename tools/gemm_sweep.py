@@ -34,6 +34,8 @@ ABLATE4 = [(bm, 128, 13 | (f << 8)) for bm in (64, 128) for f in (0, 2, 4, 8, 16
 # loader / consumer specialised gemm4 (stages 23 / 24 = ring 3 / 4) beside the plain K-split kernel
 # (the 8 + 8 / 8 + 4 wave modes and ring 2 / 4 of profiles/r03_gemm_spec.txt need their NS2VC_CASE4S / NS2VC_SET4S lines back in gemm.hip)
 SPEC = [(64, 128, 13), (64, 128, 23), (128, 128, 12), (128, 128, 13), (128, 128, 23)]
+# r5: the tap-sharing conv kernel (convts.hip; stages 54 / 58 = 4 / 8 loader waves, BN = 64 / 128) beside gemm4's loader / consumer tiles, k = 3 shapes only
+TS = [(64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58)]
 
 
 def stride_shapes():
@@ -74,8 +76,11 @@ def main():
                                                         "32 MB of L2 every launch reads L2-cold data, as inside the captured step")
     ap.add_argument("--strides", action="store_true", help="time stride_shapes() instead of the plan's shapes")
     ap.add_argument("--spec", action="store_true", help="time the SPEC list (loader / consumer wave specialisation)")
+    ap.add_argument("--ts", action="store_true", help="time the TS list (tap-sharing conv kernel) on the k = 3 shapes")
     a = ap.parse_args()
     global CONFIGS
+    if a.ts:
+        CONFIGS = TS
     if a.spec:
         CONFIGS = SPEC
     if a.ablate:
@@ -89,6 +94,8 @@ def main():
     rng = np.random.default_rng(0)
     print(f"# prec={a.prec}; time in us (best config marked *)")
     for name, M, N, K, taps, geglu, res, outk in (stride_shapes() if a.strides else shapes()):
+        if a.ts and taps != 3:
+            continue
         Cin = K // taps
         Tt = M // 32 if M >= 32 * 8 else 1
         Bb = M // Tt

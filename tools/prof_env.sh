@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel trace + stats of the bench command under an environment switch: bash tools/prof_env.sh TAG VAR=value ...
 # -> gpurun_out/<TAG>_kernel_stats.csv (in-situ kernel durations)
+export NS2VC_DEBUG_ENV=1   # the plan switches (NS2VC_FUSE_*, NS2VC_CONV_TS, ...) are only read under this (r5)
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
