@@ -332,7 +332,10 @@ int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
 int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev); /* [N] fp32: sum_k round_to_operand(rows[n][k]) */
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
 int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream); /* test tool: leave `pattern` in every CU's LDS (first lds_bytes) and in vector registers, as a foreign kernel would */
-int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile: stages 2..4 = 4-wave kernel ring depth, 12|13 = 8-wave K-split kernel ring 2|3; 0,0,0 = heuristic; (-1,0,0) = heuristic without the loader/consumer tiles, (-2,0,0) = with them again */
+/* ABI v6 (diagnostic): where the 256-thread blocks of an n_blocks launch on `stream` ran: out_host[2 i] = XCC id (HW_REG_XCC_ID),
+ * out_host[2 i + 1] = HW_REG_HW_ID of block i; `spin` > 0 keeps blocks resident for a while so the grid spreads over the CUs the stream may use. */
+int ns2vc_debug_placement(void* stream, int n_blocks, int spin, uint32_t* out_host);
+int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages); /* force the GEMM tile: stages 2..4 = 4-wave kernel ring depth, 12|13 = 8-wave K-split kernel ring 2|3; 0,0,0 = heuristic; (-1,0,0) = heuristic without the loader/consumer tiles, (-2,0,0) = with them again; ABI v6: (128, 64|128, 54|58) = the tap-sharing conv kernel with 4|8 loader waves (k = 3 launches only), (-3,0,0) = never that kernel, (-4,0,nl) = heuristic with it again, nl loader waves (0 = default) */
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream);
 /* GroupNorm (+ optional resnet time scale/shift, + optional SiLU) of a (possibly concatenated) fp32 tensor,
  * written as an operand tensor [B*T][c0+c1]; raw_op (optional) receives the un-normalised concat. Synchronous. */

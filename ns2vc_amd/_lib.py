@@ -161,6 +161,7 @@ PROTOTYPES = {
     "ns2vc_weight_rowsum": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),
+    "ns2vc_debug_placement": (_I, [_P, _I, _I, C.POINTER(C.c_uint32)]),
     "ns2vc_debug_poison": (_I, [C.c_uint, _I, _P]),
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
     "ns2vc_pack_ffn": (_I, [_P, _P, _I, _I, _PP]),

@@ -281,6 +281,7 @@ hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, 
 hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0,
                                 float* xe, void* xe_op, int prec, float* xbar, float* d1, float* mprev, size_t n, hipStream_t s);
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s);
+hipError_t launch_placement(unsigned* dev_out, int n_blocks, int spin, hipStream_t s);
 hipError_t launch_snapshot_u32(unsigned* src, unsigned* dst, hipStream_t s);   // *dst = atomicExch(src, 0)
 
 }  // namespace ns2vc

@@ -42,6 +42,9 @@ constexpr int TS_BM = 128;     // panel rows
 constexpr int TS_BMO = 126;    // output rows a tile owns
 constexpr int TS_ASLOT = TS_BM * TS_ROW;
 
+#ifndef NS2VC_CONS_PF
+#define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
+#endif
 template <int N> struct TsWait { static __device__ __forceinline__ void run(int n) { if (n >= N) wait_vmcnt<N>(); else TsWait<N - 1>::run(n); } };
 template <> struct TsWait<0> { static __device__ __forceinline__ void run(int) { wait_vmcnt<0>(); } };
 
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   constexpr int WSLOT = BN * TS_ROW;
   constexpr unsigned SZB = sizeof(TM);
   static_assert(BN == 64 || BN == 128, "BN");
-  static_assert(LA >= 1 && LB >= 1 && LA + LB <= 8, "pieces");
+  static_assert(LA >= 1 && LB >= 1 && 2 * LA + LB <= 12, "pieces");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const aring = smem;                                      // 3 activation chunks
   char* const wring = smem + 3 * TS_ASLOT;                       // 3 weight tiles
@@ -187,27 +190,55 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   // s-2 (or above), the activation chunk of a chunk's first step at the first step of the chunk two before it.  So the wait allows
   // exactly the pieces this thread issued during step s-1 (`ip`).
   int s = 0, aslot = 0, wslot = 0;
-  int ip = (loader && NCH > 1) ? LA : 0;
+  // pieces this thread issued: activation chunk / weight tile of the previous step (a1, w1), activation chunk of the step before (a2).
+  // (The prologue's second chunk counts as "the previous step's".)
+  int a1 = (loader && NCH > 1) ? LA : 0, w1 = 0, a2 = 0;
   for (int ch = 0; ch < NCH; ++ch) {
     const int ntau = ch < ncm ? 3 : 1;
     for (int ti = 0; ti < ntau; ++ti, ++s) {
       const int tau = ch < ncm ? ti : 1;
-      TsWait<LA + LB>::run(ip);
+      // Within a step the weight tile is issued BEFORE the activation chunk (the tile is needed two steps on, the chunk two chunks on, and
+      // four chunk pieces in front of it would cost the tile ~470 cycles of its two steps).  Step s needs the tile issued first at step
+      // s-2: what may still be in flight is the chunk issued behind it and everything of step s-1 -- unless this chunk's own rows were
+      // issued at step s-2 (runs of single-step chunks: the 1x1 segment).
+      const bool strict = ti == 0 && ch >= ncm + 2;
+      TsWait<2 * LA + LB>::run((strict ? 0 : a2) + w1 + a1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my fragment reads of the slots about to be refilled are done
       __builtin_amdgcn_s_barrier();
-      ip = 0;
-      if (ti == 0 && ch + 2 < NCH) {                             // chunk ch+2 -> the slot chunk ch-1 just left
-        issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
-        if (loader) ip += LA;
-      }
+      a2 = a1; a1 = 0; w1 = 0;
       if (s + 2 < S) {                                           // weight tile s+2 -> the slot tile s-1 just left
         issue_w(wslot == 0 ? 2 : wslot - 1);
-        if (loader) ip += LB;
+        if (loader) w1 = LB;
+      }
+      if (ti == 0 && ch + 2 < NCH) {                             // chunk ch+2 -> the slot chunk ch-1 just left
+        issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
+        if (loader) a1 = LA;
       }
       if (consumer) {
         const char* ap = aring + aslot * TS_ASLOT + (wm * WM + l31 + tau) * TS_ROW;
         const char* bp = wring + wslot * WSLOT + (wn * 64 + l31) * TS_ROW;
         const int swa = ((l31 + tau) >> 1) & 7;
+#if NS2VC_CONS_PF
+        // One consumer wave per SIMD: nothing hides an LDS round trip, and left alone the compiler issues three fragment reads, waits, and
+        // multiplies twice -- ~1100 cycles per step for 256 cycles of MFMA (r5 session 1: this kernel LOST to gemm4 in situ for that
+        // reason alone).  All fragment reads of the step first; the compiler's counted waits then release the MFMAs one k-slab at a time.
+        u32x4_t af[4][MT], bf[4][NT];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TS_ROW + coffa);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[kk][j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TS_ROW + coffb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[kk][i], bf[kk][j]);
+#else
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
@@ -221,6 +252,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
 #pragma unroll
             for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
         }
+#endif
       }
       if (++wslot == 3) wslot = 0;
     }

@@ -1823,6 +1823,17 @@ int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream) {
   if (e != hipSuccess) return fail("launch_poison: %s", hipGetErrorString(e));
   return 0;
 }
+int ns2vc_debug_placement(void* stream, int n_blocks, int spin, uint32_t* out_host) {
+  if (!out_host || n_blocks <= 0 || n_blocks > (1 << 20)) return fail("bad argument");
+  unsigned* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, (size_t)n_blocks * 2 * sizeof(unsigned)));
+  hipError_t e = launch_placement(d, n_blocks, spin, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) e = hipMemcpy(out_host, d, (size_t)n_blocks * 2 * sizeof(unsigned), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail("placement probe: %s", hipGetErrorString(e));
+  return 0;
+}
 int ns2vc_debug_set_gemm_tile(int bm, int bn, int stages) { set_forced_gemm_tile(bm, bn, stages); return 0; }
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream) {
   if (!a) return fail("null args");

@@ -618,6 +618,9 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #ifndef NS2VC_GEMM_ABLATE
 #define NS2VC_GEMM_ABLATE 0
 #endif
+#ifndef NS2VC_CONS_PF
+#define NS2VC_CONS_PF 1          // loader / consumer tiles: every fragment read of a K tile before its first MFMA (0: the compiler's order)
+#endif
 #if NS2VC_GEMM_ABLATE
 #define NS2VC_G4_FLAGS_PARAM , const int flags
 #define NS2VC_G4_FLAG(b) ((flags & (b)) != 0)
@@ -878,6 +881,31 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       const char* Bs = As + BM * TROW;
       const char* ap = As + (wm * WM + l31) * TROW;
       const char* bp = Bs + (wn * WN + l31) * TROW;
+#if NS2VC_CONS_PF && !NS2VC_GEMM_ABLATE
+      if constexpr (NC == 4) {
+        // r5: the loader / consumer tiles run ONE multiplying wave per SIMD, so nothing hides an LDS round trip: left alone the compiler
+        // issues three fragment reads, waits, multiplies twice (found in convts.hip's ISA, same shape here).  Every fragment read of the K
+        // tile first; the compiler's counted waits then release the MFMAs one k-slab at a time.  (With two multiplying waves per SIMD --
+        // the plain K-split tiles -- the same change was measured as a loss in r2.)
+        u32x4_t afa[4][MT], bfa[4][NT];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int coff = ((2 * kk + hi) ^ sw) * 16;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) afa[kk][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TROW + coff);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bfa[kk][j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TROW + coff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], afa[kk][i], bfa[kk][j]);
+        return;
+      }
+#endif
 #pragma unroll
       for (int kk = 0; kk < (NC == 8 ? 2 : 4); ++kk) {
         const int coff = ((2 * ((NC == 8 ? 2 * kg : 0) + kk) + hi) ^ sw) * 16;     // this K half's two 32-B k-slabs (4 consumer waves: all four)

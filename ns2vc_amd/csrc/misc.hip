@@ -762,6 +762,20 @@ int probe_xcd_round_robin(unsigned* map8) {   // 1 = ids 8 apart share an XCD, 0
   return ok;
 }
 
+// where the blocks of a launch on `s` run: out[2 i] = XCC id, out[2 i + 1] = HW_REG_HW_ID of block i (CU / SE / SH fields) -- for the CU-mask
+// partition experiments (tools/overlap_partition.py) and the placement tests
+__global__ void placement_kernel(unsigned* out, int spin) {
+  unsigned x, h;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(h));
+  for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(8);        // (keeps the block resident so that the grid spreads over the CUs)
+  if (threadIdx.x == 0) { out[2 * blockIdx.x] = x & 15u; out[2 * blockIdx.x + 1] = h; }
+}
+hipError_t launch_placement(unsigned* dev_out, int n_blocks, int spin, hipStream_t s) {
+  hipLaunchKernelGGL(placement_kernel, dim3(n_blocks), dim3(256), 0, s, dev_out, spin);
+  return hipGetLastError();
+}
+
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s) {
   hipLaunchKernelGGL(fill_i32_kernel, dim3(1), dim3(64), 0, s, p, v);
   return hipGetLastError();

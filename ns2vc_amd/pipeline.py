@@ -362,7 +362,7 @@ class OverlappedPipeline:
     """
 
     def __init__(self, denoiser: Denoiser, pre_fn, post_fn, solver: str = "unipc", steps: int = 20, order: int = 2,
-                 use_graph: bool = True, pre_device=None, post_device=None):
+                 use_graph: bool = True, pre_device=None, post_device=None, stage_cus=None, denoiser_cus=None):
         """``pre_device`` / ``post_device`` (r4): run the front / back end on ANOTHER ROCm device of the node.  On one GPU the three streams
         serialise (the denoiser's launches hold every CU: 7.8 % of the stages' kernel time overlaps, profiles/r03_overlap_trace.txt); a stage
         on its own device overlaps by construction and only its tensors cross xGMI -- content + prompt 35 MB per 32 x 10 s batch in, the
@@ -384,6 +384,20 @@ class OverlappedPipeline:
         self.s_pre = torch.cuda.Stream(self.pre_device)
         self.s_den = torch.cuda.Stream(dev)
         self.s_post = torch.cuda.Stream(self.post_device)
+        # r5: a CU partition of ONE device (hipExtStreamCreateWithCUMask through the C ABI, wrapped as torch external streams): the two
+        # PyTorch stages on `stage_cus`, the denoiser on `denoiser_cus` (iterables of CU indices; None = the whole chip).  Measured in
+        # tools/overlap_partition.py / profiles/r05_overlap_partition.txt.
+        self._masked = []
+        if stage_cus is not None or denoiser_cus is not None:
+            from .engine import Stream as _EStream
+            if stage_cus is not None and self.pre_device == dev and self.post_device == dev:
+                a, b = _EStream(cu_mask=stage_cus), _EStream(cu_mask=stage_cus)
+                self._masked += [a, b]
+                self.s_pre, self.s_post = torch.cuda.ExternalStream(a.ptr, device=dev), torch.cuda.ExternalStream(b.ptr, device=dev)
+            if denoiser_cus is not None:
+                c = _EStream(cu_mask=denoiser_cus)
+                self._masked.append(c)
+                self.s_den = torch.cuda.ExternalStream(c.ptr, device=dev)
 
     def _launch_pre(self, item):
         import torch
