@@ -66,9 +66,11 @@ int ns2vc_device_name(char* buf, int buflen);
 /* ABI v5.  1 when workgroup ids that differ by a multiple of 8 run on one XCD of the current device (the dispatcher's round robin;
  * probed once per device with HW_REG_XCC_ID), 0 when they do not, -1 when the probe could not run.  ns2vc_gemm_args.gnp_sync -- rows
  * exchanged between such workgroups through the L2 they share -- is only FAST where this is 1; the engine's `gn_coop` option
- * defaults to it and cannot be switched on elsewhere.  ABI v6: correctness no longer rests on the probe -- every workgroup of the
- * cooperative prologue compares HW_REG_XCC_ID with the XCD its slot stands for and builds all its rows itself on a mismatch
- * (a CU-masked stream, another partition mode), counted in ns2vc_unet_gn_coop_alone. */
+ * defaults to it and cannot be switched on elsewhere.  ABI v6: correctness no longer rests on the probe -- the siblings of a row block
+ * count their arrivals per XCC id (HW_REG_XCC_ID) and only trust each other's rows when all of them ran on one XCD; otherwise every
+ * workgroup builds all its rows itself (a CU-masked stream, another partition mode), counted in ns2vc_unet_gn_coop_alone.  (The
+ * dispatcher's round robin does not start at XCD 0 for every launch -- profiles/r05_placement_probe.txt -- so there is no fixed
+ * "XCD of workgroup id i" to rely on, only "ids 8 apart share one".) */
 int ns2vc_device_xcd_round_robin(int* out);
 
 /* ---- engine lifetime (replaces UNet1DConditionModel.__init__, unet_1d_condition.py:151-607) */
@@ -227,13 +229,13 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   const long long* gnp_stats; const float* gnp_gamma; const float* gnp_beta;
   const float* gnp_temb; int32_t gnp_ldtemb;
   float gnp_eps; int32_t gnp_G, gnp_silu;
-  /* ABI v5, optional: [ceil(M / 64)] 64-bit arrival counts (8-byte aligned), owned by this call site; every count must be a multiple of
-   * the number of column tiles when a launch starts (zero is: a complete launch adds exactly that number to the count of each row block
-   * it has -- the engine zeroes them at the start of every forward all the same, so that a launch that was cut short cannot hand a
-   * remainder to the next one).  With it (and more than one column tile) the column tiles of a row block -- neighbours on one XCD --
-   * build a share of the block's rows each and wait for the others' (bounded: a workgroup that waits in vain, or finds itself on
-   * another XCD than its slot stands for, builds every row itself), instead of each building all of them.  Same values either way.
-   * Needs a0 128-byte aligned and whole 128-byte lines per row (lda0 * operand size % 128 == 0). */
+  /* ABI v5 / v6, optional: [ceil(M / 64)] 64-bit arrival words (8-byte aligned), owned by this call site and ZERO when a launch starts (the
+   * engine keeps them in the statistics pool, cleared at the start of every forward).  With them (and 2 .. 15 column tiles) the column tiles
+   * of a row block -- dispatched as neighbours on one XCD -- build a share of the block's rows each and wait for the others' (bounded),
+   * instead of each building all of them.  Same values either way.  ABI v6: the placement is checked, not assumed -- an arrival adds 1 to
+   * bits 0-15 and 1 to the 4-bit count of ITS XCC id (bits 16 + 4 * HW_REG_XCC_ID ..), and a workgroup uses its siblings' rows only when
+   * all arrivals it sees carry its own XCC id; otherwise (and when it waits in vain) it builds every row itself (gnp_alone).  Bit 62 set:
+   * "do not wait" (tests).  Needs a0 128-byte aligned and whole 128-byte lines per row (lda0 * operand size % 128 == 0). */
   unsigned* gnp_sync;
   unsigned* gnp_alone;            /* optional: += 1 per workgroup that waited in vain and built every row itself */
   /* ABI v5, optional: the normalised input is the channel concat of TWO tensors (resnet.py:591 on torch.cat([h, skip]) in the up

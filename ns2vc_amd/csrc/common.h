@@ -263,8 +263,6 @@ void set_forced_rowchain_tokens(int nt);        // test hook: 0 = heuristic, 1 =
 hipError_t launch_emb_from_table(const float* table, const int* step_ptr, const float* aug, float* emb, void* emb_act_op, int prec, int B,
                                  int edim, hipStream_t s);
 int probe_xcd_round_robin(unsigned* map8 = nullptr);
-hipError_t set_gnp_xcc_map_gemm(const unsigned* map8);       // gemm.hip / convts.hip: the XCC id each workgroup slot (id mod 8) stands for, as probed
-hipError_t set_gnp_xcc_map_convts(const unsigned* map8);
 //                                             // misc.hip: 1 = workgroup ids 8 apart share an XCD (what gnp_sync relies on), 0 = not, -1 = probe failed
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s, int* counter = nullptr);                                  // bytes: any; p 16-byte aligned
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);           // bytes % 16 == 0

@@ -34,6 +34,7 @@
 #include "common.h"
 #include "mma.h"
 #include "gnpro.h"
+#include <type_traits>
 
 namespace ns2vc {
 
@@ -42,6 +43,26 @@ constexpr int TS_BM = 128;     // panel rows
 constexpr int TS_BMO = 126;    // output rows a tile owns
 constexpr int TS_ASLOT = TS_BM * TS_ROW;
 
+// optional per-workgroup phase timing (s_memtime; compiled in only with -DNS2VC_GEMM_TRACE=1, `make TRACE=1`; tools/ts_trace.py):
+// [block][16] u64: 0 entry, 1 loop begin, 2 loop end, 3 exit | loader wave 0: 4 sum of counted waits, 5 sum of barrier waits, 6 sum of issue
+// time | first consumer wave: 8 sum of barrier waits (incl. its own LDS drain), 9 sum of read + MFMA time
+__device__ unsigned long long* g_ts_trace = nullptr;
+void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ts_trace), &p, sizeof(p)); }
+#ifndef NS2VC_GEMM_TRACE
+#define NS2VC_GEMM_TRACE 0
+#endif
+#if NS2VC_GEMM_TRACE
+#define TS_NOW() __builtin_readcyclecounter()
+#define TS_STAMP(i) do { if (tr && (tid == 0)) tr[i] = TS_NOW(); } while (0)
+#define TS_CLK(t) do { t = TS_NOW(); } while (0)
+#define TS_ACC(a, t) do { const unsigned long long n_ = TS_NOW(); a += n_ - t; t = n_; } while (0)
+#define TS_PUT(i, v) do { if (tr && (lane == 0) && (wave == 0 || wave == NL)) tr[i] = (v); } while (0)
+#else
+#define TS_STAMP(i) do { (void)tr; } while (0)
+#define TS_CLK(t) do {} while (0)
+#define TS_ACC(a, t) do {} while (0)
+#define TS_PUT(i, v) do {} while (0)
+#endif
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
@@ -73,6 +94,8 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   const int cw = consumer ? wave - NL : 0;                       // consumer wave: its wave tile
   const int wm = cw / WGN, wn = cw % WGN;
   const unsigned lds0 = (unsigned)(size_t)smem;
+  unsigned long long* const tr = (NS2VC_GEMM_TRACE && g_ts_trace) ? g_ts_trace + (size_t)blockIdx.x * 16 : nullptr;
+  TS_STAMP(0);
 
   // ---- tile in the padded row space
   const int T = g.Tin, P = T + 1, MP = g.B * P;
@@ -186,78 +209,95 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
 
   const int l31 = lane & 31, hi = lane >> 5;
   const int swb = (l31 >> 1) & 7;
-  // ---- steps.  Invariant: at step s everything issued before step s-1 has landed -- the weight tile of step s was issued at step
-  // s-2 (or above), the activation chunk of a chunk's first step at the first step of the chunk two before it.  So the wait allows
-  // exactly the pieces this thread issued during step s-1 (`ip`).
-  int s = 0, aslot = 0, wslot = 0;
-  // pieces this thread issued: activation chunk / weight tile of the previous step (a1, w1), activation chunk of the step before (a2).
-  // (The prologue's second chunk counts as "the previous step's".)
-  int a1 = (loader && NCH > 1) ? LA : 0, w1 = 0, a2 = 0;
-  for (int ch = 0; ch < NCH; ++ch) {
-    const int ntau = ch < ncm ? 3 : 1;
-    for (int ti = 0; ti < ntau; ++ti, ++s) {
-      const int tau = ch < ncm ? ti : 1;
-      // Within a step the weight tile is issued BEFORE the activation chunk (the tile is needed two steps on, the chunk two chunks on, and
-      // four chunk pieces in front of it would cost the tile ~470 cycles of its two steps).  Step s needs the tile issued first at step
-      // s-2: what may still be in flight is the chunk issued behind it and everything of step s-1 -- unless this chunk's own rows were
-      // issued at step s-2 (runs of single-step chunks: the 1x1 segment).
-      const bool strict = ti == 0 && ch >= ncm + 2;
-      TsWait<2 * LA + LB>::run((strict ? 0 : a2) + w1 + a1);
+  TS_STAMP(1);
+  // ---- steps.  The two roles run their own lean loops (r5 session 2: one shared loop made every wave walk the issue cursors, the
+  // source branches and the counted-wait chain -- some 250 mostly scalar instructions and two dozen branches per step -- in front of
+  // 256 cycles of MFMA); they meet at one s_barrier per step.
+  if (consumer) {
+    const char* const arow = aring + (wm * WM + l31) * TS_ROW;
+    const char* const brow = wring + (wn * 64 + l31) * TS_ROW;
+    unsigned long long t_bar = 0, t_mma = 0, t0 = 0;
+    (void)t_bar; (void)t_mma; (void)t0;
+    auto step = [&](auto TAU, int aoff, int woff) __attribute__((always_inline)) {
+      constexpr int tau = decltype(TAU)::value;
+      const int swa = ((l31 + tau) >> 1) & 7;
+      const char* ap = arow + aoff + tau * TS_ROW;
+      const char* bp = brow + woff;
+      TS_CLK(t0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my fragment reads of the slots about to be refilled are done
       __builtin_amdgcn_s_barrier();
-      a2 = a1; a1 = 0; w1 = 0;
-      if (s + 2 < S) {                                           // weight tile s+2 -> the slot tile s-1 just left
-        issue_w(wslot == 0 ? 2 : wslot - 1);
-        if (loader) w1 = LB;
+      TS_ACC(t_bar, t0);
+      // every fragment read of the step first (one consumer wave per SIMD: nothing else hides the LDS round trip); the compiler's
+      // counted waits then release the MFMAs one k-slab at a time
+      u32x4_t af[4][MT], bf[4][NT];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TS_ROW + coffa);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bf[kk][j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TS_ROW + coffb);
       }
-      if (ti == 0 && ch + 2 < NCH) {                             // chunk ch+2 -> the slot chunk ch-1 just left
-        issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
-        if (loader) a1 = LA;
-      }
-      if (consumer) {
-        const char* ap = aring + aslot * TS_ASLOT + (wm * WM + l31 + tau) * TS_ROW;
-        const char* bp = wring + wslot * WSLOT + (wn * 64 + l31) * TS_ROW;
-        const int swa = ((l31 + tau) >> 1) & 7;
 #if NS2VC_CONS_PF
-        // One consumer wave per SIMD: nothing hides an LDS round trip, and left alone the compiler issues three fragment reads, waits, and
-        // multiplies twice -- ~1100 cycles per step for 256 cycles of MFMA (r5 session 1: this kernel LOST to gemm4 in situ for that
-        // reason alone).  All fragment reads of the step first; the compiler's counted waits then release the MFMAs one k-slab at a time.
-        u32x4_t af[4][MT], bf[4][NT];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
-#pragma unroll
-          for (int i = 0; i < MT; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TS_ROW + coffa);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bf[kk][j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TS_ROW + coffb);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[kk][i], bf[kk][j]);
-#else
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
-          u32x4_t af[MT], bf[NT];
-#pragma unroll
-          for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TS_ROW + coffa);
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const u32x4_t*>(bp + j * 32 * TS_ROW + coffb);
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[i], bf[j]);
-        }
+      __builtin_amdgcn_sched_barrier(0);
 #endif
-      }
-      if (++wslot == 3) wslot = 0;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) MmaT<TM>::mma(acc[i][j], af[kk][i], bf[kk][j]);
+      TS_ACC(t_mma, t0);
+    };
+    int aoff = 0, woff = 0;
+    auto nextw = [&]() __attribute__((always_inline)) { woff = woff == 2 * WSLOT ? 0 : woff + WSLOT; };
+    for (int ch = 0; ch < ncm; ++ch) {
+      step(std::integral_constant<int, 0>{}, aoff, woff); nextw();
+      step(std::integral_constant<int, 1>{}, aoff, woff); nextw();
+      step(std::integral_constant<int, 2>{}, aoff, woff); nextw();
+      aoff = aoff == 2 * TS_ASLOT ? 0 : aoff + TS_ASLOT;
     }
-    if (++aslot == 3) aslot = 0;
+    for (int ch = 0; ch < ncs; ++ch) {
+      step(std::integral_constant<int, 1>{}, aoff, woff); nextw();
+      aoff = aoff == 2 * TS_ASLOT ? 0 : aoff + TS_ASLOT;
+    }
+    TS_PUT(8, t_bar); TS_PUT(9, t_mma);
+  } else {
+    // Invariant: at step s everything issued before the weight tile of step s (issued FIRST at step s-2) has landed.  Within a step the
+    // weight tile goes before the activation chunk (the tile is needed two steps on, the chunk two chunks on, and four chunk pieces in
+    // front of it would cost the tile ~470 cycles of its two steps).  So what may still be in flight at step s is the chunk issued behind
+    // that tile (a2) and everything of step s-1 (w1, a1) -- unless this chunk's own rows were issued at step s-2 (runs of single-step
+    // chunks: the 1x1 segment).  (The prologue's second chunk counts as "the previous step's".)
+    int s = 0, aslot = 0, wslot = 0;
+    int a1 = NCH > 1 ? LA : 0, w1 = 0, a2 = 0;
+    unsigned long long t_wait = 0, t_bar = 0, t_iss = 0, t0 = 0;
+    (void)t_wait; (void)t_bar; (void)t_iss; (void)t0;
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int ntau = ch < ncm ? 3 : 1;
+      for (int ti = 0; ti < ntau; ++ti, ++s) {
+        const bool strict = ti == 0 && ch >= ncm + 2;
+        TS_CLK(t0);
+        TsWait<2 * LA + LB>::run((strict ? 0 : a2) + w1 + a1);
+        TS_ACC(t_wait, t0);
+        __builtin_amdgcn_s_barrier();
+        TS_ACC(t_bar, t0);
+        a2 = a1; a1 = 0; w1 = 0;
+        if (s + 2 < S) {                                         // weight tile s+2 -> the slot tile s-1 just left
+          issue_w(wslot == 0 ? 2 : wslot - 1);
+          w1 = LB;
+        }
+        if (ti == 0 && ch + 2 < NCH) {                           // chunk ch+2 -> the slot chunk ch-1 just left
+          issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
+          a1 = LA;
+        }
+        TS_ACC(t_iss, t0);
+        if (++wslot == 3) wslot = 0;
+      }
+      if (++aslot == 3) aslot = 0;
+    }
+    TS_PUT(4, t_wait); TS_PUT(5, t_bar); TS_PUT(6, t_iss);
   }
+  TS_STAMP(2);
 
   if (ewave < 0) return;                                         // loaders beyond the epilogue's eight waves (s_barrier counts live waves only)
   // ---- epilogue: per 32-row slab the four consumer waves stage their 32 x 64 tile in LDS (re-using the rings), then each of the
@@ -346,12 +386,15 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       }
     }
   }
+#if NS2VC_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (only so that the last stamp includes the store drain)
+  if (tr && wave == EOFF && lane == 0) tr[3] = TS_NOW();
+#endif
 }
 
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-hipError_t set_gnp_xcc_map_convts(const unsigned* map8) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gnp_xcc_of_slot), map8, 8 * sizeof(unsigned)); }
 
 static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)3 * bn * TS_ROW; }
 

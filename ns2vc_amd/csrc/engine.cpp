@@ -28,6 +28,7 @@ hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n
 int rowchain_slice_blocks(int n2, int slices);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
 void set_rc_trace(unsigned long long* p);
+void set_ts_trace(unsigned long long* p);
 void set_attn_optimistic(int on);
 }
 
@@ -1279,10 +1280,7 @@ static int xcd_round_robin_of_current_device() {
   std::lock_guard<std::mutex> lock(mu);
   auto it = seen.find(dev);
   if (it != seen.end()) return it->second;
-  unsigned map8[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-  int r = probe_xcd_round_robin(map8);
-  // the cooperative prologue compares HW_REG_XCC_ID with this table in every workgroup (gnpro.h): a consistent permutation keeps the fast path
-  if (r == 1 && (set_gnp_xcc_map_gemm(map8) != hipSuccess || set_gnp_xcc_map_convts(map8) != hipSuccess)) r = -1;
+  const int r = probe_xcd_round_robin();
   seen[dev] = r;
   return r;
 }
@@ -1813,6 +1811,7 @@ int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) {
   set_gemm_trace((unsigned long long*)dev_u64_blocks_x8);
   set_ffn_trace((unsigned long long*)dev_u64_blocks_x8);
   set_rc_trace((unsigned long long*)dev_u64_blocks_x8);
+  set_ts_trace((unsigned long long*)dev_u64_blocks_x8);     // (convts.hip writes 16 words per block)
   return 0;
 }
 int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream) {

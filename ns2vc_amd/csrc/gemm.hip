@@ -977,7 +977,6 @@ static hipError_t launch_cfg(const GemmArgs& g, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t set_gnp_xcc_map_gemm(const unsigned* map8) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gnp_xcc_of_slot), map8, 8 * sizeof(unsigned)); }
 void set_gemm_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &p, sizeof(p)); }
 
 static constexpr size_t gemm4_lds_bytes(int bm, int bn, int stages) {
@@ -1074,8 +1073,10 @@ static hipError_t launch_typed(const GemmArgs& g, hipStream_t s) {
   return gemm_invalid(__LINE__);
 }
 
-hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& g_, int prec, hipStream_t s) {
+  GemmArgs g = g_;
   if (g.N % 64 != 0 || g.M <= 0) return gemm_invalid(__LINE__);
+  if (g.N / 64 > 15) g.gnp_sync = nullptr;          // the arrival word counts the sharers of a row block per XCC in 4 bits (gnpro.h)
   const int bke = prec == PREC_F32 ? 32 : 64;
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return gemm_invalid(__LINE__);
   if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return gemm_invalid(__LINE__);

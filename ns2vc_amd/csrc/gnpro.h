@@ -22,10 +22,6 @@ namespace ns2vc {
 #ifndef NS2VC_GNP_WT
 #define NS2VC_GNP_WT 1
 #endif
-// XCC id (HW_REG_XCC_ID) of the XCD that workgroup ids equal to i mod 8 run on, as the placement probe of this device saw it (misc.hip
-// probe_xcd_round_robin; identity until then).  One copy per translation unit that carries the prologue (no relocatable device code in
-// this build), each with its setter: set_gnp_xcc_map_gemm / set_gnp_xcc_map_convts.
-static __device__ unsigned g_gnp_xcc_of_slot[8] = {0, 1, 2, 3, 4, 5, 6, 7};
 // In two halves: `begin` issues EVERY load of the prologue -- the first batch of fp32 rows, the int64 statistics of the (item, group)
 // pairs this tile touches, gamma / beta and the time scale / shift rows --, `finish` does the arithmetic and the stores.  (They run back to
 // back: hoisting `begin` above the kernel's row-offset set-up was measured and lost, see NS2VC_GNP_SPLIT.)
@@ -39,7 +35,6 @@ template <typename TM, int XB_> struct GnPrologue {
   static constexpr int XB = XB_;                                            // rows in flight per thread (1: no gain in the loop, 6: -1 %); more only where the tile is alone on its CU anyway
   static constexpr int OFF_BSUM = 256, OFF_OK = 3584;                       // table area (the ring stage nobody has been issued into yet): (mean, rstd) pairs | block sums | flag
   int rlo, rhi, olo, ohi, lim, rln, b_lo, nbi, rl, c, cq, gg, Cg, nshare_, cur;
-  unsigned xcc_expect;                                                      // XCC id my workgroup slot stands for (loaded early: a scalar load on nobody's critical path)
   unsigned long long* cnt_;
   bool active;
   float4 ga, be, t1, t2, xb[XB];                                            // t1 / t2: the time (scale | shift) quad of item `cur`
@@ -115,7 +110,6 @@ template <typename TM, int XB_> struct GnPrologue {
     // cooperative form (gnp_sync): the nshare workgroups that share these rows (the column tiles of one row block, neighbours on one
     // XCD) build a contiguous share each; [olo, ohi) is mine
     nshare_ = nshare;
-    xcc_expect = g_gnp_xcc_of_slot[blockIdx.x & 7];
     cnt_ = nshare > 1 ? reinterpret_cast<unsigned long long*>(g.gnp_sync) + blk : nullptr;
     const int per = (rhi - rlo + nshare - 1) / nshare;
     olo = min(rlo + share * per, rhi); ohi = min(olo + per, rhi);
@@ -203,38 +197,44 @@ template <typename TM, int XB_> struct GnPrologue {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my rows are in L2 ...
     __syncthreads();                                        // ... and so are everybody else's: the DMA may read them
     if (nshare_ > 1) {
-      // Cooperative form: publish my share, wait (bounded) for the others'.  One 64-bit arrival count per row block; the value my arrival
-      // finds tells which multiple of nshare completes THIS launch, so a count that starts as a multiple of nshare needs no reset between
-      // launches -- the engine nevertheless zeroes every count at the start of each forward (they live in the statistics pool, one clear
-      // launch), so that a launch that was cut short cannot leave a remainder behind for the next forward.  A sibling that does not show up
-      // in time (not resident yet: nothing guarantees co-scheduling) costs a repeat of the whole range by this workgroup; the values are
-      // the same whoever writes them, so the result does not depend on which way it went.
+      // Cooperative form: publish my share, wait (bounded) for the others'.  One 64-bit arrival word per row block, ZERO when the launch
+      // starts (the engine carves the words from the statistics pool, so the one clear launch of every forward zeroes them; a word is used by
+      // one launch per forward).  A sibling that does not show up in time (not resident yet: nothing guarantees co-scheduling) costs a repeat
+      // of the whole range by this workgroup; the values are the same whoever writes them, so the result does not depend on which way it went.
       int* const okf = reinterpret_cast<int*>(smem + OFF_OK);
       if (tid == 0) {
         // The siblings exchange rows through ONE XCD's L2 (the cooperative tile order puts workgroup ids that are equal mod 8 side by
         // side, and the dispatcher deals ids round robin over the XCDs): the rows were written through and acknowledged (vmcnt(0)
         // above), and the count is only ever touched by read-modify-writes, which execute in that L2.  (Agent-scope fences / atomics
         // would be correct under any placement, but on this multi-XCD part they cost an L2 write-back and a trip to the memory side per
-        // workgroup: measured, the prologue got slower than the redundant form.)  r5: that placement is CHECKED here, per workgroup and
-        // launch, not assumed: a workgroup that does not run on the XCD its slot stands for (a CU-masked stream, another partition
-        // mode, a dispatcher that deals differently) neither trusts its siblings' rows nor touches their count -- it builds every row
-        // it reads itself, and so do the siblings it leaves waiting, after their bounded wait.
+        // workgroup: measured, the prologue got slower than the redundant form.)
+        // r5: that placement is CHECKED, per row block and launch, not assumed.  The dispatcher's round robin does NOT start at XCD 0 for
+        // every launch (measured, profiles/r05_placement_probe.txt: the first launch of a process deals id i to XCD i % 8, later ones
+        // start at XCD 7), so there is no absolute "XCD of slot i" to compare with; what matters is that the siblings share an XCD.  Every
+        // arrival therefore also counts itself in the nibble of ITS XCC id (HW_REG_XCC_ID) inside the same 64-bit word:
+        //   bits 0-15 arrivals | bits 16-47 eight 4-bit per-XCC arrival counts | bit 62 "do not wait" (tests)
+        // and a workgroup trusts its siblings' rows only when all nshare arrivals it can see carry its own XCC id.  A sibling that runs
+        // elsewhere (a CU-masked stream, another partition mode, a dispatcher that deals differently) works on its own L2's copy of the
+        // word: nobody ever sees nshare arrivals, everybody builds all its rows itself after the bounded wait.  The engine zeroes the
+        // words at the start of every forward (they live in the statistics pool), so whatever such a launch leaves behind is gone
+        // before the word's next use; a word that does not start at zero (> nshare arrivals, foreign nibbles) is never trusted.
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const bool placed = (xcc & 15u) == xcc_expect;
-        int ok = 0;
-        if (placed) {
-          unsigned long long old, v, one = 1ull, zero = 0ull;
-          asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(cnt_), "v"(one) : "memory");
-          const unsigned long long target = (old / (unsigned)nshare_ + 1ull) * (unsigned)nshare_;
-          ok = old + 1ull == target;
-          const int spins = (old >> 62) ? 0 : NS2VC_GNP_SPIN;                  // (a count with bit 62 set: "do not wait" -- how the tests reach the path below)
-          if (old >> 62) ok = 0;
-          for (int it = 0; !ok && it < spins; ++it) {
-            asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(cnt_), "v"(zero) : "memory");
-            ok = v >= target;
-            if (!ok) __builtin_amdgcn_s_sleep(2);
-          }
+        xcc &= 7u;
+        const unsigned long long inc = 1ull | (1ull << (16 + 4 * xcc));
+        const unsigned long long want = (unsigned long long)(unsigned)nshare_ | ((unsigned long long)(unsigned)nshare_ << (16 + 4 * xcc));
+        unsigned long long old, v, zero = 0ull;
+        asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(old) : "v"(cnt_), "v"(inc) : "memory");
+        v = old + inc;
+        int ok = v == want;
+        const unsigned long long mine = 0xffffull | (0xfull << (16 + 4 * xcc));
+        // test flag / a word that did not start at zero / arrivals from another XCC: nothing to wait for
+        bool hopeless = (old >> 62) != 0 || (v & 0xffffull) > (unsigned)nshare_ || (v & ~mine) != 0;
+        for (int it = 0; !ok && !hopeless && it < NS2VC_GNP_SPIN; ++it) {
+          asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(cnt_), "v"(zero) : "memory");
+          ok = v == want;
+          hopeless = (v & 0xffffull) > (unsigned)nshare_ || (v & ~mine) != 0;
+          if (!ok && !hopeless) __builtin_amdgcn_s_sleep(2);
         }
         okf[0] = ok;
       }

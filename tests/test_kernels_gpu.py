@@ -314,9 +314,8 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         d_w, d_bias = _pack(W, prec), _dev(bias)
         t_ptr = (d_t.ptr + 4 * toff) if temb_on else None
         outs, ops = [], []
-        # 2: the cooperative form (gnp_sync: the column tiles of a row block build a share of its rows each), twice on the same arrival
-        # counts (they only grow); 3: counts with bit 62 set = "do not wait" -- every workgroup takes the path of one that waited in
-        # vain for a sibling and builds all its rows itself
+        # 2: the cooperative form (gnp_sync: the column tiles of a row block build a share of its rows each), twice; 3: arrival words with bit 62
+        # set = "do not wait" -- every workgroup takes the path of one that waited in vain for a sibling and builds all its rows itself
         nsync = (M + 63) // 64
         d_sync = DevBuf.from_numpy(np.zeros(nsync, dtype=np.uint64))
         d_poison = DevBuf.from_numpy(np.full(nsync, 1 << 62, dtype=np.uint64))
@@ -334,6 +333,8 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
             if fused:
                 g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_st.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
                 g.gnp_temb = t_ptr; g.gnp_ldtemb = ldt; g.gnp_eps = 1e-5; g.gnp_G = Gn; g.gnp_silu = silu
+                if fused == 2:
+                    d_sync.upload(np.zeros(nsync, dtype=np.uint64))          # (the arrival words start every launch at zero: the engine's per-forward clear)
                 g.gnp_sync = d_sync.ptr if fused == 2 else (d_poison.ptr if fused == 3 else None)
                 g.gnp_alone = d_alone.ptr + 4 * (fused == 3)
             else:
@@ -366,8 +367,11 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
         ts = taps == 3 and (tile == (0, 0, 0) or tile[2] in TS_STAGES)
         nshare = N // (tile[1] if tile[2] in TS_STAGES else 64) if ts else N // 128
         assert alone[0] == 0 and (alone[1] > 0) == (nshare > 1), f"workgroups that waited in vain: {alone}"
-        per = 2 * nshare if nshare > 1 else 0
-        assert np.isin(counts, (0, per)).all() and counts[0] == per, "every cooperative launch adds one arrival per column tile to a row block's count"
+        per = nshare if nshare > 1 else 0
+        arrivals, nibbles = counts & np.uint64(0xffff), (counts >> np.uint64(16)) & np.uint64(0xffffffff)
+        assert np.isin(arrivals, (0, per)).all() and arrivals[0] == per, "a cooperative launch adds one arrival per column tile to a row block's word"
+        # ... each also counted in the nibble of the XCC it ran on: one nibble holds them all (the siblings shared an XCD)
+        assert all(int(n) in [per << (4 * k) for k in range(8)] for n, a in zip(nibbles, arrivals) if a), [hex(int(c)) for c in counts[:4]]
         diag(f"gemm+GroupNorm prologue tile={tile} prec={prec} B={B} T={T} C={Cc} N={N} taps={taps} temb={temb_on} silu={silu}: "
              f"rows vs fp64 {e_op:.2e}  result vs fp64 {e_out:.2e}  rows==two-launch {same_op}  result==two-launch {same_out}")
         assert np.isfinite(ops[1]).all() and np.isfinite(outs[1]).all()          # every row the tiles read was produced
@@ -419,6 +423,8 @@ def test_gemm_groupnorm_prologue_of_a_concat(tile, prec, diag):
                 g.gnp_x = d_x0.ptr; g.gnp_ldx = ld0; g.gnp_stats = d_s0.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
                 g.gnp_eps = 1e-5; g.gnp_G = Gn; g.gnp_silu = 1
                 g.gnp_x1 = d_x1.ptr; g.gnp_ldx1 = ld1; g.gnp_c1 = c1; g.gnp_stats1 = d_s1.ptr; g.gnp_raw = d_r.ptr
+                if fused == 2:
+                    d_sync.upload(np.zeros((M + 63) // 64, dtype=np.uint64))
                 g.gnp_sync = d_sync.ptr if fused == 2 else None
             else:
                 check(lib.ns2vc_k_groupnorm_stats2(d_x0.ptr, ld0, c0, d_s0.ptr, d_x1.ptr, ld1, c1, d_s1.ptr, B, T, Gn, 1e-5, d_g.ptr, d_b.ptr, None, 0, 0, 1,
@@ -454,7 +460,8 @@ def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, level,
     "gamma reads zero" failure (a packed fp32 product formed under outstanding LDS reads came back as 0.0 for lanes 48-63 of a
     few waves per launch; tools/gnp_probe.py, profiles/r04_gn_prologue_rootcause.txt): it failed 22 of 22 launches before the
     fix and must stay at zero.  The coarser levels (384 / 512 channels: 3 / 4 column tiles per row block) run the COOPERATIVE form
-    (gnp_sync) on one set of arrival counts for all eight launches: same bits, and no workgroup waits in vain for a sibling."""
+    (gnp_sync), the arrival words zeroed before every launch as the engine's per-forward clear does: same bits, and no workgroup waits in
+    vain for a sibling."""
     from ns2vc_amd._lib import GemmArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
@@ -483,6 +490,7 @@ def test_gemm_groupnorm_prologue_is_reproducible_at_the_bench_shape(prec, level,
         if fused:
             g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_st.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
             g.gnp_eps = 1e-5; g.gnp_G = 8; g.gnp_silu = 1
+            d_sync.upload(np.zeros((M + 63) // 64, dtype=np.uint64))
             g.gnp_sync = d_sync.ptr; g.gnp_alone = d_alone.ptr
         else:
             check(lib.ns2vc_k_groupnorm_stats(d_x.ptr, Cc, Cc, d_st.ptr, B, T, 8, 1e-5, d_g.ptr, d_b.ptr, None, 0, 0, 1, d_a.ptr, prec, None), "groupnorm_stats")
