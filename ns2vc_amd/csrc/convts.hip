@@ -19,7 +19,7 @@
 //   * per 64-channel chunk: ONE 16-KB activation chunk + three (BN x 128 B) weight tiles (k offset tau * Ctot + c: the packed
 //     [N][K] layout already has them, just in another order).  BN = 64: 13.3 KB per 1.05 MFLOP (gemm4: 24.5), BN = 128:
 //     21.3 KB per 2.1 MFLOP (gemm4 128 x 128: 32) -- and the 128 x 64 tile gives as many workgroups as gemm4's 64 x 128;
-//   * activation chunks and weight tiles ride separate 3-deep rings (a chunk is issued two chunks ahead, a weight tile two
+//   * activation chunks and weight tiles ride separate rings (a chunk is issued two chunks ahead, a weight tile five / four
 //     steps ahead), counted s_waitcnt vmcnt, one s_barrier per step; loader / consumer wave specialisation as in gemm4's
 //     SPEC kernels: NL loader waves issue every LDS-DMA piece, 4 consumer waves own the MFMAs;
 //   * the concat of the up blocks is a chunk walk over two descriptors, the fused 1x1 shortcut (K segment c2) a run of
@@ -44,7 +44,7 @@ constexpr int TS_BMO = 126;    // output rows a tile owns
 constexpr int TS_ASLOT = TS_BM * TS_ROW;
 
 // optional per-workgroup phase timing (s_memtime; compiled in only with -DNS2VC_GEMM_TRACE=1, `make TRACE=1`; tools/ts_trace.py):
-// [block][16] u64: 0 entry, 1 loop begin, 2 loop end, 3 exit | loader wave 0: 4 sum of counted waits, 5 sum of barrier waits, 6 sum of issue
+// [block][16] u64: 0 entry, 7 prologue done, 1 loop begin, 2 loop end, 3 exit | loader wave 0: 4 sum of counted waits, 5 sum of barrier waits, 6 sum of issue
 // time | first consumer wave: 8 sum of barrier waits (incl. its own LDS drain), 9 sum of read + MFMA time
 __device__ unsigned long long* g_ts_trace = nullptr;
 void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ts_trace), &p, sizeof(p)); }
@@ -66,8 +66,17 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
-template <int N> struct TsWait { static __device__ __forceinline__ void run(int n) { if (n >= N) wait_vmcnt<N>(); else TsWait<N - 1>::run(n); } };
-template <> struct TsWait<0> { static __device__ __forceinline__ void run(int) { wait_vmcnt<0>(); } };
+// Weight ring depth.  r5 session 4 (tools/ts_trace.py): with a tile issued two steps ahead the loader waves -- issue ~110 cycles per 1-KB piece,
+// wait for the landing, barrier, issue again -- never kept the CU's DMA queue full: 360 cycles of issue + 245 of counted waits per step
+// against 330 for the consumers' reads + MFMAs.  Five steps ahead the counted wait finds its tile long landed and the loop runs at the issue rate.
+template <int BN> struct TsRing { static constexpr int SW = BN == 64 ? 6 : 5; };
+// s_waitcnt vmcnt(n) for a wave-uniform n in [LO, HI]: the count is an immediate, so a binary tree of scalar branches picks it
+template <int LO, int HI> struct TsWait {
+  static __device__ __forceinline__ void run(int n) {
+    if constexpr (LO == HI) wait_vmcnt<LO>();
+    else { constexpr int MID = (LO + HI + 1) / 2; if (n >= MID) TsWait<MID, HI>::run(n); else TsWait<LO, MID - 1>::run(n); }
+  }
+};
 
 template <typename TM, int BN, int NL, bool GNP>
 __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g) {
@@ -79,12 +88,13 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   constexpr int LA = TS_BM / RPP, LB = BN / RPP;                 // 16-B DMA pieces per loading thread: activation chunk / weight tile
   constexpr int WGN = BN / 64, WGM = 4 / WGN, WM = TS_BM / WGM, MT = WM / 32, NT = 2;
   constexpr int WSLOT = BN * TS_ROW;
+  constexpr int SW = TsRing<BN>::SW, D = SW - 1;                 // weight ring: a tile is issued D steps ahead
   constexpr unsigned SZB = sizeof(TM);
   static_assert(BN == 64 || BN == 128, "BN");
-  static_assert(LA >= 1 && LB >= 1 && 2 * LA + LB <= 12, "pieces");
+  static_assert(LA >= 1 && LB >= 1 && D * LB + 3 * LA <= 60, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const aring = smem;                                      // 3 activation chunks
-  char* const wring = smem + 3 * TS_ASLOT;                       // 3 weight tiles
+  char* const wring = smem + 3 * TS_ASLOT;                       // SW weight tiles
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -147,10 +157,11 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     if (wc_ch < ncm && wc_tau < 2) ++wc_tau;
     else { ++wc_ch; wc_tau = wc_ch < ncm ? 0 : 1; }
   };
-  // the first two weight tiles depend on nothing but the tile's column: in flight while the row offsets (a division per piece) and
+  // the first D weight tiles depend on nothing but the tile's column: in flight while the row offsets (a division per piece) and
   // the GroupNorm prologue are still being worked out
-  if (S > 0) issue_w(0);
-  if (S > 1) issue_w(1);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < S) issue_w(d);
 
   unsigned off0[LA], off1[LA], off2[LA];
 #pragma unroll
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       gpro.finish(g, tid, aring);                                // (its table lives in the activation ring: nothing has been issued into it yet)
     }
   }
+  TS_STAMP(7);
   issue_a(0, 0);
   if (NCH > 1) issue_a(1, 1);
 
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       TS_ACC(t_mma, t0);
     };
     int aoff = 0, woff = 0;
-    auto nextw = [&]() __attribute__((always_inline)) { woff = woff == 2 * WSLOT ? 0 : woff + WSLOT; };
+    auto nextw = [&]() __attribute__((always_inline)) { woff = woff == (SW - 1) * WSLOT ? 0 : woff + WSLOT; };
     for (int ch = 0; ch < ncm; ++ch) {
       step(std::integral_constant<int, 0>{}, aoff, woff); nextw();
       step(std::integral_constant<int, 1>{}, aoff, woff); nextw();
@@ -263,37 +275,55 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     }
     TS_PUT(8, t_bar); TS_PUT(9, t_mma);
   } else {
-    // Invariant: at step s everything issued before the weight tile of step s (issued FIRST at step s-2) has landed.  Within a step the
-    // weight tile goes before the activation chunk (the tile is needed two steps on, the chunk two chunks on, and four chunk pieces in
-    // front of it would cost the tile ~470 cycles of its two steps).  So what may still be in flight at step s is the chunk issued behind
-    // that tile (a2) and everything of step s-1 (w1, a1) -- unless this chunk's own rows were issued at step s-2 (runs of single-step
-    // chunks: the 1x1 segment).  (The prologue's second chunk counts as "the previous step's".)
+    // Invariant: at step s everything issued before the weight tile of step s (issued FIRST at step s-D, or above) has landed.  Within a
+    // step the weight tile goes before the activation chunk.  So what may still be in flight at step s is the chunk issued behind that
+    // tile at step s-D and everything of steps s-D+1 .. s-1: hw / ha hold the piece counts of the last D steps ([0] = step s-1).  A chunk's
+    // rows are issued at the first step of the chunk two before it (`sa`; the prologue's second chunk counts as step -1): usually further
+    // back than the tile (landed with it), but at the head of the loop and around the single-step chunks of the 1x1 segment only 4 or 2
+    // steps back -- then the wait spares only what was issued after them.
     int s = 0, aslot = 0, wslot = 0;
-    int a1 = NCH > 1 ? LA : 0, w1 = 0, a2 = 0;
+    int hw[D], ha[D];                                            // weight / activation pieces issued at step s-1-i
+#pragma unroll
+    for (int i = 0; i < D; ++i) { hw[i] = 0; ha[i] = 0; }
+    ha[0] = NCH > 1 ? LA : 0;
+    int fs_m2 = -1, fs_m1 = -1;                                  // first steps of the chunks two / one before this one (-1: the prologue)
     unsigned long long t_wait = 0, t_bar = 0, t_iss = 0, t0 = 0;
     (void)t_wait; (void)t_bar; (void)t_iss; (void)t0;
     for (int ch = 0; ch < NCH; ++ch) {
       const int ntau = ch < ncm ? 3 : 1;
+      const int fs = s;
       for (int ti = 0; ti < ntau; ++ti, ++s) {
-        const bool strict = ti == 0 && ch >= ncm + 2;
+        const int lb = (ti == 0 && ch > 0) ? s - fs_m2 : D + 1;    // steps back to the issue of this chunk's rows (if they are needed now)
+        int allow = 0;
+        if (lb <= D) {
+#pragma unroll
+          for (int i = 0; i < D - 1; ++i) allow += (i <= lb - 2) ? hw[i] + ha[i] : 0;
+        } else {
+#pragma unroll
+          for (int i = 0; i < D - 1; ++i) allow += hw[i] + ha[i];
+          allow += ha[D - 1];
+        }
         TS_CLK(t0);
-        TsWait<2 * LA + LB>::run((strict ? 0 : a2) + w1 + a1);
+        TsWait<0, D * LB + 3 * LA>::run(allow);
         TS_ACC(t_wait, t0);
         __builtin_amdgcn_s_barrier();
         TS_ACC(t_bar, t0);
-        a2 = a1; a1 = 0; w1 = 0;
-        if (s + 2 < S) {                                         // weight tile s+2 -> the slot tile s-1 just left
-          issue_w(wslot == 0 ? 2 : wslot - 1);
-          w1 = LB;
+#pragma unroll
+        for (int i = D - 1; i > 0; --i) { hw[i] = hw[i - 1]; ha[i] = ha[i - 1]; }
+        hw[0] = 0; ha[0] = 0;
+        if (s + D < S) {                                         // weight tile s+D -> the slot tile s-1 just left
+          issue_w(wslot == 0 ? SW - 1 : wslot - 1);
+          hw[0] = LB;
         }
         if (ti == 0 && ch + 2 < NCH) {                           // chunk ch+2 -> the slot chunk ch-1 just left
           issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
-          a1 = LA;
+          ha[0] = LA;
         }
         TS_ACC(t_iss, t0);
-        if (++wslot == 3) wslot = 0;
+        if (++wslot == SW) wslot = 0;
       }
       if (++aslot == 3) aslot = 0;
+      fs_m2 = fs_m1; fs_m1 = fs;
     }
     TS_PUT(4, t_wait); TS_PUT(5, t_bar); TS_PUT(6, t_iss);
   }
@@ -396,7 +426,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
 // host side
 // ---------------------------------------------------------------------------
 
-static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)3 * bn * TS_ROW; }
+static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)(bn == 64 ? TsRing<64>::SW : TsRing<128>::SW) * bn * TS_ROW; }
 
 bool convts_eligible(const GemmArgs& g, int prec) {
   const int bke = prec == PREC_F32 ? 32 : 64;
