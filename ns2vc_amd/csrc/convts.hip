@@ -19,7 +19,7 @@
 //   * per 64-channel chunk: ONE 16-KB activation chunk + three (BN x 128 B) weight tiles (k offset tau * Ctot + c: the packed
 //     [N][K] layout already has them, just in another order).  BN = 64: 13.3 KB per 1.05 MFLOP (gemm4: 24.5), BN = 128:
 //     21.3 KB per 2.1 MFLOP (gemm4 128 x 128: 32) -- and the 128 x 64 tile gives as many workgroups as gemm4's 64 x 128;
-//   * activation chunks and weight tiles ride separate rings (a chunk is issued two chunks ahead, a weight tile five / four
+//   * activation chunks and weight tiles ride separate 3-deep rings (a chunk is issued two chunks ahead, a weight tile two
 //     steps ahead), counted s_waitcnt vmcnt, one s_barrier per step; loader / consumer wave specialisation as in gemm4's
 //     SPEC kernels: NL loader waves issue every LDS-DMA piece, 4 consumer waves own the MFMAs;
 //   * the concat of the up blocks is a chunk walk over two descriptors, the fused 1x1 shortcut (K segment c2) a run of
@@ -66,10 +66,12 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
-// Weight ring depth.  r5 session 4 (tools/ts_trace.py): with a tile issued two steps ahead the loader waves -- issue ~110 cycles per 1-KB piece,
-// wait for the landing, barrier, issue again -- never kept the CU's DMA queue full: 360 cycles of issue + 245 of counted waits per step
-// against 330 for the consumers' reads + MFMAs.  Five steps ahead the counted wait finds its tile long landed and the loop runs at the issue rate.
-template <int BN> struct TsRing { static constexpr int SW = BN == 64 ? 6 : 5; };
+// Weight ring depth: a tile is issued SW - 1 steps ahead.  r5 sessions 4 / 5 (tools/ts_trace.py, profiles/r05_ts_trace.txt): five steps ahead
+// (SW = 6) changed nothing against two (3.62 ms/step either way, 790 cycles per step in the traced build) -- the loop is not waiting for
+// latency but for the LDS: DMA writes + the consumers' fragment reads move 61 KB per step (BN = 64; 85 KB at BN = 128, 72 KB per tile in
+// gemm4's loader / consumer tiles), and all three settle at 78-88 B/clk/CU.  So the ring stays as shallow as the pipeline needs
+// (72 / 96 KB: two 128 x 64 workgroups per CU); the counted-wait bookkeeping below is written for any depth.
+template <int BN> struct TsRing { static constexpr int SW = 3; };
 // s_waitcnt vmcnt(n) for a wave-uniform n in [LO, HI]: the count is an immediate, so a binary tree of scalar branches picks it
 template <int LO, int HI> struct TsWait {
   static __device__ __forceinline__ void run(int n) {

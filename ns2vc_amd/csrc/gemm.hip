@@ -618,9 +618,9 @@ __device__ __forceinline__ void gemm4_epilogue(const GemmArgs& g, f32x16_t (&acc
 #ifndef NS2VC_GEMM_ABLATE
 #define NS2VC_GEMM_ABLATE 0
 #endif
-#ifndef NS2VC_CONS_PF
-#define NS2VC_CONS_PF 1          // loader / consumer tiles: every fragment read of a K tile before its first MFMA (0: the compiler's order)
-#endif
+#ifndef NS2VC_G4_CONS_PF
+#define NS2VC_G4_CONS_PF 0       // loader / consumer tiles: every fragment read of a K tile before its first MFMA (0: the compiler's order).
+#endif                           // r5 session 2, same box: 4.054 vs 4.046 ms/step -- no gain (the tile is LDS-bandwidth-bound, not latency-bound), +19 VGPRs: off
 #if NS2VC_GEMM_ABLATE
 #define NS2VC_G4_FLAGS_PARAM , const int flags
 #define NS2VC_G4_FLAG(b) ((flags & (b)) != 0)
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(64 * G4Waves<SPEC>::NW) void gemm4_kernel(const Gem
       const char* Bs = As + BM * TROW;
       const char* ap = As + (wm * WM + l31) * TROW;
       const char* bp = Bs + (wn * WN + l31) * TROW;
-#if NS2VC_CONS_PF && !NS2VC_GEMM_ABLATE
+#if NS2VC_G4_CONS_PF && !NS2VC_GEMM_ABLATE
       if constexpr (NC == 4) {
         // r5: the loader / consumer tiles run ONE multiplying wave per SIMD, so nothing hides an LDS round trip: left alone the compiler
         // issues three fragment reads, waits, multiplies twice (found in convts.hip's ISA, same shape here).  Every fragment read of the K

@@ -53,7 +53,7 @@ for name, T, Cin, N in shapes:
         check(lib.ns2vc_k_gemm(C.byref(g), PREC, None), "gemm"); sync()
         check(lib.ns2vc_debug_set_gemm_trace(None), "trace")
         t = Tr.to_numpy((nblk, W), dtype=np.uint64).astype(np.float64)
-        t = t[t[:, 0] > 0]                                       # (padding workgroups of a cooperative grid leave no stamps)
+        t = t[t[:, (3 if ts else 6)] > 0]                         # (padding workgroups of a cooperative grid return at once)
         t0 = t[:, 0].min()
         if ts:
             steps = 3 * (Cin // 64)
