@@ -102,6 +102,9 @@ struct Op {
   int kind = 0;          // 0 other, 1 implicit GEMM, 2 attention, 3 norm statistics, 4 copy
   double flops = 0.0;    // algorithmic FLOPs (2*MAC) of this launch
   double bytes = 0.0;    // algorithmic (compulsory) HBM bytes: operands read once + result written once
+  // what the forward's one clear launch does for THIS op (zero the arrival words of a cooperative GroupNorm prologue): only
+  // ns2vc_unet_profile_forward needs it, because it repeats an op without the rest of the forward in between
+  std::function<hipError_t(hipStream_t)> rearm;
 };
 struct Tap {
   std::string name;
@@ -677,7 +680,9 @@ struct Planner {
     stats_of[tensor] = p;
     return p;
   }
-  unsigned* new_sync(size_t nblocks) {       // 64-bit arrival counts of a cooperative GroupNorm prologue, one per row block
+  unsigned* new_sync(size_t nblocks) {       // 64-bit arrival words of a cooperative GroupNorm prologue, one per row block
+    nblocks = (nblocks + 1) & ~(size_t)1;     // (whole 16-byte units, 16-byte aligned: Op::rearm zeroes them with 16-byte stores)
+    stats_used = (stats_used + 1) & ~(size_t)1;
     if (stats_used + nblocks > stats_cap) return nullptr;
     long long* p = stats_pool ? stats_pool + stats_used : reinterpret_cast<long long*>(sizeof(long long) * (stats_used + 1));
     stats_used += nblocks;
@@ -724,6 +729,11 @@ struct Planner {
     // (a GroupNorm prologue reads the fp32 rows and writes + re-reads the operand rows it builds)
     const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz * (g.gnp_raw ? 2.0 : 1.0)) : 0.0;
     add(g.gnp_x ? name + "[+norm]" : name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes + pro);
+    if (!sizing && g.gnp_x && g.gnp_sync) {
+      unsigned* words = g.gnp_sync;
+      const size_t nbytes = (((size_t)g.B * g.Tin + 63) / 64) * 8;
+      ops->back().rearm = [=](hipStream_t s) { return launch_zero(words, (nbytes + 15) & ~(size_t)15, s); };
+    }
   }
   // A = operand tensor [B*Tin][c0]; results to out_f32 and/or out_op (row stride = logical width)
   GemmArgs base(const void* a0, int lda0, int c0, int Tin, int Tout, const PackedW& w, float* out_f32, void* out_op, int ldo) {
@@ -1726,19 +1736,38 @@ int ns2vc_unet_profile_forward(ns2vc_unet* h, float* ms, int n_ms, int reps, voi
   std::vector<hipEvent_t> ev(2 * n);
   for (auto& e : ev) HIPCHK(hipEventCreate(&e));
   int rc = 0;
+  // An op with a cooperative GroupNorm prologue starts from zeroed arrival words (the forward's clear launch): repeated here, it gets
+  // its own small clear in front of every repetition, and the time of `reps` such clears alone (measured once, below) is taken off.
+  hipEvent_t rz0 = nullptr, rz1 = nullptr;
+  const Op* rz_op = nullptr;
   for (size_t i = 0; i < n && !rc; ++i) {
+    const Op& op = h->fwd_ops[i];
+    if (op.rearm && !rz_op) rz_op = &op;
     if (hipEventRecord(ev[2 * i], s) != hipSuccess) rc = fail("hipEventRecord failed");
     for (int r = 0; r < reps && !rc; ++r) {
-      hipError_t e = h->fwd_ops[i].fn(s);
-      if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", h->fwd_ops[i].name.c_str(), hipGetErrorString(e));
+      hipError_t e = op.rearm ? op.rearm(s) : hipSuccess;
+      if (e == hipSuccess) e = op.fn(s);
+      if (e != hipSuccess) rc = fail("launch of '%s' failed: %s", op.name.c_str(), hipGetErrorString(e));
     }
     if (!rc && hipEventRecord(ev[2 * i + 1], s) != hipSuccess) rc = fail("hipEventRecord failed");
   }
+  if (!rc && rz_op) {
+    if (hipEventCreate(&rz0) != hipSuccess || hipEventCreate(&rz1) != hipSuccess) rc = fail("hipEventCreate failed");
+    if (!rc) (void)hipEventRecord(rz0, s);
+    for (int r = 0; r < reps && !rc; ++r)
+      if (rz_op->rearm(s) != hipSuccess) rc = fail("clear launch failed");
+    if (!rc) (void)hipEventRecord(rz1, s);
+  }
   if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail("stream sync failed: %s", hipGetErrorString(hipGetLastError()));
+  float rz_ms = 0.f;
+  if (!rc && rz_op && hipEventElapsedTime(&rz_ms, rz0, rz1) != hipSuccess) rc = fail("hipEventElapsedTime failed");
   for (size_t i = 0; i < n && !rc; ++i) {
     if (hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) rc = fail("hipEventElapsedTime failed");
+    if (h->fwd_ops[i].rearm) ms[i] = std::max(ms[i] - rz_ms, 0.f);
     ms[i] /= (float)reps;
   }
+  if (rz0) (void)hipEventDestroy(rz0);
+  if (rz1) (void)hipEventDestroy(rz1);
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
 }

@@ -9,6 +9,7 @@
    plain streams (the r3 arrangement), and overlapped with the PyTorch stages on k CUs of every XCD and the denoiser on the rest
    (k = 2, 4, 6), plus the denoiser alone on the reduced CU set (what the partition costs it)."""
 import ctypes as C
+import functools
 import json
 import os
 import sys
@@ -33,6 +34,9 @@ PRE_CFG = {"phoneme_encoder": {"in_channels": 256, "hidden_channels": 256, "out_
            "prompt_encoder": {"in_channels": 100, "hidden_channels": 256, "out_channels": 256, "n_layers": 6, "p_dropout": 0.2}}
 
 
+print = functools.partial(print, flush=True)
+
+
 def placement(stream, n=512, spin=200):
     lib = _lib.load()
     out = (C.c_uint32 * (2 * n))()
@@ -47,7 +51,7 @@ def main():
     # ---- 1. the mask's bit order
     bit_xcc, bit_hw = [], []
     for b in range(ncu):
-        st = Stream(cu_mask=[b])
+        st = Stream(cu_mask=[b])      # (256 tiny streams: a few seconds)
         x, h = placement(st, n=16, spin=0)
         bit_xcc.append(sorted(set(x.tolist())))
         bit_hw.append(sorted(set((h & 0xffffff00).tolist())))
@@ -70,7 +74,7 @@ def main():
     torch.manual_seed(0)
     voc = VocosDecoder().eval().to(dev)
     den = Denoiser(procedural_state_dict(seed=0), precision_check=None)
-    B, T, Lp, steps, n = 32, 938, 469, 20, 6
+    B, T, Lp, steps, n = 32, 938, 469, 20, 3
     g = torch.Generator(device=dev).manual_seed(5)
     c = torch.randn((B, 256, T), device=dev, generator=g)
     refer = torch.randn((B, 100, Lp), device=dev, generator=g)
@@ -84,7 +88,7 @@ def main():
     def post_fn(latent, k):
         return voc.decode(latent)
 
-    def timed(fn, reps=2):
+    def timed(fn, reps=1):
         best = 1e9
         for _ in range(reps):
             torch.cuda.synchronize()
@@ -120,7 +124,17 @@ def main():
     s0 = torch.cuda.Stream(dev)
     rows.append(("denoiser alone, whole chip", timed(lambda: denoiser_only(s0))))
     rows.append(("front end + vocoder alone, whole chip", timed(lambda: stages_only(s0))))
-    for k in (2, 4, 6, 8):
+    for name, ms in rows:
+        print(f"{ms:9.2f}  {name}")
+    # Under a partition a cooperative grid is no longer one resident round of workgroups: siblings wait for each other in vain (bounded,
+    # ~130 us each).  So the partitioned runs use the gn_coop = 0 plan (every column tile builds its rows), the documented switch for it.
+    print("# plain runs done; partitioned runs with the gn_coop = 0 plan")
+    den.engine.set_option("gn_coop", False)
+    sequential()
+    rows.append(("sequential, one stream, gn_coop = 0 plan", timed(sequential)))
+    print(f"{rows[-1][1]:9.2f}  {rows[-1][0]}")
+    for k in (4, 8, 2):
+      try:
         stage = [b for x in range(8) for b in by_xcd[x][-k:]]
         rest = [b for b in range(ncu) if b not in set(stage)]
         sd = Stream(cu_mask=rest)
@@ -139,7 +153,11 @@ def main():
         pipe2 = OverlappedPipeline(den, pre_fn, post_fn, solver="unipc", steps=steps, stage_cus=stage)
         pipe2.run([0])
         rows.append((f"   ... stages on {len(stage)} CUs, denoiser unmasked: overlapped", timed(lambda: pipe2.run(list(range(n))))))
-    print(f"# ms per 32 x 10 s batch ({steps}-step UniPC, fp16 engine, fp32 PyTorch stages), best of 2 runs of {n} batches")
+        for name, ms in rows[-4:]:
+            print(f"{ms:9.2f}  {name}")
+      except Exception as ex:
+        print(f"# partition k={k} failed: {ex!r}")
+    print(f"# ms per 32 x 10 s batch ({steps}-step UniPC, fp16 engine, fp32 PyTorch stages), one run of {n} batches each")
     for name, ms in rows:
         print(f"{ms:9.2f}  {name}")
 
