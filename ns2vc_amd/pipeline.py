@@ -153,6 +153,13 @@ class Denoiser:
             self._ln_checked = False                # a new shape is a new set of rows: check synchronously once
             self._ln_pending = False
 
+    def set_option(self, name: str, value: bool) -> None:
+        """A plan option of the engine (``Engine.set_option``; e.g. ``gn_coop`` off for a pipeline that runs the denoiser on a CU partition).
+        The plan and the sampler table are rebuilt by the next ``sample``."""
+        self.engine.set_option(name, value)
+        self._shape = None
+        self._table_key = None
+
     def _table(self, solver: str, steps: int, order: int) -> None:
         key = (solver, steps, order)
         if self._table_key != key:

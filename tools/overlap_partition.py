@@ -48,23 +48,12 @@ def placement(stream, n=512, spin=200):
 def main():
     dev = torch.device("cuda", 0)
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    # ---- 1. the mask's bit order
-    bit_xcc, bit_hw = [], []
-    for b in range(ncu):
-        st = Stream(cu_mask=[b])      # (256 tiny streams: a few seconds)
-        x, h = placement(st, n=16, spin=0)
-        bit_xcc.append(sorted(set(x.tolist())))
-        bit_hw.append(sorted(set((h & 0xffffff00).tolist())))
-        del st
-    one_cu = all(len(v) == 1 for v in bit_xcc)
-    xcc_of_bit = [v[0] for v in bit_xcc]
-    print(f"# CU-mask bit -> XCC id (every bit lands on exactly one XCD: {one_cu}):")
-    print("#  bits 0..15:", xcc_of_bit[:16], " bits 32..47:", xcc_of_bit[32:48])
-    interleaved = all(xcc_of_bit[b] == xcc_of_bit[b % 8] for b in range(ncu))
-    print(f"#  bit b -> XCD of bit b mod 8 (interleaved enumeration): {interleaved}; CUs per XCD: {[xcc_of_bit.count(x) for x in range(8)]}")
+    # ---- 1. the mask's bit order (tools/cu_mask_probe.py, profiles/r05_cu_mask_probe.txt): bit b = CU b // 8 of XCD b % 8 -- every contiguous run of
+    # 32 bits gives each XCD four CUs; an XCD left without any enabled CU runs the stream's kernels UNMASKED, so a partition must leave
+    # every XCD some CUs on both sides.  The dispatcher keeps dealing workgroup ids round robin over all eight XCDs under any such mask.
+    by_xcd = {k: [b for b in range(ncu) if b % 8 == k] for k in range(8)}
     x, _ = placement(None, n=1024, spin=200)
-    print("#  unmasked stream, block i -> XCC:", x[:16].tolist(), " round robin:", bool(all(x[i] == x[i % 8] for i in range(1024))))
-    by_xcd = {k: [b for b in range(ncu) if xcc_of_bit[b] == k] for k in range(8)}
+    print("# unmasked stream, block i -> XCC:", x[:16].tolist(), " round robin:", bool(all(x[i] == x[i % 8] for i in range(1024))))
 
     # ---- 2. the pipeline
     keys = json.load(open(os.path.join(ROOT, "tests", "golden", "pre_model_state_keys.json")))
@@ -129,7 +118,7 @@ def main():
     # Under a partition a cooperative grid is no longer one resident round of workgroups: siblings wait for each other in vain (bounded,
     # ~130 us each).  So the partitioned runs use the gn_coop = 0 plan (every column tile builds its rows), the documented switch for it.
     print("# plain runs done; partitioned runs with the gn_coop = 0 plan")
-    den.engine.set_option("gn_coop", False)
+    den.set_option("gn_coop", False)
     sequential()
     rows.append(("sequential, one stream, gn_coop = 0 plan", timed(sequential)))
     print(f"{rows[-1][1]:9.2f}  {rows[-1][0]}")
