@@ -167,17 +167,20 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
     n1 = int(max(1, min(8, (budget_s * 0.4) / max(best[1] * B / 4, 1e-3))))
     dt, y_ref = run(B, n1, th)
     single = {"sample_steps_per_s": B * n1 / dt, "threads": th, "batch": B, "forwards": n1, "seconds": dt}
-    # ---- all cores
-    nproc = max(1, cores // th)
-    agg = None
-    if nproc > 1:
-        secs = max(4.0, budget_s * 0.35)
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(secs), "--cpu-threads", str(th), "--cpu-frames", str(T),
+    # ---- all cores: a small grid of (processes x threads), every worker pinned to its own contiguous cores (= one NUMA-local block of
+    # the socket; unpinned, 16 x 16 threads ran SLOWER than one process in rounds 1-2).  r5: the best leg is the baseline, the grid is
+    # reported (`all_cores_sweep`), so the ratio is not against a configuration nobody tried to make fast.
+    agg, sweep = None, []
+    grid = sorted({(max(1, cores // t), t) for t in (8, 16, 32, 64) if t <= cores} | {(max(1, cores // th), th)})
+    grid = [g for g in grid if g[0] > 1]
+    secs = max(4.0, budget_s * 0.7 / max(len(grid), 1))
+    for nproc, tha in grid:
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(secs), "--cpu-threads", str(tha), "--cpu-frames", str(T),
                "--prompt-frames", str(Lp)]
-        env = dict(os.environ, OMP_NUM_THREADS=str(th), MKL_NUM_THREADS=str(th), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-        # every worker is pinned to its own `th` cores (unpinned, 16 x 16 threads ran SLOWER than one process in rounds 1-2)
-        procs = [subprocess.Popen(cmd + ["--cpu-pin", f"{i * th}-{(i + 1) * th}"], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        env = dict(os.environ, OMP_NUM_THREADS=str(tha), MKL_NUM_THREADS=str(tha), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        procs = [subprocess.Popen(cmd + ["--cpu-pin", f"{i * tha}-{(i + 1) * tha}"], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
                  for i in range(nproc)]
+        leg = None
         try:
             for p in procs:
                 line = p.stdout.readline()
@@ -186,18 +189,22 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
             for p in procs:
                 p.stdin.write("go\n"); p.stdin.flush()
             outs = [json.loads(p.stdout.readline()) for p in procs]
-            agg = {"sample_steps_per_s": sum(o["samples"] / o["seconds"] for o in outs), "processes": nproc, "threads_per_process": th,
-                   "batch_per_process": 4, "seconds": secs, "pinned": "each process on its own disjoint cores (sched_setaffinity)"}
+            leg = {"sample_steps_per_s": sum(o["samples"] / o["seconds"] for o in outs), "processes": nproc, "threads_per_process": tha,
+                   "batch_per_process": 4, "seconds": secs, "pinned": "each process on its own disjoint contiguous cores (sched_setaffinity)"}
         except Exception as ex:
-            agg = {"error": repr(ex)}
+            leg = {"error": repr(ex), "processes": nproc, "threads_per_process": tha}
         finally:
             for p in procs:
                 try:
                     p.kill()
                 except Exception:
                     pass
+        sweep.append(leg)
+        if "sample_steps_per_s" in leg and (agg is None or leg["sample_steps_per_s"] > agg["sample_steps_per_s"]):
+            agg = leg
+    nproc = agg["processes"] if agg else 1
     use = agg if agg and "sample_steps_per_s" in agg and agg["sample_steps_per_s"] > single["sample_steps_per_s"] else single
-    used_cores = nproc * th if use is agg else th
+    used_cores = agg["processes"] * agg["threads_per_process"] if use is agg else th
     # ---- the sampled latent of the timed solver on the first utterances (the oracle treats utterances independently)
     samp = None
     if sampler is not None:
@@ -217,9 +224,9 @@ def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
     out = {"value": use["sample_steps_per_s"] / B, "unit": f"denoiser-steps/s (batch {B})", "cores": used_cores, "host_cores": cores, "kind": "port",
            "sample_steps_per_s": use["sample_steps_per_s"],
            "sample": (f"oracle UNet forward (torch CPU fp32) at T={T}, Lp={Lp}: " +
-                      (f"{nproc} processes x {th} threads x batch 4 for {agg['seconds']:.0f} s, samples/s summed" if use is agg else
+                      (f"{agg['processes']} processes x {agg['threads_per_process']} threads x batch 4 for {agg['seconds']:.0f} s, samples/s summed (best of the all_cores_sweep grid)" if use is agg else
                        f"one process, {th} threads, batch {B}, {n1} forwards in {dt:.1f} s")),
-           "single_process": single, "all_cores": agg}
+           "single_process": single, "all_cores": agg, "all_cores_sweep": sweep}
     return out, (x.numpy(), content.numpy(), prompt.numpy(), mask.numpy(), t_par.numpy(), y_ref.numpy()), samp
 
 
@@ -617,6 +624,7 @@ def main():
 
         # ---- the exact-fp32 precision: same job, same roofline definition (peak = 157.3 TFLOP/s fp32 MFMA)
         fp32_block = None
+        bf16_block = None
         e32 = None
         if world == 1 and a.precision != "fp32" and not a.skip_fp32 and not dry:
             eng.close()
@@ -630,6 +638,22 @@ def main():
                           "sampled_latent_vs_timed_precision": rel_l2_dev(x_timed, x32)}
             if ref is not None:
                 fp32_block["parity"] = parity_of(e32, "fp32")
+            # BASELINE configs[2] literally says "bf16": the headline workload with bf16 operands (same MFMA rate and bytes as the fp16 that is
+            # served and timed above; bf16 cannot meet the 1e-3 tolerance -- BASELINE.md section 2), with its parity beside it (r5)
+            if a.precision == "fp16":
+                try:
+                    eb = build("bf16")
+                    wb, _, _ = timed_jobs(eb, io, K, K, min(reps, 3), False)
+                    xb = x.clone()
+                    bf16_block = {"dtype": "bf16", "what": "the headline job (set_condition + 20 UniPC steps, batch 32, 10 s) with bf16 MFMA operands, as BASELINE configs[2] names it",
+                                  "ms_per_step": statistics.median(wb) * 1e3 / K, "value": K / statistics.median(wb), "jobs_ms": [w * 1e3 for w in wb],
+                                  "launches_per_step": eb.launches()[0], "sampled_latent_vs_fp32_loop": rel_l2_dev(xb, x32),
+                                  "fp16_sampled_latent_vs_fp32_loop": rel_l2_dev(x_timed, x32), "tolerance": 1e-3}
+                    if ref is not None:
+                        bf16_block["parity"] = parity_of(eb, "bf16")
+                    eb.close()
+                except Exception as ex:
+                    bf16_block = {"error": repr(ex)}
             # the mixed-precision loop at the headline shape: the last two evaluations on this fp32 engine
             if a.tail_fp32 == 0:
                 try:
@@ -739,7 +763,7 @@ def main():
             "gn_prologue_workgroups_alone": gn_alone,
             "xcd_round_robin": (None if dry else E.xcd_round_robin()),
             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "parity": parity, "self_check": self_check, "fp32_parity_mode": fp32_block, "other_configs": others, "strong_scaling": None,
+            "roofline": roof, "parity": parity, "self_check": self_check, "fp32_parity_mode": fp32_block, "bf16_as_stated": bf16_block, "other_configs": others, "strong_scaling": None,
             "cpu_baseline": cpu,
         }
         if dry:
