@@ -162,6 +162,7 @@ struct ns2vc_unet {
   bool fuse_gn_cat = true;                // ... also where the norm's input is a concat of two tensors and / or a raw operand copy is wanted (first resnet of a level, up blocks)
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
+  int cus = 256;               // compute units of this device (hipDeviceProp_t.multiProcessorCount): the "one round of workgroups" heuristics scale with it
   int xcd_probe = -1;          // misc.hip's placement probe of this device: 1 = workgroup ids 8 apart share an XCD
   bool slice_rows = true;      // first row chain of a dim-384 block as two N-slices per token block (r4; see Planner::transformer)
   unsigned* ln_health = nullptr;
@@ -870,7 +871,7 @@ struct Planner {
       }
       // r4: two N-slices per token block where that still is one round of workgroups (dim 384 at the bench batch: 118 blocks on 256 CUs);
       // only for the chain without a residual (the second chain reads and rewrites y in place: two slices would race on it)
-      if (!res && stream == a.chain_in && a.chain_in_s2 && h->slice_rows && 2 * ((M + 63) / 64) <= 264) { c.wstream = a.chain_in_s2; c.slices = 2; }
+      if (!res && stream == a.chain_in && a.chain_in_s2 && h->slice_rows && 2 * ((M + 63) / 64) <= h->cus + 8) { c.wstream = a.chain_in_s2; c.slices = 2; }   // (one round of workgroups on this device's CUs)
       add(c.slices == 2 ? nm + "[2 slices]" : nm, [=](hipStream_t s) { return launch_rowchain(c, pr, s); }, 1, 2.0 * M * (double)d * (d + n2),
           (double)M * (d * ((gn_st ? 4.0 : opsz) + 4.0 + (res ? 4.0 : 0.0)) + n2 * opsz) + (double)(d + n2) * d * opsz);
     };
@@ -1326,6 +1327,11 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   auto* h = new ns2vc_unet();
   h->cfg = *cfg;
   if (hipGetDevice(&h->device) != hipSuccess) { delete h; return fail("hipGetDevice failed"); }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
+    set_convts_bn128_min(h->cus * 5 / 8);      // 128-column tap-sharing tiles while they still give 5/8 of the CUs a workgroup (160 of 256)
+  }
   // rows shared between workgroups through an XCD's L2 only where the placement probe has SEEN ids 8 apart on one XCD (and even then
   // every workgroup checks its own placement, gnpro.h)
   h->xcd_probe = xcd_round_robin_of_current_device();
