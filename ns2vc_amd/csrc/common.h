@@ -233,7 +233,7 @@ bool convts_eligible(const GemmArgs& g, int prec);
 int convts_default_bn(const GemmArgs& g);
 void set_convts_bn128_min(int wgs);
 int convts_row_blocks(const GemmArgs& g);
-hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, hipStream_t s);
+hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, int ks, hipStream_t s);
 hipError_t init_convts_attributes();
 void set_forced_gemm_tile(int bm, int bn, int stages);
 void set_gemm_trace(unsigned long long* p);

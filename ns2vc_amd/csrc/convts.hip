@@ -63,6 +63,9 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #define TS_ACC(a, t) do {} while (0)
 #define TS_PUT(i, v) do {} while (0)
 #endif
+#ifndef NS2VC_TS_KS_DEFAULT
+#define NS2VC_TS_KS_DEFAULT 0    // K-split consumer layout of the 64-column tile by default (set after the same-box A/B)
+#endif
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
@@ -80,7 +83,10 @@ template <int LO, int HI> struct TsWait {
   }
 };
 
-template <typename TM, int BN, int NL, bool GNP>
+// KS (BN = 64 only): the four consumer waves as 2 row halves x 2 K halves of 64 x 64 wave tiles instead of four 32 x 64 tiles over the whole K:
+// 8 KB instead of 12 KB of fragment reads per wave and step (1 KB per MFMA instead of 1.5) -- the loop is LDS-bandwidth-bound (TsRing comment) --,
+// the two K halves meet in the LDS-staged epilogue as gemm4_kernel's do.
+template <typename TM, int BN, int NL, bool GNP, bool KS = false>
 __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   constexpr int NW = NL + 4, EOFF = NW - 8;                      // waves; first wave with a role in the 8-wave epilogue
   constexpr int LTH = NL * 64, RPP = LTH / 8, PASSB = RPP * TS_ROW;
   constexpr int LA = TS_BM / RPP, LB = BN / RPP;                 // 16-B DMA pieces per loading thread: activation chunk / weight tile
-  constexpr int WGN = BN / 64, WGM = 4 / WGN, WM = TS_BM / WGM, MT = WM / 32, NT = 2;
+  static_assert(!KS || BN == 64, "the K-split consumer layout is the 64-column tile's");
+  constexpr int WGN = BN / 64, WGM = KS ? 2 : 4 / WGN, WM = TS_BM / WGM, MT = WM / 32, NT = 2;
+  constexpr int NKK = KS ? 2 : 4;                                // 32-B k-slabs of a step a consumer wave multiplies
   constexpr int WSLOT = BN * TS_ROW;
   constexpr int SW = TsRing<BN>::SW, D = SW - 1;                 // weight ring: a tile is issued D steps ahead
   constexpr unsigned SZB = sizeof(TM);
@@ -104,7 +112,8 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   const bool loader = wave < NL, consumer = wave >= NL;
   const int ewave = wave - EOFF;                                 // role in the epilogue (< 0: none)
   const int cw = consumer ? wave - NL : 0;                       // consumer wave: its wave tile
-  const int wm = cw / WGN, wn = cw % WGN;
+  const int wm = KS ? cw >> 1 : cw / WGN, wn = KS ? 0 : cw % WGN;
+  const int kh = KS ? cw & 1 : 0;                                // K half of a consumer wave (KS)
   const unsigned lds0 = (unsigned)(size_t)smem;
   unsigned long long* const tr = (NS2VC_GEMM_TRACE && g_ts_trace) ? g_ts_trace + (size_t)blockIdx.x * 16 : nullptr;
   TS_STAMP(0);
@@ -243,10 +252,11 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       TS_ACC(t_bar, t0);
       // every fragment read of the step first (one consumer wave per SIMD: nothing else hides the LDS round trip); the compiler's
       // counted waits then release the MFMAs one k-slab at a time
-      u32x4_t af[4][MT], bf[4][NT];
+      u32x4_t af[NKK][MT], bf[NKK][NT];
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int coffa = ((2 * kk + hi) ^ swa) * 16, coffb = ((2 * kk + hi) ^ swb) * 16;
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int ks = KS ? 2 * kh + kk : kk;
+        const int coffa = ((2 * ks + hi) ^ swa) * 16, coffb = ((2 * ks + hi) ^ swb) * 16;
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[kk][i] = *reinterpret_cast<const u32x4_t*>(ap + i * 32 * TS_ROW + coffa);
 #pragma unroll
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -334,10 +344,13 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   if (ewave < 0) return;                                         // loaders beyond the epilogue's eight waves (s_barrier counts live waves only)
   // ---- epilogue: per 32-row slab the four consumer waves stage their 32 x 64 tile in LDS (re-using the rings), then each of the
   // eight waves moves 16 whole rows out (16-B fp32 / 8-B 16-bit stores, coalesced); bias, residual, statistics; padded -> real rows
-  const int kg = ewave >> 2, wq = ewave & 3;                     // row half inside a slab, wave tile
-  const int em = wq / WGN, en = wq % WGN;
+  const int kg = ewave >> 2, wq = ewave & 3;                     // row half inside a slab; slab slot (KS: 32-row slab of the tile, else wave tile)
+  // The eight epilogue waves each own rows kg*16 .. +15 of one staged 32 x 64 slab `wq`.  Plain layout: slab wq = consumer wq's current 32-row
+  // block (MT rounds); K-split layout: all four 32-row slabs of the tile are staged at once, each by the two consumers (K halves) of its
+  // row half, and the readers add the pair.
+  const int em = KS ? 0 : wq / WGN, en = KS ? 0 : wq % WGN;
   constexpr int EP = 64 + 4, SLAB = 32 * EP;
-  float* const et = reinterpret_cast<float*>(smem) + wq * SLAB;
+  float* const etw = reinterpret_cast<float*>(smem);             // staging: [K half][4 slabs] (KS) / [4 slabs]
   float* of = g.out_f32;
   TM* oo = reinterpret_cast<TM*>(g.out_op);
   constexpr int LPR = 16, RPI = 4, NIT = 4;
@@ -345,25 +358,39 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   const int ncol = n0 + en * 64 + cq * 4;
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (g.bias) bv = *reinterpret_cast<const float4*>(g.bias + ncol);
-  const int qw0 = q0 + em * WM;                                  // first padded row of the wave tile
-  const int b0 = min(qw0 / P, g.B - 1);                          // its batch item; T >= 66 > WM: the tile touches b0 and at most b0 + 1
+  constexpr int ROUNDS = KS ? 1 : MT;
+  const int qw0 = q0 + (KS ? wq * 32 : em * WM);                 // first padded row of what this wave's statistics cover
+  constexpr int QSPAN = KS ? 32 : WM;
+  const int b0 = min(qw0 / P, g.B - 1);                          // its batch item; T >= 66 > QSPAN: the rows touch b0 and at most b0 + 1
   float gs0 = 0.f, gq0 = 0.f, gs1 = 0.f, gq1 = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
+  for (int mt = 0; mt < ROUNDS; ++mt) {
     lds_barrier();                                               // rings (or the previous slab) are free
-    if (kg == 1) {
+    if (kg == 1) {                                               // (the consumer waves)
+      if constexpr (KS) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int i = 0; i < MT; ++i) {
+          float* const e = etw + (kh * 4 + wm * 2 + i) * SLAB;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) et[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[i][j][r];
+        }
+      } else {
+        float* const e = etw + wq * SLAB;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) e[(8 * (r >> 2) + 4 * hi + (r & 3)) * EP + j * 32 + l31] = acc[mt][j][r];
+      }
     }
     lds_barrier();
     int mrow[NIT];
     bool okr[NIT], first[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
-      const int rl = mt * 32 + kg * 16 + k * RPI + rsub;         // row inside the wave tile
-      const int rt = em * WM + rl;                               // row inside the tile
+      const int rl = kg * 16 + k * RPI + rsub;                   // row inside the slab
+      const int rt = KS ? wq * 32 + rl : em * WM + mt * 32 + rl; // row inside the tile
       const int q = q0 + rt;
       const int b = q / P, t = q - b * P;
       okr[k] = rt < TS_BMO && q < MP && t < T;
@@ -379,10 +406,15 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       for (int k = 0; k < NIT; ++k) rr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float4 vv[NIT];
+    const float* const er = etw + wq * SLAB;
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int row = kg * 16 + k * RPI + rsub;
-      const float4 a = *reinterpret_cast<const float4*>(et + row * EP + cq * 4);
+      float4 a = *reinterpret_cast<const float4*>(er + row * EP + cq * 4);
+      if constexpr (KS) {                                        // K half 0 + K half 1, always in this order
+        const float4 a1 = *reinterpret_cast<const float4*>(er + 4 * SLAB + row * EP + cq * 4);
+        a.x += a1.x; a.y += a1.y; a.z += a1.z; a.w += a1.w;
+      }
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (okr[k]) {
         v.x = a.x + bv.x + rr[k].x; v.y = a.y + bv.y + rr[k].y; v.z = a.z + bv.z + rr[k].z; v.w = a.w + bv.w + rr[k].w;
@@ -412,7 +444,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       unsigned long long* st = reinterpret_cast<unsigned long long*>(g.stats) + ((size_t)b0 * nblk + blk) * 2;
       atomicAdd(st, (unsigned long long)llrint(d0 * GN_SUM_SCALE));
       atomicAdd(st + 1, (unsigned long long)llrint(d1 * GN_SQ_SCALE));
-      if (b0 + 1 < g.B && (b0 + 1) * P < qw0 + WM) {
+      if (b0 + 1 < g.B && (b0 + 1) * P < qw0 + QSPAN) {
         atomicAdd(st + 2 * nblk, (unsigned long long)llrint(d2 * GN_SUM_SCALE));
         atomicAdd(st + 2 * nblk + 1, (unsigned long long)llrint(d3 * GN_SQ_SCALE));
       }
@@ -446,31 +478,32 @@ int convts_default_bn(const GemmArgs& g) {
 }
 int convts_row_blocks(const GemmArgs& g) { return (int)(((long long)g.B * (g.Tin + 1) + TS_BMO - 1) / TS_BMO); }
 
-template <typename TM, int BN, int NL> static hipError_t launch_ts_cfg(const GemmArgs& g, hipStream_t s) {
+template <typename TM, int BN, int NL, bool KS> static hipError_t launch_ts_cfg(const GemmArgs& g, hipStream_t s) {
   const int nbm = convts_row_blocks(g), nbn = g.N / BN;
   int nb = nbm * nbn;
   if (g.gnp_x && g.gnp_sync && nbn > 1) nb = 8 * ((nbm + 7) / 8) * nbn;      // cooperative prologue: row blocks per XCD, padded
-  if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, true>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
-  else hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, false>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, true, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  else hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, false, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
   return hipGetLastError();
 }
-template <typename TM> static hipError_t launch_ts_typed(const GemmArgs& g, int bn, int nl, hipStream_t s) {
-  if (bn == 64 && nl == 4) return launch_ts_cfg<TM, 64, 4>(g, s);
-  if (bn == 128 && nl == 4) return launch_ts_cfg<TM, 128, 4>(g, s);
-  if (bn == 64 && nl == 8) return launch_ts_cfg<TM, 64, 8>(g, s);
-  if (bn == 128 && nl == 8) return launch_ts_cfg<TM, 128, 8>(g, s);
+template <typename TM> static hipError_t launch_ts_typed(const GemmArgs& g, int bn, int nl, int ks, hipStream_t s) {
+  if (bn == 64 && nl == 4) return ks ? launch_ts_cfg<TM, 64, 4, true>(g, s) : launch_ts_cfg<TM, 64, 4, false>(g, s);
+  if (bn == 64 && nl == 8) return ks ? launch_ts_cfg<TM, 64, 8, true>(g, s) : launch_ts_cfg<TM, 64, 8, false>(g, s);
+  if (bn == 128 && nl == 4) return launch_ts_cfg<TM, 128, 4, false>(g, s);
+  if (bn == 128 && nl == 8) return launch_ts_cfg<TM, 128, 8, false>(g, s);
   return hipErrorInvalidValue;
 }
-// bn 64 | 128 (0: heuristic), nl 4 | 8 loader waves (0: default)
-hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, hipStream_t s) {
+// bn 64 | 128 (0: heuristic), nl 4 | 8 loader waves (0: default), ks: the K-split consumer layout of the 64-column tile (-1: default)
+hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, int ks, hipStream_t s) {
   if (!convts_eligible(g, prec)) return hipErrorInvalidValue;
   if (!bn) bn = convts_default_bn(g);
   if (!nl) nl = 8;          // (r5 session 6, same box: 3.564 ms/step with 8 loader waves, 3.576 with 4)
+  if (ks < 0) ks = NS2VC_TS_KS_DEFAULT;
   if (g.N % bn) return hipErrorInvalidValue;
   switch (prec) {
-    case PREC_BF16: return launch_ts_typed<bf16_t>(g, bn, nl, s);
-    case PREC_F16: return launch_ts_typed<f16_t>(g, bn, nl, s);
-    case PREC_F32: return launch_ts_typed<float>(g, bn, nl, s);
+    case PREC_BF16: return launch_ts_typed<bf16_t>(g, bn, nl, ks, s);
+    case PREC_F16: return launch_ts_typed<f16_t>(g, bn, nl, ks, s);
+    case PREC_F32: return launch_ts_typed<float>(g, bn, nl, ks, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -484,6 +517,10 @@ template <typename TM> static hipError_t ts_init_typed() {
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, false>, ts_lds_bytes(BN_));     \
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, true>, ts_lds_bytes(BN_))
   NS2VC_TS_SET(64, 4); NS2VC_TS_SET(128, 4); NS2VC_TS_SET(64, 8); NS2VC_TS_SET(128, 8);
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, false, true>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, true, true>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, false, true>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, true, true>, ts_lds_bytes(64));
 #undef NS2VC_TS_SET
   return e;
 }

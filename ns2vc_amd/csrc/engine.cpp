@@ -162,6 +162,7 @@ struct ns2vc_unet {
   bool fuse_gn_cat = true;                // ... also where the norm's input is a concat of two tensors and / or a raw operand copy is wanted (first resnet of a level, up blocks)
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
+  int gn_coop_min = 2;         // fewest column tiles of a row block for which the cooperative prologue is used (tuning: NS2VC_GN_COOP_MIN under NS2VC_DEBUG_ENV)
   int cus = 256;               // compute units of this device (hipDeviceProp_t.multiProcessorCount): the "one round of workgroups" heuristics scale with it
   int xcd_probe = -1;          // misc.hip's placement probe of this device: 1 = workgroup ids 8 apart share an XCD
   bool slice_rows = true;      // first row chain of a dim-384 block as two N-slices per token block (r4; see Planner::transformer)
@@ -765,7 +766,7 @@ struct Planner {
   }
   GnPro groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
                   const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw,
-                  int consumer_n = 0) {
+                  int consumer_n = 0, int consumer_taps = 1) {
     (void)cout;
     const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N, pr = prec;
     double* part = gn_partial;
@@ -784,7 +785,14 @@ struct Planner {
       // wider than one column tile: the column tiles of a row block share the prologue's rows (one 64-bit count per 64-row block, zeroed with the arena)
       // (r5: the counts live in the statistics pool, so the forward's one clear launch also zeroes them: a launch that was cut short cannot
       //  leave a remainder behind for the next forward)
-      if (h->gn_coop && consumer_n > 128) { p.sync = new_sync(((size_t)Bq * Tl + 63) / 64); p.alone = (p.sync && h->ln_health) ? h->ln_health + 48 : nullptr; }
+      int nshare = consumer_n / 128;           // column tiles of a row block: N / 128 in gemm4_kernel, N / BN in the tap-sharing conv kernel
+      if (consumer_taps == 3 && h->conv_ts && Tl >= 66) {
+        GemmArgs t;
+        memset(&t, 0, sizeof(t));
+        t.B = Bq; t.Tin = t.Tout = Tl; t.N = consumer_n;
+        nshare = consumer_n / convts_default_bn(t);
+      }
+      if (h->gn_coop && nshare >= std::max(2, h->gn_coop_min)) { p.sync = new_sync(((size_t)Bq * Tl + 63) / 64); p.alone = (p.sync && h->ln_health) ? h->ln_health + 48 : nullptr; }
       return p;
     }
     if (!epi) {
@@ -805,7 +813,7 @@ struct Planner {
     const int cin = c0 + c1;
     // ---- conv1(act(norm1(x)))
     const GnPro p1 = groupnorm(r.prefix + ".norm1", a0, lda0, c0, a1, lda1, c1, Tl, 1e-5f, r.n1g, r.n1b, nullptr, 0, 0, 1, xn,
-                               r.shortcut ? xr : nullptr, r.conv1.N);
+                               r.shortcut ? xr : nullptr, r.conv1.N, 3);
     GemmArgs g = base(xn, cin, cin, Tl, Tl, r.conv1, h1, nullptr, r.cout);
     g.taps = 3;
     gn_fuse(g, p1);
@@ -813,7 +821,7 @@ struct Planner {
     gemm(r.prefix + ".conv1", g);
     // ---- conv2(act(norm2(h) * (1 + scale) + shift)) + shortcut
     const GnPro p2 = groupnorm(r.prefix + ".norm2", h1, r.cout, r.cout, nullptr, 0, 0, Tl, 1e-5f, r.n2g, r.n2b, h->temb, r.temb_off, r.cout, 1, hn,
-                               nullptr, r.conv2.N);
+                               nullptr, r.conv2.N, 3);
     GemmArgs g2 = base(hn, r.cout, r.cout, Tl, Tl, r.conv2, out, out_op, r.cout);
     g2.taps = 3;
     gn_fuse(g2, p2);
@@ -1180,7 +1188,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   }
   if (!skips.empty()) return fail("internal: %zu skips left over", skips.size());
   {
-    const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N);
+    const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N, 3);
     GemmArgs g = P.base(P.xn, curC, curC, T, T, h->conv_out, h->x0, nullptr, CP);
     g.taps = 3;
     P.gn_fuse(g, pno);
@@ -1349,7 +1357,12 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
       }
     if (h->xcd_probe != 1) h->gn_coop = false;
-    if (const char* v = getenv("NS2VC_TS_NL")) set_forced_gemm_tile(-4, 0, atoi(v));      // loader waves of the tap-sharing conv kernel (4 | 8), process-wide
+    {   // loader waves (4 | 8) and consumer layout (NS2VC_TS_KS = 1: K-split, 0: plain) of the tap-sharing conv kernel, process-wide
+      const char* nl = getenv("NS2VC_TS_NL");
+      const char* ks = getenv("NS2VC_TS_KS");
+      if (nl || ks) set_forced_gemm_tile(-4, ks ? (atoi(ks) ? 1 : 2) : 0, nl ? atoi(nl) : 0);
+    }
+    if (const char* v = getenv("NS2VC_GN_COOP_MIN")) h->gn_coop_min = atoi(v);
     if (const char* v = getenv("NS2VC_TS_BN128_MIN")) set_convts_bn128_min(atoi(v));        // workgroups a 128-column tiling must still give to be chosen
   }
   h->blocks = make_topology(*cfg);

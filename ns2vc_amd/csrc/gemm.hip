@@ -1006,11 +1006,11 @@ static hipError_t gemm_invalid(int line) { g_gemm_fail_line = line; return hipEr
 int last_gemm_refusal_line() { const int l = g_gemm_fail_line; g_gemm_fail_line = 0; return l; }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_st = 0;
-static int g_ts = 1, g_ts_nl = 0;   // tap-sharing conv kernel on / off (tests / tuning: ns2vc_debug_set_gemm_tile(-3, 0, 0) off, (-4, 0, nl) on with nl loader waves, 0 = default)
+static int g_ts = 1, g_ts_nl = 0, g_ts_ks = -1;   // tap-sharing conv kernel on / off (tests / tuning: ns2vc_debug_set_gemm_tile(-3, 0, 0) off, (-4, 0, nl) on with nl loader waves, 0 = default)
 static int g_spec = 1;   // loader / consumer tiles where the heuristic wants them; tests / tuning: ns2vc_debug_set_gemm_tile(-1, 0, 0) selects the round-2 (plain) tile choice, (-2, 0, 0) restores
 void set_forced_gemm_tile(int bm, int bn, int stages) {
   if (bm == -1 || bm == -2) { g_spec = bm == -2 ? 1 : 0; return; }
-  if (bm == -3 || bm == -4) { g_ts = bm == -4 ? 1 : 0; g_ts_nl = (bm == -4 && (stages == 4 || stages == 8)) ? stages : 0; return; } g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
+  if (bm == -3 || bm == -4) { g_ts = bm == -4 ? 1 : 0; g_ts_nl = (bm == -4 && (stages == 4 || stages == 8)) ? stages : 0; g_ts_ks = bm == -4 ? (bn == 1 ? 1 : bn == 2 ? 0 : -1) : -1; return; } g_force_bm = bm; g_force_bn = bn; g_force_st = stages & 255; g_gemm_flags = stages >> 8; }
 
 // Tile choice.  `st` 2..4 = gemm2_kernel with that ring depth; 12 / 13 = gemm4_kernel (8 waves, K split) with ring 2 / 3.
 // The compiled set is exactly what this function can return:
@@ -1108,9 +1108,11 @@ hipError_t launch_gemm(const GemmArgs& g_, int prec, hipStream_t s) {
   // k = 3 / stride 1: the tap-sharing kernel (convts.hip) unless the caller (algo = 1), the global switch or a forced gemm4 / gemm2 tile says otherwise;
   // a forced tile (128, 64 | 128, 54 | 58) selects its BN and loader-wave count
   {
-    const bool forced_ts = g_force_bm == 128 && (g_force_st == 54 || g_force_st == 58);
+    // (stages 64 | 68: the same with the K-split consumer layout, 64-column tiles only)
+    const bool forced_ks = g_force_bm == 128 && g_force_bn == 64 && (g_force_st == 64 || g_force_st == 68);
+    const bool forced_ts = (g_force_bm == 128 && (g_force_st == 54 || g_force_st == 58)) || forced_ks;
     if (g.algo != 1 && (forced_ts || (g_ts && !g_force_bm)) && convts_eligible(g, prec))
-      return launch_convts(g, prec, forced_ts ? g_force_bn : 0, forced_ts ? g_force_st - 50 : g_ts_nl, s);
+      return launch_convts(g, prec, forced_ts ? g_force_bn : 0, forced_ts ? g_force_st % 10 : g_ts_nl, forced_ts ? (forced_ks ? 1 : 0) : g_ts_ks, s);
     if (forced_ts) return gemm_invalid(__LINE__);
   }
   switch (prec) {

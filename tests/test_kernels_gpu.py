@@ -218,11 +218,11 @@ def test_gemm_every_tile(tile, prec, diag):
         assert e < TOL[prec]
 
 
-TS_STAGES = (54, 58)     # ns2vc_debug_set_gemm_tile(128, BN, 50 + loader waves): the tap-sharing conv kernel (convts.hip), BN 64 | 128
+TS_STAGES = (54, 58, 64, 68)     # ns2vc_debug_set_gemm_tile(128, BN, 50 + loader waves): the tap-sharing conv kernel (convts.hip), BN 64 | 128; 60 + loader waves: BN 64 with the K-split consumer layout
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58), (128, 64, 64), (128, 64, 68)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_conv_tapshare_kernel(tile, prec, diag):
     """conv3ts_kernel (k = 3, stride 1: resnet.py:591-641 conv1 / conv2, unet_1d_condition.py:943,1032) against numpy fp64 AND against
     gemm4_kernel on the same operands: every tile (BN 64 / 128, 4 / 8 loader waves); items shorter, equal to and longer than a 126-row tile
@@ -285,7 +285,7 @@ def test_conv_tapshare_kernel(tile, prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 13), (128, 128, 13), (64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58)],
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 13), (128, 128, 13), (64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 64, 68)],
                          ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_groupnorm_prologue(tile, prec, diag):
     """ns2vc_gemm_args.gnp_*: the GEMM writes act(GroupNorm(x)) for the rows its tiles read into its own A operand and then runs as
@@ -380,7 +380,7 @@ def test_gemm_groupnorm_prologue(tile, prec, diag):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 128, 58)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+@pytest.mark.parametrize("tile", [(0, 0, 0), (64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 128, 58), (128, 64, 64)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
 def test_gemm_groupnorm_prologue_of_a_concat(tile, prec, diag):
     """The prologue on the channel concat of TWO tensors, each with its own epilogue statistics (resnet.py:591 on torch.cat([h, skip]) in the
     up blocks: 128+128 ... 512+512 channels, 512+384 with groups that straddle the two sources), plus the un-normalised operand copy the
@@ -520,7 +520,7 @@ def test_gemm_epilogue_groupnorm_stats(prec, diag):
     lib = _lib()
     rng = np.random.default_rng(5)
     B, T, c0, N = 3, 167, 128, 256
-    for tile in [(0, 0, 0), (64, 128, 2), (64, 64, 2), (128, 128, 13), (64, 128, 13), (128, 128, 23), (64, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58)]:
+    for tile in [(0, 0, 0), (64, 128, 2), (64, 64, 2), (128, 128, 13), (64, 128, 13), (128, 128, 23), (64, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58), (128, 64, 64), (128, 64, 68)]:
         a0 = rnd(rng.standard_normal((B, T, c0)), prec)
         W = rnd(rng.standard_normal((N, 3 * c0)) / np.sqrt(3 * c0), prec)
         bias = rng.standard_normal(N).astype(np.float32)

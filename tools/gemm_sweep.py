@@ -35,7 +35,7 @@ ABLATE4 = [(bm, 128, 13 | (f << 8)) for bm in (64, 128) for f in (0, 2, 4, 8, 16
 # (the 8 + 8 / 8 + 4 wave modes and ring 2 / 4 of profiles/r03_gemm_spec.txt need their NS2VC_CASE4S / NS2VC_SET4S lines back in gemm.hip)
 SPEC = [(64, 128, 13), (64, 128, 23), (128, 128, 12), (128, 128, 13), (128, 128, 23)]
 # r5: the tap-sharing conv kernel (convts.hip; stages 54 / 58 = 4 / 8 loader waves, BN = 64 / 128) beside gemm4's loader / consumer tiles, k = 3 shapes only
-TS = [(64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58)]
+TS = [(64, 128, 23), (128, 128, 23), (128, 64, 54), (128, 128, 54), (128, 64, 58), (128, 128, 58), (128, 64, 64), (128, 64, 68)]   # 64 / 68: K-split consumers
 
 
 def stride_shapes():
