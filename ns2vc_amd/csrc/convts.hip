@@ -63,17 +63,19 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #define TS_ACC(a, t) do {} while (0)
 #define TS_PUT(i, v) do {} while (0)
 #endif
+#ifndef NS2VC_TS_ABLATE
+#define NS2VC_TS_ABLATE 0        // diagnostic builds (wrong results): 1 = consumers neither read fragments nor multiply, 2 = loaders issue no DMA inside the loop,
+#endif                           // 4 = consumers read fragments but do not multiply
 #ifndef NS2VC_TS_KS_DEFAULT
 #define NS2VC_TS_KS_DEFAULT 0    // K-split consumer layout of the 64-column tile by default (set after the same-box A/B)
 #endif
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
-// Weight ring depth: a tile is issued SW - 1 steps ahead.  r5 sessions 4 / 5 (tools/ts_trace.py, profiles/r05_ts_trace.txt): five steps ahead
-// (SW = 6) changed nothing against two (3.62 ms/step either way, 790 cycles per step in the traced build) -- the loop is not waiting for
-// latency but for the LDS: DMA writes + the consumers' fragment reads move 61 KB per step (BN = 64; 85 KB at BN = 128, 72 KB per tile in
-// gemm4's loader / consumer tiles), and all three settle at 78-88 B/clk/CU.  So the ring stays as shallow as the pipeline needs
-// (72 / 96 KB: two 128 x 64 workgroups per CU); the counted-wait bookkeeping below is written for any depth.
+// Weight ring depth: a tile is issued SW - 1 steps ahead.  r5 sessions 4 / 5 / 12 (tools/ts_trace.py, profiles/r05_ts_trace.txt, r05_ts_ablate.txt): five steps
+// ahead (SW = 6) changed nothing against two (3.62 ms/step either way) -- the loop does not wait for latency: the DMA stream ALONE (consumers idle)
+// takes 95 % of the full kernel's time, i.e. the loop runs at the rate the L2 -> LDS path delivers tiles to all CUs at once (~22 B/clk/CU here).  So
+// the ring stays as shallow as the pipeline needs (72 / 96 KB: two 128 x 64 workgroups per CU); the counted-wait bookkeeping is written for any depth.
 template <int BN> struct TsRing { static constexpr int SW = 3; };
 // s_waitcnt vmcnt(n) for a wave-uniform n in [LO, HI]: the count is an immediate, so a binary tree of scalar branches picks it
 template <int LO, int HI> struct TsWait {
@@ -84,8 +86,9 @@ template <int LO, int HI> struct TsWait {
 };
 
 // KS (BN = 64 only): the four consumer waves as 2 row halves x 2 K halves of 64 x 64 wave tiles instead of four 32 x 64 tiles over the whole K:
-// 8 KB instead of 12 KB of fragment reads per wave and step (1 KB per MFMA instead of 1.5) -- the loop is LDS-bandwidth-bound (TsRing comment) --,
-// the two K halves meet in the LDS-staged epilogue as gemm4_kernel's do.
+// 8 KB instead of 12 KB of fragment reads per wave and step (1 KB per MFMA instead of 1.5); the two K halves meet in the LDS-staged epilogue as
+// gemm4_kernel's do.  Measured (r5 session 11): 11.9 vs 11.5 us isolated, 3.543 vs 3.542 ms/step in situ -- the consumers hide under the DMA stream either
+// way (profiles/r05_ts_ablate.txt), so it stays a tested option (NS2VC_TS_KS_DEFAULT 0).
 template <typename TM, int BN, int NL, bool GNP, bool KS = false>
 __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g) {
   op_mode_init<TM>();
@@ -252,6 +255,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       TS_ACC(t_bar, t0);
       // every fragment read of the step first (one consumer wave per SIMD: nothing else hides the LDS round trip); the compiler's
       // counted waits then release the MFMAs one k-slab at a time
+      if (NS2VC_TS_ABLATE & 1) return;
       u32x4_t af[NKK][MT], bf[NKK][NT];
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
@@ -265,6 +269,16 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
 #if NS2VC_CONS_PF
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      if (NS2VC_TS_ABLATE & 4) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(af[kk][i]));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(bf[kk][j]));
+        }
+        return;
+      }
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
@@ -323,11 +337,11 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
 #pragma unroll
         for (int i = D - 1; i > 0; --i) { hw[i] = hw[i - 1]; ha[i] = ha[i - 1]; }
         hw[0] = 0; ha[0] = 0;
-        if (s + D < S) {                                         // weight tile s+D -> the slot tile s-1 just left
+        if (s + D < S && !(NS2VC_TS_ABLATE & 2)) {               // weight tile s+D -> the slot tile s-1 just left
           issue_w(wslot == 0 ? SW - 1 : wslot - 1);
           hw[0] = LB;
         }
-        if (ti == 0 && ch + 2 < NCH) {                           // chunk ch+2 -> the slot chunk ch-1 just left
+        if (ti == 0 && ch + 2 < NCH && !(NS2VC_TS_ABLATE & 2)) { // chunk ch+2 -> the slot chunk ch-1 just left
           issue_a(ch + 2, aslot == 0 ? 2 : aslot - 1);
           ha[0] = LA;
         }
