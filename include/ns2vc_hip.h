@@ -249,6 +249,10 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
   /* ABI v6: kernel choice.  0 = automatic (k = 3 / stride-1 convolutions with Tin >= 66 run on the tap-sharing kernel, convts.hip: the
    * activation chunk of the three taps is loaded once; same result to fp32 rounding, another summation order over K), 1 = never that kernel. */
   int32_t algo;
+  /* ABI v6, optional (k = 3 / stride-1 launches only): the same weights as `w` in the tile-major layout of ns2vc_pack_conv3_tiled.  The
+   * tap-sharing kernel then reads every (64-column group, step) weight block as 8 KB of consecutive bytes instead of 64 row segments
+   * K * 2 bytes apart (-1.1 % of the step: the tiles come from beyond L2 every step); `w` is still required (other kernels, fallbacks). */
+  const void* w_tiled;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {
@@ -331,6 +335,9 @@ int ns2vc_from_operand(const void* dev, size_t n, int precision, float* host);
 int ns2vc_round_to_operand(const float* host_in, size_t n, int precision, float* host_out);
 int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void** out_dev); /* [N][K] fp32 host -> device, engine dtype */
 int ns2vc_k_gemm(const ns2vc_gemm_args* a, int precision, void* stream);
+/* ABI v6: rows [N][3 * ctot + c2] fp32 host (k = tap * ctot + c, then the c2 columns of a fused 1x1 segment) -> device, engine dtype, N padded to 128,
+ * tile-major: [N / 64][steps][64 rows][128 B] in the tap-sharing kernel's step order, pre-swizzled (csrc/convts.hip pack_conv3_tiled). */
+int ns2vc_pack_conv3_tiled(const float* rows_host, int N, int ctot, int c2, int precision, void** out_dev);
 int ns2vc_weight_rowsum(const float* rows_host, int N, int K, int precision, float** out_dev); /* [N] fp32: sum_k round_to_operand(rows[n][k]) */
 int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8); /* tuning: per-workgroup s_memtime stamps of the next GEMM launches; NULL = off */
 int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream); /* test tool: leave `pattern` in every CU's LDS (first lds_bytes) and in vector registers, as a foreign kernel would */

@@ -52,7 +52,7 @@ class GemmArgs(C.Structure):
         ("gnp_eps", C.c_float), ("gnp_G", C.c_int32), ("gnp_silu", C.c_int32),
         ("gnp_sync", C.c_void_p), ("gnp_alone", C.c_void_p),
         ("gnp_x1", C.c_void_p), ("gnp_ldx1", C.c_int32), ("gnp_c1", C.c_int32), ("gnp_stats1", C.c_void_p), ("gnp_raw", C.c_void_p),
-        ("algo", C.c_int32),
+        ("algo", C.c_int32), ("w_tiled", C.c_void_p),
     ]
 
 
@@ -158,6 +158,7 @@ PROTOTYPES = {
     "ns2vc_event_elapsed_ms": (_I, [_P, _P, C.POINTER(C.c_float)]),
     "ns2vc_pack_weight": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_k_gemm": (_I, [C.POINTER(GemmArgs), _I, _P]),
+    "ns2vc_pack_conv3_tiled": (_I, [_P, _I, _I, _I, _I, _PP]),
     "ns2vc_weight_rowsum": (_I, [_P, _I, _I, _I, _PP]),
     "ns2vc_debug_set_gemm_trace": (_I, [_P]),
     "ns2vc_debug_set_gemm_tile": (_I, [_I, _I, _I]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <vector>
 #include "../../include/ns2vc_hip.h"
 
 namespace ns2vc {
@@ -235,6 +236,7 @@ void set_convts_bn128_min(int wgs);
 int convts_row_blocks(const GemmArgs& g);
 hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, int ks, hipStream_t s);
 hipError_t init_convts_attributes();
+hipError_t pack_conv3_tiled(const float* rows, int N, int ctot, int c2, int prec, std::vector<unsigned char>& out);   // tile-major k = 3 conv weights (convts.hip)
 void set_forced_gemm_tile(int bm, int bn, int stages);
 void set_gemm_trace(unsigned long long* p);
 hipError_t init_attn_attributes();

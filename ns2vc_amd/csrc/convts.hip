@@ -35,6 +35,8 @@
 #include "mma.h"
 #include "gnpro.h"
 #include <type_traits>
+#include <vector>
+#include <cstring>
 
 namespace ns2vc {
 
@@ -161,13 +163,32 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   for (int j = 0; j < LB; ++j) vw[j] = ((unsigned)(n0 + j * RPP + prow) * (unsigned)g.K) * SZB + acolb;
   const i32x4_t rW = make_rsrc(g.w, (unsigned long long)g.N * g.K * SZB);
   int wc_ch = 0, wc_tau = 0;                                     // issue cursor of the weight stream (step order)
+  // Tile-major weights (GemmArgs.w_tiled, pack_conv3_tiled below): the [64 rows][128 B] block of (64-column group, step) is ONE contiguous,
+  // pre-swizzled 8 KB, in the order the loop consumes the steps -- a piece is 1 KB of consecutive bytes instead of eight 128-B row segments
+  // K * 2 bytes apart.  The tiles come from beyond L2 every step (this layer's weights were last read a step ago; every XCD reads all of
+  // them), and DRAM / MALL serve consecutive bytes much better than scattered lines (profiles/r05_ab_weight_tiles.txt).
+  const bool wtiled = g.w_tiled != nullptr;
+  const i32x4_t rWt = make_rsrc(wtiled ? g.w_tiled : g.w, (unsigned long long)g.N * g.K * SZB);
+  int wc_step = 0;
+  unsigned vwt[LB];
+#pragma unroll
+  for (int j = 0; j < LB; ++j) {
+    const int r = j * RPP + prow;                                // row inside the BN-row tile
+    vwt[j] = (unsigned)(((n0 >> 6) + (r >> 6)) * S) * 8192u + (unsigned)((r & 63) * TS_ROW + pchunk * 16);
+  }
   auto issue_w = [&](int slot) __attribute__((always_inline)) {
     const int koff = wc_ch < ncm ? wc_tau * Ctot + wc_ch * BKE : K1 + (wc_ch - ncm) * BKE;
     if (loader) {
       const unsigned base = lds0 + 3 * TS_ASLOT + slot * WSLOT + wave * 1024;
+      if (wtiled) {
 #pragma unroll
-      for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)koff * SZB, base + j * PASSB);
+        for (int j = 0; j < LB; ++j) blds16(rWt, vwt[j], (unsigned)wc_step * 8192u, base + j * PASSB);
+      } else {
+#pragma unroll
+        for (int j = 0; j < LB; ++j) blds16(rW, vw[j], (unsigned)koff * SZB, base + j * PASSB);
+      }
     }
+    ++wc_step;
     if (wc_ch < ncm && wc_tau < 2) ++wc_tau;
     else { ++wc_ch; wc_tau = wc_ch < ncm ? 0 : 1; }
   };
@@ -473,6 +494,38 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
+
+// Tile-major image of a k = 3 conv weight for conv3ts_kernel (GemmArgs.w_tiled).  rows: [N][K] fp32 as ns2vc_pack_weight takes them, K = 3 * ctot + c2
+// (k = tap * ctot + c, then the c2 columns of a fused 1x1 segment); N is padded to a multiple of 128 with zero rows.  Output, in the operand type:
+// [Np / 64 column groups][S steps][64 rows][128 B], S = 3 * (ctot / bke) + c2 / bke steps in the kernel's consumption order (chunk-major, tap-minor, then the
+// single-tap chunks); inside a block byte r * 128 + p * 16 holds the 16-B chunk (p ^ ((r >> 1) & 7)) of row r: the bank-conflict-free LDS image, so the DMA is
+// lane-linear.
+hipError_t pack_conv3_tiled(const float* rows, int N, int ctot, int c2, int prec, std::vector<unsigned char>& out) {
+  const int bke = prec == PREC_F32 ? 32 : 64, esz = prec == PREC_F32 ? 4 : 2, epc = 16 / esz;
+  if (N <= 0 || ctot < bke || (ctot % bke) || (c2 % bke)) return hipErrorInvalidValue;
+  const int K = 3 * ctot + c2, Np = (N + 127) / 128 * 128;
+  const int ncm = ctot / bke, ncs = c2 / bke, S = 3 * ncm + ncs;
+  out.assign((size_t)Np * K * esz, 0);
+  for (int tg = 0; tg < Np / 64; ++tg)
+    for (int s = 0; s < S; ++s) {
+      const int koff = s < 3 * ncm ? (s % 3) * ctot + (s / 3) * bke : 3 * ctot + (s - 3 * ncm) * bke;
+      unsigned char* blk = out.data() + ((size_t)tg * S + s) * 8192;
+      for (int r = 0; r < 64; ++r) {
+        const int n = tg * 64 + r;
+        if (n >= N) continue;
+        for (int p = 0; p < 8; ++p) {
+          const int lc = p ^ ((r >> 1) & 7);
+          for (int e = 0; e < epc; ++e) {
+            const float v = rows[(size_t)n * K + koff + lc * epc + e];
+            unsigned char* dst = blk + r * 128 + p * 16 + e * esz;
+            if (prec == PREC_F32) memcpy(dst, &v, 4);
+            else { const uint16_t q = f32_to_op16_bits(v, prec); memcpy(dst, &q, 2); }
+          }
+        }
+      }
+    }
+  return hipSuccess;
+}
 
 static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)(bn == 64 ? TsRing<64>::SW : TsRing<128>::SW) * bn * TS_ROW; }
 

@@ -61,6 +61,7 @@ struct HostTensor {
 
 struct PackedW {     // device-resident packed GEMM weight
   void* w = nullptr;
+  void* wt = nullptr;      // k = 3 convs: the same weights tile-major for conv3ts_kernel (pack_conv3_tiled)
   float* bias = nullptr;
   float* wsum = nullptr;   // [N] row sums of the packed (rounded) weights: LayerNorm-by-linearity consumers only
   int N = 0, K = 0;
@@ -162,6 +163,7 @@ struct ns2vc_unet {
   bool fuse_gn_cat = true;                // ... also where the norm's input is a concat of two tensors and / or a raw operand copy is wanted (first resnet of a level, up blocks)
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
+  bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
   int gn_coop_min = 2;         // fewest column tiles of a row block for which the cooperative prologue is used (tuning: NS2VC_GN_COOP_MIN under NS2VC_DEBUG_ENV)
   int cus = 256;               // compute units of this device (hipDeviceProp_t.multiProcessorCount): the "one round of workgroups" heuristics scale with it
   int xcd_probe = -1;          // misc.hip's placement probe of this device: 1 = workgroup ids 8 apart share an XCD
@@ -368,10 +370,21 @@ struct Packer {
   }
   float* vec(const std::string& k) { return upload_f32(T(k).data); }
   // rows: [N][K] fp32, bias: [N] or empty.  Pads N to a multiple of 128 with zero rows.
-  PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias, bool want_wsum = false) {
+  // tile3_ctot > 0: a k = 3 conv weight (K = 3 * tile3_ctot + tile3_c2): also packed tile-major for the tap-sharing kernel
+  PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias, bool want_wsum = false, int tile3_ctot = 0, int tile3_c2 = 0) {
     PackedW p;
     const int Np = round_up(N, 128);
     p.N = Np; p.K = K;
+    if (tile3_ctot > 0 && K == 3 * tile3_ctot + tile3_c2) {
+      std::vector<unsigned char> img;
+      if (pack_conv3_tiled(rows.data(), N, tile3_ctot, tile3_c2, h->prec, img) == hipSuccess) {
+        void* dt = nullptr;
+        if (hipMalloc(&dt, img.size()) != hipSuccess) { err = fail("hipMalloc failed (tile-major weights)"); return p; }
+        h->weight_allocs.push_back(dt);
+        if (hipMemcpy(dt, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed");
+        p.wt = dt;
+      }
+    }
     if (want_wsum) p.wsum = upload_f32(rounded_rowsum(rows.data(), N, K, Np, h->prec));
     void* d = nullptr;
     if (h->prec != PREC_F32) {
@@ -405,11 +418,11 @@ struct Packer {
         for (int t = 0; t < taps; ++t) rows[((size_t)n * taps + t) * CinP + (c - c_lo)] = w.data[((size_t)n * Cin + c) * taps + t];
     return rows;
   }
-  PackedW conv(const std::string& prefix) {
+  PackedW conv(const std::string& prefix, bool tile3 = false) {
     const HostTensor& w = T(prefix + ".weight");
     if (err) return {};
     const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], taps = (int)w.shape[2];
-    return pack(conv_rows(w, 0, Cin, Cin), Cout, taps * Cin, T(prefix + ".bias").data);
+    return pack(conv_rows(w, 0, Cin, Cin), Cout, taps * Cin, T(prefix + ".bias").data, false, (tile3 && taps == 3) ? Cin : 0, 0);
   }
   // Linear whose input is LayerNorm(x): fold gamma into W and beta into the bias.
   void ln_fold(const HostTensor& w, const HostTensor* b, const HostTensor& g, const HostTensor& be, std::vector<float>& rows,
@@ -470,7 +483,7 @@ int pack_all(ns2vc_unet* h) {
   {
     const HostTensor& w = P.T("conv_in.weight");
     if (P.err) return 1;
-    h->conv_in_x = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {});
+    h->conv_in_x = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {}, false, CP, 0);
     h->conv_in_c = P.pack(P.conv_rows(w, lat, lat + c.content_channels, c.content_channels), c0, 3 * c.content_channels, P.T("conv_in.bias").data);
   }
   // time MLP, transposed to [in][out] for coalesced GEMV reads
@@ -506,7 +519,7 @@ int pack_all(ns2vc_unet* h) {
     for (auto& r : b.res) {
       r.n1g = P.vec(r.prefix + ".norm1.weight"); r.n1b = P.vec(r.prefix + ".norm1.bias");
       r.n2g = P.vec(r.prefix + ".norm2.weight"); r.n2b = P.vec(r.prefix + ".norm2.bias");
-      r.conv1 = P.conv(r.prefix + ".conv1");
+      r.conv1 = P.conv(r.prefix + ".conv1", true);
       if (r.shortcut) {   // conv2 and the 1x1 shortcut share one GEMM: K = 3*cout + cin, biases summed
         const HostTensor& w2 = P.T(r.prefix + ".conv2.weight");
         const HostTensor& ws = P.T(r.prefix + ".conv_shortcut.weight");
@@ -521,9 +534,9 @@ int pack_all(ns2vc_unet* h) {
           memcpy(&rows[(size_t)n * (K1 + K2) + K1], &ws.data[(size_t)n * K2], K2 * sizeof(float));
           bias[n] = b2.data[n] + bs.data[n];
         }
-        r.conv2 = P.pack(rows, r.cout, K1 + K2, bias);
+        r.conv2 = P.pack(rows, r.cout, K1 + K2, bias, false, r.cout, K2);
       } else {
-        r.conv2 = P.conv(r.prefix + ".conv2");
+        r.conv2 = P.conv(r.prefix + ".conv2", true);
       }
       const HostTensor& tw = P.T(r.prefix + ".time_emb_proj.weight");
       const HostTensor& tb = P.T(r.prefix + ".time_emb_proj.bias");
@@ -646,7 +659,7 @@ int pack_all(ns2vc_unet* h) {
   {
     const HostTensor& w = P.T("conv_out.weight");
     if (P.err) return 1;
-    h->conv_out = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data);
+    h->conv_out = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data, false, c0, 0);
   }
   return P.err;
 }
@@ -745,6 +758,7 @@ struct Planner {
     g.B = B; g.Tin = Tin; g.Tout = Tout; g.M = B * Tout;
     g.taps = 1; g.tmode = TMODE_SAME;
     g.w = w.w; g.K = w.K; g.N = w.N; g.bias = w.bias;
+    g.w_tiled = h->conv_wtiled ? w.wt : nullptr;     // (only the k = 3 / stride-1 launches of the tap-sharing kernel look at it)
     g.out_f32 = out_f32; g.ldo_f32 = ldo;
     g.out_op = out_op; g.ldo_op = ldo;
     g.algo = h->conv_ts ? 0 : 1;
@@ -1264,6 +1278,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "attn_optimistic")) return &h->attn_optimistic;
   if (!strcmp(name, "slice_rows")) return &h->slice_rows;
   if (!strcmp(name, "conv_ts")) return &h->conv_ts;
+  if (!strcmp(name, "conv_wtiled")) return &h->conv_wtiled;
   return nullptr;
 }
 
@@ -1351,7 +1366,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1436,7 +1451,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -1839,6 +1854,16 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
     HIPCHK(hipMalloc(&d, (size_t)N * K * 4));
     HIPCHK(hipMemcpy(d, rows_host, (size_t)N * K * 4, hipMemcpyHostToDevice));
   }
+  *out_dev = d;
+  return 0;
+}
+int ns2vc_pack_conv3_tiled(const float* rows_host, int N, int ctot, int c2, int precision, void** out_dev) {
+  if (!rows_host || !out_dev || N <= 0) return fail("bad argument");
+  std::vector<unsigned char> img;
+  if (pack_conv3_tiled(rows_host, N, ctot, c2, precision, img) != hipSuccess) return fail("pack_conv3_tiled: ctot / c2 must be multiples of the chunk (64 elements; 32 for fp32)");
+  void* d = nullptr;
+  HIPCHK(hipMalloc(&d, img.size()));
+  HIPCHK(hipMemcpy(d, img.data(), img.size(), hipMemcpyHostToDevice));
   *out_dev = d;
   return 0;
 }

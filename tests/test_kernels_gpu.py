@@ -78,7 +78,17 @@ def eps16(prec):
     return {0: 2.0 ** -25, 1: 2.0 ** -9, 2: 2.0 ** -12}[prec]
 
 
-def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, geglu, dual, tile=(0, 0, 0)):
+def _pack_tiled(W, ctot, c2, prec):
+    """device copy of the k = 3 conv weight W [N][3 * ctot + c2] in the tap-sharing kernel's tile-major layout (ns2vc_pack_conv3_tiled)"""
+    from ns2vc_amd._lib import check
+    lib = _lib()
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    out = C.c_void_p()
+    check(lib.ns2vc_pack_conv3_tiled(W.ctypes.data_as(C.c_void_p), W.shape[0], ctot, c2, prec, C.byref(out)), "pack_conv3_tiled")
+    return out
+
+
+def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, geglu, dual, tile=(0, 0, 0), tiled=False):
     from ns2vc_amd._lib import GemmArgs, check
     from ns2vc_amd.engine import DevBuf, sync
     lib = _lib()
@@ -116,6 +126,9 @@ def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, g
     g.B, g.Tin, g.Tout, g.M = B, Tin, Tout, M
     g.taps, g.tmode = taps, tmode
     g.w = d_w.value; g.K = K; g.N = N
+    d_wt = _pack_tiled(W, Ct, 0, prec) if (tiled and taps == 3) else None
+    if d_wt is not None:
+        g.w_tiled = d_wt.value
     if d_bias is not None:
         g.bias = d_bias.ptr
     if d_res is not None:
@@ -133,6 +146,8 @@ def run_gemm(rng, prec, B, Tin, Tout, c0, c1, N, taps, tmode, bias_on, res_on, g
     out = d_out.to_numpy((M, Nout))
     out_op = d_oop.read() if d_oop is not None else None
     lib.ns2vc_dev_free(d_w)
+    if d_wt is not None:
+        lib.ns2vc_dev_free(d_wt)
     return out, ref, out_op
 
 
@@ -228,7 +243,8 @@ def test_conv_tapshare_kernel(tile, prec, diag):
     gemm4_kernel on the same operands: every tile (BN 64 / 128, 4 / 8 loader waves); items shorter, equal to and longer than a 126-row tile
     (T = 66, 70, 125, 126, 127, 300: pad rows at every position of a tile, tiles inside one item, items inside one tile); 1, 2, 3 and many
     channel chunks; the concat of two sources; the fused 1x1 segment (single-tap chunks behind the main ones); bias, residual that aliases
-    nothing, fp32 + operand outputs; NaN-prefilled outputs (every row written exactly where it belongs, nothing else touched)."""
+    nothing, fp32 + operand outputs; NaN-prefilled outputs (every row written exactly where it belongs, nothing else touched); and the same launches
+    reading tile-major weights (ns2vc_gemm_args.w_tiled, ns2vc_pack_conv3_tiled): bit-identical."""
     lib = _lib()
     rng = np.random.default_rng(tile[1] * 7 + tile[2])
     ck = 64 if prec else 32
@@ -240,6 +256,8 @@ def test_conv_tapshare_kernel(tile, prec, diag):
             e = rel_l2(out, ref)
             out4, _, _ = run_gemm(np.random.default_rng(1), prec, B, T, T, c0, c1, N, 3, 0, 1, 1, 0, 0, tile=(64, 128, 23))
             outs, _, _ = run_gemm(np.random.default_rng(1), prec, B, T, T, c0, c1, N, 3, 0, 1, 1, 0, 0, tile=tile)
+            outt, _, _ = run_gemm(np.random.default_rng(1), prec, B, T, T, c0, c1, N, 3, 0, 1, 1, 0, 0, tile=tile, tiled=True)
+            assert np.array_equal(outs, outt), "tile-major weights (w_tiled): same products in the same order, only another source layout"
             e4 = rel_l2(outs, out4)
             diag(f"conv3ts tile={tile} prec={prec} B={B} T={T} c={c0}+{c1} N={N}: vs fp64 {e:.3e}  vs gemm4_kernel {e4:.3e}  nan={int(np.isnan(out).sum())}")
             assert e < TOL[prec] and e4 < (1e-5 if prec == 0 else 1e-5), (B, T, c0, c1, N, e, e4)
@@ -266,13 +284,22 @@ def test_conv_tapshare_kernel(tile, prec, diag):
         g.w = d_w.value; g.K = 3 * c0 + c2; g.N = N; g.bias = d_b.ptr
         g.out_f32 = d_o.ptr; g.ldo_f32 = N
         g.stats = d_s.ptr
-        check(lib.ns2vc_debug_set_gemm_tile(*tile), "tile")
-        try:
-            check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
-            sync()
-        finally:
-            lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
-        out = d_o.to_numpy((M, N))
+        d_wt = _pack_tiled(W, c0, c2, prec)
+        outs2 = []
+        for use_tiled in (True, False):
+            g.w_tiled = d_wt.value if use_tiled else None
+            d_o.upload(np.full((M, N), np.nan, dtype=np.float32))
+            d_s.upload(np.zeros((B, N // 16, 2), dtype=np.int64))
+            check(lib.ns2vc_debug_set_gemm_tile(*tile), "tile")
+            try:
+                check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+                sync()
+            finally:
+                lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+            outs2.append(d_o.to_numpy((M, N)))
+        lib.ns2vc_dev_free(d_wt)
+        assert np.array_equal(outs2[0], outs2[1]), "tile-major weights with a fused 1x1 segment"
+        out = outs2[1]
         e = rel_l2(out, ref)
         st = d_s.to_numpy((B, N // 16, 2), dtype=np.int64).astype(np.float64)
         blk = out.astype(np.float64).reshape(B, T, N // 16, 16)
