@@ -288,6 +288,20 @@ def test_dropin_default_precision_is_the_checked_fast_engine(state, diag):
          f"vs reference golden {e:.2e}")
     assert m._engine.precision == "fp16" and m.precision_error_seen <= 1e-3 and e < 1e-3 and torch.equal(y, y2)
     assert not any("serving from the fp32 engine" in str(i.message) for i in w)
+    # r5: the same weights are measured once more at the first call late in a trajectory (t < late_check_below) -- and only once
+    assert m.precision_checks == 1
+    t_late = torch.tensor([49.95, 49.95]).cuda()
+    with torch.no_grad():
+        yl = m(torch.cat([x, content], dim=1), t_late, prompt, encoder_attention_mask=mask).sample
+        yl2 = m(torch.cat([x, content], dim=1), t_late, prompt, encoder_attention_mask=mask).sample
+    diag(f"... late-timestep re-check (t = 49.95): {m.precision_checks} measurements, worst seen {m.precision_error_seen:.2e} / {m.precision_error_worst_item:.2e}")
+    assert m.precision_checks == 2 and m._engine.precision == "fp16" and torch.equal(yl, yl2) and m.precision_error_seen <= 1e-3
+    # ... and weights that change again within check_min_interval_s are not measured again (the last verdict stands): evaluation between optimizer steps
+    with torch.no_grad():
+        m.conv_out.bias.add_(0.0)                       # an in-place update: new weights key, same values
+        y4 = m(torch.cat([x, content], dim=1), t, prompt, encoder_attention_mask=mask).sample
+    assert m.precision_checks == 2 and m._engine.precision == "fp16" and torch.equal(y4, y)
+    m.check_min_interval_s = 0.0                        # (from here on every new set of weights is measured, as before r5)
     # a checkpoint outside the fp16 range
     hot = {k: v.clone() for k, v in state.items()}
     rng = np.random.default_rng(1)

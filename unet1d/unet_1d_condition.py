@@ -115,6 +115,15 @@ class UNet1DConditionModel(nn.Module):
         self.precision_error_seen: Optional[float] = None
         self.precision_error_worst_item: Optional[float] = None
         self._precision_checked_key = None                                    # weights key the verdict belongs to
+        # r5 (round-4 advice): the first point of a sampling trajectory is not the worst one for the 16-bit engine (ns2vc_amd.pipeline.Denoiser
+        # measures three; the last is ~5 % worse), so the same weights are measured ONCE MORE at the first call with a late timestep
+        # (max t < late_check_below); and a module whose weights change all the time (evaluation between optimizer steps) does not pay an
+        # fp32 engine per change: at most one measurement per `check_min_interval_s` seconds, the last verdict standing in between.
+        self.late_check_below: float = 100.0
+        self.check_min_interval_s: float = 30.0
+        self._late_checked_key = None
+        self._last_check_time = None
+        self.precision_checks = 0                                             # fp16-vs-fp32 measurements taken so far (diagnostics / tests)
         self._engine = None
         self._engine_key = None
         self._engine_shape = None
@@ -179,12 +188,15 @@ class UNet1DConditionModel(nn.Module):
             self._ln_checked = self._ln_pending = False
         return self._engine
 
-    def _auto_check(self, eng, out16, x, ts, content, prompt, mask, shape, stream):
+    def _auto_check(self, eng, out16, x, ts, content, prompt, mask, shape, stream, late: bool = False):
         """engine_precision="auto": the fp16 result of this call against the exact-fp32 engine on the same inputs, once per set of
         weights.  Inside ``precision_check`` (batch figure AND worst utterance): keep fp16, release the fp32 engine.  Outside: warn, keep
         the fp32 engine as THE engine from now on and return its result."""
         from ns2vc_amd.engine import Engine
+        import time as _time
         self._precision_checked_key = self._engine_key[1]
+        self._last_check_time = _time.monotonic()
+        self.precision_checks += 1
         e32 = Engine(self.cfg, precision="fp32")
         e32.load_state_dict({k: v for k, v in self.state_dict().items()})
         torch.cuda.synchronize(x.device)
@@ -196,9 +208,12 @@ class UNet1DConditionModel(nn.Module):
         num = (out16 - out32).flatten(1).norm(dim=1)
         den = out32.flatten(1).norm(dim=1).clamp_min(1e-30)
         finite = bool(torch.isfinite(out16).all())
-        self.precision_error_seen = float(num.norm() / den.norm()) if finite else float("inf")
-        self.precision_error_worst_item = float((num / den).max()) if finite else float("inf")
-        if self.precision_error_seen <= self.precision_check and self.precision_error_worst_item <= self.precision_check:
+        seen = float(num.norm() / den.norm()) if finite else float("inf")
+        worst = float((num / den).max()) if finite else float("inf")
+        # (the figures reported are the worst over the measurements taken on these weights)
+        self.precision_error_seen = max(seen, self.precision_error_seen) if (late and self.precision_error_seen is not None) else seen
+        self.precision_error_worst_item = max(worst, self.precision_error_worst_item) if (late and self.precision_error_worst_item is not None) else worst
+        if seen <= self.precision_check and worst <= self.precision_check:
             e32.close()
             return out16
         warnings.warn(f"UNet1DConditionModel(engine_precision='auto'): the fp16 engine is {self.precision_error_seen:.2e} (relative L2 over the batch; worst "
@@ -317,11 +332,25 @@ class UNet1DConditionModel(nn.Module):
             eng.set_content(content, stream=stream)
             eng.forward(x, ts, out, stream=stream)
             self.engine_calls += 1
-            if self._auto and self._precision == "fp16" and self.precision_check is not None and self._precision_checked_key != self._engine_key[1]:
-                out = self._auto_check(eng, out, x, ts, content, prompt, mask, (B, T, Lp), stream)
-                if self._precision != "fp16":        # demoted: `out` already is the fp32 engine's result
-                    out = out.to(sample.dtype)
-                    return UNet1DConditionOutput(sample=out) if return_dict else (out,)
+            if self._auto and self._precision == "fp16" and self.precision_check is not None:
+                import time as _time
+                wkey = self._engine_key[1]
+                first = self._precision_checked_key != wkey
+                late = (not first) and self._late_checked_key != wkey and float(ts.max()) < self.late_check_below
+                due = self._last_check_time is None or (_time.monotonic() - self._last_check_time) >= self.check_min_interval_s
+                if first and not due:
+                    # weights changed again within the interval: the previous verdict (fp16 inside the bar) stands for them too
+                    self._precision_checked_key = wkey
+                    self._warn_once("auto-rate", "UNet1DConditionModel(engine_precision='auto'): the weights change more often than once per "
+                                    f"{self.check_min_interval_s:g} s; the fp16-vs-fp32 check is rate-limited and the last verdict stands in between "
+                                    "(set engine_precision explicitly for a module under training)")
+                elif first or late:
+                    if late:
+                        self._late_checked_key = wkey
+                    out = self._auto_check(eng, out, x, ts, content, prompt, mask, (B, T, Lp), stream, late=late)
+                    if self._precision != "fp16":        # demoted: `out` already is the fp32 engine's result
+                        out = out.to(sample.dtype)
+                        return UNet1DConditionOutput(sample=out) if return_dict else (out,)
             if self._ln_guard_after(eng, stream):      # first call of this plan found LayerNorm rows above the threshold: redo on the explicit plan
                 return self.forward(sample, timestep, encoder_hidden_states, encoder_attention_mask=encoder_attention_mask, return_dict=return_dict)
         out = out.to(sample.dtype)
