@@ -275,7 +275,7 @@ def family_table(eng, stream, ops_path=""):
 
 
 def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
-    """Dominant kernel family = implicit GEMM (conv3ts_kernel + gemm4_kernel + the fused feed-forward ffn_kernel + rowchain_kernel).
+    """Dominant kernel family = implicit GEMM (conv3ts_kernel + gemm4_kernel + the fused feed-forward ffn_kernel + geglu_kernel + rowchain_kernel).
     `achieved` is what the family reaches INSIDE the timed loop: its algorithmic FLOP / (step time x the family's share of the
     step), the share taken from the per-launch HIP-event timings (rocprofv3 cannot run inside bench.py; its kernel-trace
     figure for the same command is stamped as `rocprof` when profiles/ holds one for this shape and precision).  `isolated`
@@ -321,7 +321,7 @@ def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
                        "source": f"profiles/{fn}", "command": fj.get("source"), "measured_at": fj.get("commit")}
             break
     return {
-        "bound": "mfma", "kernel": "implicit-GEMM family: conv3ts_kernel (conv1d k3, tap-sharing) + gemm4_kernel (stride-2 / upsample convs, conv1d k1, linear) + ffn_kernel (fused feed-forward) + rowchain_kernel (token-local linear chains)",
+        "bound": "mfma", "kernel": "implicit-GEMM family: conv3ts_kernel (conv1d k3, tap-sharing) + gemm4_kernel (stride-2 / upsample convs, conv1d k1, linear) + ffn_kernel (fused feed-forward) + geglu_kernel (token-stationary GEGLU projection, dim 384) + rowchain_kernel (token-local linear chains)",
         "achieved": gemm_tflops, "peak": peak, "unit": "TFLOP/s", "frac": gemm_tflops / peak,
         "achieved_method": "family FLOP / (timed ms_per_step x the family's share of the per-launch HIP-event times)",
         "family_share_of_step": share, "family_ms_in_loop": loop_ms,

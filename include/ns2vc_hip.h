@@ -296,6 +296,24 @@ int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, 
 int ns2vc_pack_ffn_pre(const float* w1_packed_host, const float* w2f_host, const float* w0_host, int dim, int precision, void** out_stream_dev);
 int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream);
 
+/* r5: token-stationary GEGLU projection (csrc/geglu.hip; 16-bit precisions, dim 384): h = (n W1v^T + b1v) * gelu(n W1g^T + b1g),
+ * n = LayerNorm(y) by linearity -- BasicTransformerBlock.ff.net.0 (reference unet1d/attention.py:178-203, GEGLU 206-301) of the blocks
+ * whose hidden tensor does not fit the fused ns2vc_k_ffn.  128 tokens stay in LDS, four workgroups per token block sweep a quarter of
+ * the hidden units each; out_op [M][ldo] (>= 4 dim columns) operand-typed.  yn = the RAW operand copy of y [M][ldy]; ln_stats as in
+ * ns2vc_gemm_args.ln_stats ([M][dim/64] (sum, sumsq)); wstream / consts from ns2vc_pack_geglu. */
+typedef struct ns2vc_geglu_args {
+  const void* yn; int32_t ldy;
+  const float* ln_stats; float ln_eps;
+  const void* wstream; const float* consts;
+  void* out_op; int32_t ldo;
+  int32_t M, dim;
+  unsigned* ln_health;                      /* optional, as in ns2vc_gemm_args */
+} ns2vc_geglu_args;
+/* w1_packed [8*dim][dim], bias1_packed [8*dim] (or NULL): LayerNorm-folded ff.net.0 rows / bias in the packed (32 value | 32 gate) order,
+ * fp32 host.  Returns the device tile stream and the device constants ((rowsum of the rounded row, bias) per stream row). */
+int ns2vc_pack_geglu(const float* w1_packed_host, const float* bias1_packed_host, int dim, int precision, void** out_stream_dev, float** out_consts_dev);
+int ns2vc_k_geglu(const ns2vc_geglu_args* a, int precision, void* stream);
+
 /* Two token-local GEMMs with a LayerNorm in between, in one launch (csrc/rowchain.hip; 16-bit precisions, dim 128 / 256):
  *   y = A W1^T + bias1 (+ res)  -> out1_f32 (optional);   z = LayerNorm(y) W2'^T + b2'  -> out2_op   (gamma/beta folded into W2' / b2')
  * Replaces Transformer2DModel.proj_in + BasicTransformerBlock.norm1 + attn1.to_q|to_k|to_v (transformer_1d.py:270-279,

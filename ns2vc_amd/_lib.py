@@ -73,6 +73,17 @@ class FfnArgs(C.Structure):
     ]
 
 
+class GegluArgs(C.Structure):
+    _fields_ = [
+        ("yn", C.c_void_p), ("ldy", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_eps", C.c_float),
+        ("wstream", C.c_void_p), ("consts", C.c_void_p),
+        ("out_op", C.c_void_p), ("ldo", C.c_int32),
+        ("M", C.c_int32), ("dim", C.c_int32),
+        ("ln_health", C.c_void_p),
+    ]
+
+
 class RowchainArgs(C.Structure):
     _fields_ = [
         ("a_op", C.c_void_p), ("lda", C.c_int32),
@@ -168,6 +179,8 @@ PROTOTYPES = {
     "ns2vc_pack_ffn": (_I, [_P, _P, _I, _I, _PP]),
     "ns2vc_pack_ffn_pre": (_I, [_P, _P, _P, _I, _I, _PP]),
     "ns2vc_k_ffn": (_I, [C.POINTER(FfnArgs), _I, _P]),
+    "ns2vc_pack_geglu": (_I, [_P, _P, _I, _I, _PP, _PP]),
+    "ns2vc_k_geglu": (_I, [C.POINTER(GegluArgs), _I, _P]),
     "ns2vc_pack_rowchain": (_I, [_P, _P, _I, _I, _I, _PP]),
     "ns2vc_pack_rowchain_sliced": (_I, [_P, _P, _I, _I, _I, _I, _PP]),
     "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),

@@ -27,8 +27,14 @@ hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, 
 hipError_t pack_rowchain_stream(const float* w1, const float* w2, int dim, int n2, int prec, std::vector<unsigned short>& out, int slices = 1);
 int rowchain_slice_blocks(int n2, int slices);   // rowchain.hip
 void set_ffn_trace(unsigned long long* p);
+typedef ::ns2vc_geglu_args GegluArgs;
+bool geglu_eligible(int dim, int T, int prec);                                                                                                       // geglu.hip
+hipError_t pack_geglu_stream(const float* w1p, const float* bias1p, int dim, int prec, std::vector<unsigned short>& stream, std::vector<float>& consts);
+hipError_t launch_geglu(const GegluArgs& a, int prec, hipStream_t s);
+hipError_t init_geglu_attributes();
 void set_rc_trace(unsigned long long* p);
 void set_ts_trace(unsigned long long* p);
+void set_gg_trace(unsigned long long* p);
 void set_attn_optimistic(int on);
 }
 
@@ -83,6 +89,8 @@ struct AttnW {
   void* ffn_pre_stream = nullptr; // the same stream with attn2.to_out in front (pre-stage of the fused kernel)
   void* ffn_stream = nullptr;     // fused feed-forward + proj_out (ffn.hip): weight tile stream ...
   float* ffn_consts = nullptr;    // ... and (rowsum, bias) per packed ff.net.0 row; 16-bit precisions, dim <= 256 only
+  void* geglu_stream = nullptr;   // token-stationary GEGLU projection (geglu.hip): weight tile stream and constants; 16-bit precisions, dim 384
+  float* geglu_consts = nullptr;
   // token-local chains (rowchain.hip; 16-bit precisions, dim <= 256): proj_in -> norm1 -> q|k|v and attn1.to_out -> norm2 -> attn2.to_q
   void *chain_in = nullptr, *chain_mid = nullptr;          // weight tile streams
   void* chain_in_s2 = nullptr;                              // ... of the first chain packed for two N-slices (dim 384, r4)
@@ -153,6 +161,7 @@ struct ns2vc_unet {
   bool fuse_rows = true;     // proj_in+q|k|v and attn1.to_out+attn2.to_q as one launch each (rowchain.hip)
   bool attn_fp8 = false;     // PV product of every attention on the fp8 MFMA (16-bit precisions; BASELINE config 5's fp8 path; costs parity)
   bool fuse_ffn_pre = true;  // attn2.to_out + residual computed inside the fused feed-forward kernel
+  bool fuse_geglu = true;    // r5: token-stationary GEGLU projection (csrc/geglu.hip) where the fused feed-forward does not apply (dim 384)
   bool fuse_rows_gn = true;  // ... and the transformer's GroupNorm computed in the prologue of the first of them
   // GroupNorm-apply as the prologue of the GEMM that consumes it (gemm.hip gn_prologue, ns2vc_gemm_args.gnp_*) wherever the norm has
   // one source, one consumer and epilogue statistics: resnet norm2 -> conv2, norm1 -> conv1 of the resnets without a
@@ -633,6 +642,17 @@ int pack_all(ns2vc_unet* h) {
         } else {
           a.ffn_stream = nullptr; a.ffn_pre_stream = nullptr; a.ffn_consts = nullptr;
         }
+        if (geglu_eligible(d, 1, h->prec)) {                   // token-stationary GEGLU projection (csrc/geglu.hip)
+          std::vector<unsigned short> st;
+          std::vector<float> cs;
+          if (pack_geglu_stream(ff1_rows.data(), ff1_bias.data(), d, h->prec, st, cs) != hipSuccess) return fail("geglu stream packing failed");
+          void* dev = nullptr;
+          if (hipMalloc(&dev, st.size() * 2) != hipSuccess) return fail("hipMalloc failed (weights)");
+          h->weight_allocs.push_back(dev);
+          if (hipMemcpy(dev, st.data(), st.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed (weights)");
+          a.geglu_stream = dev;
+          a.geglu_consts = P.upload_f32(cs);
+        }
       }
       {  // cross-attention k|v of this block into the hoisted all-blocks projection
         const HostTensor& wk = P.T(t + ".attn2.to_k.weight");
@@ -970,10 +990,21 @@ struct Planner {
       return;
     }
     if (!r3) layernorm(t + ".norm3");
-    g = base(yn, d, d, Tl, Tl, a.ff1, nullptr, ffh, 4 * d);
-    g.geglu = 1;
-    consume(g, r3, a.ff1);
-    gemm(t + ".ff.geglu", g);
+    if (r3 && h->fuse_geglu && a.geglu_stream && geglu_eligible(d, Tl, pr)) {
+      // the token rows stay in LDS, only weights stream (csrc/geglu.hip): half the L2 -> LDS bytes of the GEMM below
+      ns2vc_geglu_args f;
+      memset(&f, 0, sizeof(f));
+      f.yn = yn; f.ldy = d; f.ln_stats = r3; f.ln_eps = 1e-5f;
+      f.wstream = a.geglu_stream; f.consts = a.geglu_consts;
+      f.out_op = ffh; f.ldo = 4 * d; f.M = M; f.dim = d; f.ln_health = h->ln_health;
+      add(t + ".ff.geglu[token-stationary]", [=](hipStream_t s) { return launch_geglu(f, pr, s); }, 1, 2.0 * M * (double)d * 8.0 * d,
+          (double)M * d * opsz * 5.0 + (double)M * (d / 64) * 8.0 + 8.0 * d * d * opsz);
+    } else {
+      g = base(yn, d, d, Tl, Tl, a.ff1, nullptr, ffh, 4 * d);
+      g.geglu = 1;
+      consume(g, r3, a.ff1);
+      gemm(t + ".ff.geglu", g);
+    }
     if (fold) {
       // out = [Wpo W2 | Wpo] [ffh | yn] + (Wpo b2 + bpo) + x : ff.net.2 and proj_out in one launch
       g = base(ffh, 4 * d, 4 * d, Tl, Tl, a.ffpo, out, out_op, d);
@@ -1274,6 +1305,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "gn_coop")) return &h->gn_coop;
   if (!strcmp(name, "fuse_gn_cat")) return &h->fuse_gn_cat;
   if (!strcmp(name, "fuse_ffn_pre")) return &h->fuse_ffn_pre;
+  if (!strcmp(name, "fuse_geglu")) return &h->fuse_geglu;
   if (!strcmp(name, "attn_fp8")) return &h->attn_fp8;
   if (!strcmp(name, "attn_optimistic")) return &h->attn_optimistic;
   if (!strcmp(name, "slice_rows")) return &h->slice_rows;
@@ -1345,6 +1377,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   if (e == hipSuccess) e = init_convts_attributes();
   if (e == hipSuccess) e = init_attn_attributes();
   if (e == hipSuccess) e = init_ffn_attributes();
+  if (e == hipSuccess) e = init_geglu_attributes();
   if (e == hipSuccess) e = init_rowchain_attributes();
   if (e != hipSuccess) return fail("kernel attribute setup failed: %s (is a gfx950 GPU visible?)", hipGetErrorString(e));
   auto* h = new ns2vc_unet();
@@ -1365,7 +1398,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
     static const struct { const char* env; const char* opt; } sw[] = {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
-      {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
+      {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
       {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
@@ -1451,7 +1484,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -1840,6 +1873,7 @@ int ns2vc_pack_weight(const float* rows_host, int N, int K, int precision, void*
   if (e == hipSuccess) e = init_convts_attributes();
     if (e == hipSuccess) e = init_attn_attributes();
     if (e == hipSuccess) e = init_ffn_attributes();
+    if (e == hipSuccess) e = init_geglu_attributes();
     if (e == hipSuccess) e = init_rowchain_attributes();
     if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
     inited = true;
@@ -1884,7 +1918,8 @@ int ns2vc_debug_set_gemm_trace(void* dev_u64_blocks_x8) {
   set_gemm_trace((unsigned long long*)dev_u64_blocks_x8);
   set_ffn_trace((unsigned long long*)dev_u64_blocks_x8);
   set_rc_trace((unsigned long long*)dev_u64_blocks_x8);
-  set_ts_trace((unsigned long long*)dev_u64_blocks_x8);     // (convts.hip writes 16 words per block)
+  set_ts_trace((unsigned long long*)dev_u64_blocks_x8);     // (convts.hip and geglu.hip write 16 words per block)
+  set_gg_trace((unsigned long long*)dev_u64_blocks_x8);
   return 0;
 }
 int ns2vc_debug_poison(unsigned pattern, int lds_bytes, void* stream) {
@@ -1999,6 +2034,29 @@ int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_ffn(*a, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("launch_ffn: %s", hipGetErrorString(e));
+  return 0;
+}
+int ns2vc_pack_geglu(const float* w1_packed_host, const float* bias1_packed_host, int dim, int precision, void** out_stream_dev, float** out_consts_dev) {
+  if (!w1_packed_host || !out_stream_dev || !out_consts_dev) return fail("null argument");
+  hipError_t e = init_geglu_attributes();
+  if (e != hipSuccess) return fail("kernel attribute setup failed: %s", hipGetErrorString(e));
+  std::vector<unsigned short> st;
+  std::vector<float> cs;
+  if (pack_geglu_stream(w1_packed_host, bias1_packed_host, dim, precision, st, cs) != hipSuccess) return fail("geglu: dim must be 384 and the precision 16-bit");
+  void* d = nullptr;
+  float* c = nullptr;
+  HIPCHK(hipMalloc(&d, st.size() * 2));
+  HIPCHK(hipMemcpy(d, st.data(), st.size() * 2, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc((void**)&c, cs.size() * 4));
+  HIPCHK(hipMemcpy(c, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+  *out_stream_dev = d;
+  *out_consts_dev = c;
+  return 0;
+}
+int ns2vc_k_geglu(const ns2vc_geglu_args* a, int precision, void* stream) {
+  if (!a) return fail("null args");
+  hipError_t e = launch_geglu(*a, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("launch_geglu: %s", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_attention(const ns2vc_attn_args* a, int head_dim, int precision, void* stream) {

@@ -833,6 +833,76 @@ def test_gemm_bench_shapes(case, prec, diag):
 
 
 @pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("M,ldo_extra", [(7520, 0), (128, 0), (97, 64), (1, 0), (1285, 8)], ids=str)
+def test_geglu_token_stationary(M, ldo_extra, prec, diag):
+    """The token-stationary GEGLU projection (csrc/geglu.hip, dim 384) against numpy fp64 of
+        h = (n W1v^T + b1v) * gelu(n W1g^T + b1g),  n = LayerNorm(y)
+    with the engine's pack-time folds (gamma / beta into W1 / b1, value|gate row interleave) and the kernel's rounding points (operands rounded,
+    LayerNorm by linearity from the per-64-channel row sums).  Row counts: the benchmarked 7520 (59 token blocks, the last one short), one full
+    block, a short one, a single row, an odd count; an output pitch wider than 4 dim leaves the columns beyond untouched.  Every result element
+    is written exactly once: the buffer starts as NaN."""
+    from scipy.special import erf
+    from ns2vc_amd._lib import GegluArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    d = 384
+    rng = np.random.default_rng(M * 7 + prec)
+    y = (rng.standard_normal((M, d)) + 1.5 * rng.standard_normal((M, 1))).astype(np.float32)
+    gamma, beta = (1.0 + 0.2 * rng.standard_normal(d)), 0.2 * rng.standard_normal(d)
+    W1, b1 = rng.standard_normal((8 * d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(8 * d)
+    W1f, b1f = W1 * gamma[None, :], b1 + W1 @ beta
+    order = np.concatenate([np.concatenate([np.arange(32 * g, 32 * g + 32), 4 * d + np.arange(32 * g, 32 * g + 32)]) for g in range(4 * d // 32)])
+    W1p, b1p = np.ascontiguousarray(W1f[order].astype(np.float32)), np.ascontiguousarray(b1f[order].astype(np.float32))
+    W1r, yr = rnd(W1p, prec).astype(np.float64), rnd(y, prec).astype(np.float64)
+    y64 = y.astype(np.float64)
+    mean, var = y64.mean(1, keepdims=True), y64.var(1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + 1e-5)
+    pre = rstd * (yr @ W1r.T - mean * W1r.sum(1).astype(np.float32).astype(np.float64)[None, :]) + b1p.astype(np.float64)[None, :]
+    pg = pre.reshape(M, 4 * d // 32, 2, 32)
+    ref = (pg[:, :, 0] * 0.5 * pg[:, :, 1] * (1.0 + erf(pg[:, :, 1] / np.sqrt(2.0)))).reshape(M, 4 * d)
+    ys = y64.reshape(M, d // 64, 64)
+    stats = np.stack([ys.sum(2), (ys ** 2).sum(2)], axis=-1).astype(np.float32)
+    stream, consts = C.c_void_p(), C.c_void_p()
+    check(lib.ns2vc_pack_geglu(W1p.ctypes.data, b1p.ctypes.data, d, prec, C.byref(stream), C.byref(consts)), "pack_geglu")
+    ldo = 4 * d + ldo_extra
+    d_y, d_st = OpBuf(y, prec), _dev(stats)
+    d_h = OpBuf(np.full((M, ldo), np.nan, dtype=np.float32), prec)
+    d_health = DevBuf.from_numpy(np.zeros(16, dtype=np.uint32))
+    f = GegluArgs()
+    f.yn = d_y.ptr; f.ldy = d; f.ln_stats = d_st.ptr; f.ln_eps = 1e-5
+    f.wstream = stream.value; f.consts = consts.value
+    f.out_op = d_h.ptr; f.ldo = ldo; f.M = M; f.dim = d; f.ln_health = d_health.ptr
+    check(lib.ns2vc_k_geglu(C.byref(f), prec, None), "k_geglu")
+    sync()
+    h = d_h.read().reshape(M, ldo)
+    out = h[:, :4 * d]
+    e = rel_l2(out, ref)
+    ratio = float(d_health.to_numpy((16,), dtype=np.uint32)[:1].view(np.float32)[0])
+    diag(f"geglu token-stationary M={M} ldo={ldo} prec={prec}: rel_l2 {e:.3e} (rounding {eps16(prec):.1e}) nan={int(np.isnan(out).sum())} |mean|/std {ratio:.2f}")
+    # the result is stored in the operand type: it must be the rounded reference up to one-ulp flips where fp32 accumulation moved a value across a tie
+    flips = float(np.mean(out != rnd(ref.astype(np.float32), prec)))
+    if not (e < eps16(prec) and flips < 0.03):
+        err = np.abs(out - ref)
+        bad = np.argwhere(~(err <= 2e-2 + 2e-2 * np.abs(ref)))
+        diag(f"  FAIL: flips {flips:.4f}; {len(bad)} bad of {out.size}; rows {sorted(set(bad[:, 0].tolist()))[:16]} cols {sorted(set(bad[:, 1].tolist()))[:24]}")
+    assert np.isfinite(out).all() and e < eps16(prec) and flips < 0.03
+    assert np.isnan(h[:, 4 * d:]).all()
+    assert (0.2 if M > 1 else 0.0) < ratio < 12.0      # (max over rows of |mean| / std: a single row can have any)
+    # the same launch twice: bitwise equal (no accumulation order depends on timing)
+    d_h2 = OpBuf(np.full((M, ldo), np.nan, dtype=np.float32), prec)
+    f.out_op = d_h2.ptr
+    check(lib.ns2vc_k_geglu(C.byref(f), prec, None), "k_geglu")
+    sync()
+    assert np.array_equal(d_h2.read().reshape(M, ldo)[:, :4 * d], out)
+    # refused: any other dim, a misaligned output
+    f.dim = 256
+    assert lib.ns2vc_k_geglu(C.byref(f), prec, None) != 0
+    f.dim = d; f.out_op = d_h2.ptr + 2
+    assert lib.ns2vc_k_geglu(C.byref(f), prec, None) != 0
+    lib.ns2vc_dev_free(stream); lib.ns2vc_dev_free(consts)
+
+
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
 @pytest.mark.parametrize("prestage", [False, True], ids=["plain", "pre"])
 @pytest.mark.parametrize("dim,B,T", [(128, 3, 150), (256, 2, 97), (128, 1, 64), (256, 5, 200)], ids=str)
 def test_ffn_fused(dim, B, T, prestage, prec, diag):

@@ -15,7 +15,7 @@ def short(name):
 
 
 def family(k):
-    if k.startswith(("gemm", "conv3ts", "ffn", "rowchain", "splitk")):
+    if k.startswith(("gemm", "conv3ts", "ffn", "geglu", "rowchain", "splitk")):
         return "implicit_gemm"
     if k.startswith("attn"):
         return "attention"

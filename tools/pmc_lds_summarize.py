@@ -13,7 +13,7 @@ out = {"source": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INS
                  "--skip-fp32 --steps 4 --warmup 4 --reps 1 (own pass)", "commit": os.environ.get("NS2VC_COMMIT"), "kernels": {}}
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", 0)):
     a, c = v.get("SQ_ACTIVE_INST_LDS", 0.0), v.get("SQ_LDS_BANK_CONFLICT", 0.0)
-    if not k.startswith(("gemm", "conv3ts", "attn", "ffn", "rowchain", "gn_apply", "time_embed", "solver")):
+    if not k.startswith(("gemm", "conv3ts", "attn", "ffn", "geglu", "rowchain", "gn_apply", "time_embed", "solver")):
         continue
     out["kernels"][k] = {"launches": launches[k], "lds_insts": v.get("SQ_INSTS_LDS", 0.0), "lds_active_cycles": a, "bank_conflict_cycles": c,
                          "conflict_fraction_of_lds_active": round(c / a, 4) if a else None}

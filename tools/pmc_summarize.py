@@ -16,7 +16,7 @@ def short(name):
 
 
 def family(k):
-    if k.startswith(("gemm", "conv3ts", "ffn", "rowchain", "splitk")):      # the kind-1 launches of the engine plan (bench.py family table)
+    if k.startswith(("gemm", "conv3ts", "ffn", "geglu", "rowchain", "splitk")):      # the kind-1 launches of the engine plan (bench.py family table)
         return "implicit_gemm"
     if k.startswith("attn"):
         return "attention"

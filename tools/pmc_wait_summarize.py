@@ -16,7 +16,7 @@ for r in csv.DictReader(open(src)):
 out = {"source": "rocprofv3 --pmc " + " ".join(sorted(names)) + " --kernel-trace -- python bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 4 --warmup 4 --reps 1 (own pass)",
        "commit": os.environ.get("NS2VC_COMMIT"), "kernels": {}}
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
-    if not k.startswith(("gemm", "conv3ts", "attn", "ffn", "rowchain")):
+    if not k.startswith(("gemm", "conv3ts", "attn", "ffn", "geglu", "rowchain")):
         continue
     wc = v.get("SQ_WAVE_CYCLES", 0.0) or 1.0
     row = {"launches": launches[k]}
