@@ -27,12 +27,18 @@
 #ifndef NS2VC_GEMM_TRACE
 #define NS2VC_GEMM_TRACE 0
 #endif
+#ifndef NS2VC_GG_PRIO
+#define NS2VC_GG_PRIO 0
+#endif
+#ifndef NS2VC_GG_PINGPONG
+#define NS2VC_GG_PINGPONG 1   // 1: the two waves of a SIMD alternate between a load segment and a compute segment, half a step apart; 0: all eight waves in lock step
+#endif
 
 namespace ns2vc {
 
 typedef ::ns2vc_geglu_args GegluArgs;
 
-// optional per-workgroup phase timing (cycle counter, wave 0): [block][16] = entry, prologue end, then sums over the steps: wait for the tile (vmcnt),
+// optional per-wave phase timing (cycle counter): [block][wave][16] = entry, prologue end, then sums over the steps: wait for the tile (vmcnt),
 // barrier, tile issue + fragment reads issued, MFMAs + GEGLU chunk (to completion), stores; exit.  Only in trace builds (`make TRACE=1`), set through
 // ns2vc_debug_set_gemm_trace, read by tools/geglu_trace.py
 __device__ unsigned long long* g_gg_trace = nullptr;
@@ -48,14 +54,15 @@ void set_gg_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 constexpr int GG_TILE = 128 * 128;      // bytes: [128 rows][128 B of K]
 constexpr int GG_TOK = 128;             // tokens per workgroup
 constexpr int GG_SPLIT = 4;             // workgroups per token block (hidden-unit quarters)
-constexpr int GG_RING = 9;              // weight tiles resident in LDS (eight in flight: the stream is latency-bound, bytes in flight per CU set its rate)
+constexpr int GG_RING = 8;              // weight tiles resident in LDS (seven in flight: the stream is latency-bound, bytes in flight per CU set its rate)
 
 template <int D> struct GegluGeom {
   static constexpr int KT = D / 64;                          // K tiles
   static constexpr int UB = 4 * D / 64 / GG_SPLIT;           // 64-unit blocks per workgroup (each = one 128-row tile per K tile)
   static constexpr int NP = UB * KT;                         // weight tiles per workgroup
   static constexpr int CONSTS = UB * 128 * 8;                // bytes: (rowsum, bias) per stream row of this workgroup's quarter
-  static constexpr int LDS = GG_RING * GG_TILE + CONSTS;
+  static constexpr int STAGE = 4 * 32 * 128;                 // bytes: result staging, [token quarter][32 tokens][64 units] per unit block
+  static constexpr int LDS = GG_RING * GG_TILE + CONSTS + STAGE;
   static_assert(LDS <= 160 * 1024, "LDS budget");
   static_assert((4 * D / 64) % GG_SPLIT == 0, "whole unit blocks per quarter");
   static_assert(KT % 2 == 0, "fragment double buffer: the parity of a step is the parity of its K tile");
@@ -115,7 +122,9 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
   };
   // ---- DMA: the token rows (96 KB = ring slots 3 .. 8 for now: whole 128-byte rows, each fetched once per workgroup; source-side swizzle, rows
   // past M read as zeros), the constants, the first three weight tiles
-  constexpr int PANEL0 = 3 * GG_TILE;
+  constexpr int NT0 = RING - KT * GG_TOK * 128 / GG_TILE;     // weight tiles that fit beside the token panel at the start
+  static_assert(NT0 >= 1, "room for a first weight tile beside the token panel");
+  constexpr int PANEL0 = NT0 * GG_TILE;
   static_assert(PANEL0 + KT * GG_TOK * 128 <= RING * GG_TILE, "the token panel fits in the ring slots it borrows");
   {
     const i32x4_t rY = make_rsrc(a.yn, (unsigned long long)a.M * a.ldy * 2ull);
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     }
   }
 #pragma unroll
-  for (int p0 = 0; p0 < 3; ++p0) issue_tile(p0, p0);
+  for (int p0 = 0; p0 < NT0; ++p0) issue_tile(p0, p0);
 
   // ---- LayerNorm statistics of this lane's token (ordinary loads: the compiler waits for them -- and, not seeing the DMA above, for everything
   // issued so far: that is the wait for the panel)
@@ -182,7 +191,9 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) tk[kt][ks] = *reinterpret_cast<const u32x4_t*>(trow + kt * (GG_TOK * 128) + ((2 * ks + hi) ^ sw) * 16);
+#if !NS2VC_GG_PINGPONG
     read_frags(0, fw[0]);
+#endif
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
@@ -190,8 +201,11 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                   // everyone has its tokens: the panel's slots join the ring
 #pragma unroll
-    for (int p0 = 3; p0 < RING; ++p0) issue_tile(p0, p0);
+    for (int p0 = NT0; p0 < RING; ++p0) issue_tile(p0, p0);
   }
+#if NS2VC_GG_PRIO
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // static priority for the second-dispatched half (the arbitration loser on every step otherwise)
+#endif
   const unsigned long long t_pro = GG_NOW();
   (void)t_pro;
   tmark = t_pro;
@@ -235,19 +249,94 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     hp[2 * j] = Op16<TM>::pack(hh[0], hh[1]);
     hp[2 * j + 1] = Op16<TM>::pack(hh[2], hh[3]);
   };
-  // result stores: buffer stores with the descriptor in SGPRs and ONE 32-bit offset register per lane (a 64-bit address per lane would not fit beside
-  // 96 token + 64 accumulator + 64 fragment registers: spilled, its reload drained the DMA queue once per unit block); a lane past M carries an
-  // out-of-range offset: the hardware drops its store, and every wave issues the same number of stores
+  // Result stores.  A lane holds 16 units of ONE token: stored from the registers, every instruction is 64 scattered 16-byte pieces in 32 rows, and the
+  // store path -- not the MFMAs, not the weight stream -- set the kernel's time (with everything else removed from the loop it still ran 25 of its
+  // 38 us).  So a unit block goes through LDS: the two waves of a token quarter write their halves of [32 tokens][64 units] (swizzled 16-byte chunks),
+  // and after the next barrier each stores 16 of the rows: two instructions of 8 full 128-byte lines.  Buffer stores: descriptor in SGPRs, one
+  // 32-bit offset register per lane; a row past M carries an out-of-range offset (the hardware drops it), so every wave issues the same stores.
+  char* const stage = smem + RING * GG_TILE + G::CONSTS + tq * (32 * 128);
   const i32x4_t rO = uniform_rsrc(make_rsrc(a.out_op, (unsigned long long)a.M * (unsigned long long)a.ldo * 2ull));
-  const unsigned ooff = mtok < a.M ? ((unsigned)mtok * (unsigned)a.ldo + (unsigned)(q * UB * 64 + hg * 32 + 16 * hi)) * 2u : 0xC0000000u;   // (no wrap-around with the instruction offset)
-  auto store_block = [&](int ubp) __attribute__((always_inline)) {
-    // hidden units ((q UB + ubp) 2 + hg) 32 + 16 hi .. + 15 of this token: 32 consecutive bytes
-    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ubp * 128);
+  const int srow = 16 * hg + (lane >> 3);           // staged row this lane stores (and + 8)
+  unsigned ooff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + 32 * tq + srow + 8 * j;
+    ooff[j] = m < a.M ? ((unsigned)m * (unsigned)a.ldo + (unsigned)(q * UB * 64)) * 2u + (unsigned)((lane & 7) * 16) : 0xC0000000u;
+  }
+  auto stage_block = [&]() __attribute__((always_inline)) {
+    // units 32 hg + 16 hi .. + 15 of token l31: chunks 4 hg + 2 hi, + 1 of its row
+    char* row = stage + l31 * 128;
+    const int c0 = 4 * hg + 2 * hi, x = l31 & 7;
     const u32x4_t v0 = {hp[0], hp[1], hp[2], hp[3]}, v1 = {hp[4], hp[5], hp[6], hp[7]};
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen " NS2VC_WT_MOD "\n\tbuffer_store_dwordx4 %4, %1, %2, %3 offen offset:16 " NS2VC_WT_MOD "\n\ts_nop 1"
-                 :: "v"(v0), "v"(ooff), "s"(rO), "s"(so), "v"(v1) : "memory");
+    *reinterpret_cast<u32x4_t*>(row + ((c0 ^ x) * 16)) = v0;
+    *reinterpret_cast<u32x4_t*>(row + (((c0 + 1) ^ x) * 16)) = v1;
+  };
+  auto store_block = [&](int ubp) __attribute__((always_inline)) {
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ubp * 128);
+    const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(stage + srow * 128 + (((lane & 7) ^ (srow & 7)) * 16));
+    const u32x4_t v1 = *reinterpret_cast<const u32x4_t*>(stage + (srow + 8) * 128 + (((lane & 7) ^ (srow & 7)) * 16));
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen " NS2VC_WT_MOD "\n\tbuffer_store_dwordx4 %4, %5, %2, %3 offen " NS2VC_WT_MOD "\n\ts_nop 1"
+                 :: "v"(v0), "v"(ooff[0]), "s"(rO), "s"(so), "v"(v1), "v"(ooff[1]) : "memory");
   };
   // MM: a tile is multiplied in this step; EP: a quarter of the previous unit block's GEGLU rides along
+#if NS2VC_GG_PINGPONG
+  // PING-PONG.  Lock-stepped, the two waves of a SIMD want the matrix pipe at the same time and the DMA / LDS / store paths at the same time: measured,
+  // the parts of a step ADD UP (step = MFMAs + fragment reads + DMA issue + GEGLU, ~2000 cycles) instead of overlapping.  So waves 4 .. 7 (the SIMD
+  // partners of waves 0 .. 3) run HALF A STEP BEHIND: every step is a load segment (refill a ring slot, read this tile's fragments, stores) and a
+  // compute segment (8 MFMAs with a quarter of the previous block's GEGLU between them), a barrier after each, and one extra barrier at the start
+  // of the late half / the end of the early half.  While one wave of a SIMD multiplies, its partner loads.
+  //   early half:  L0 | C0 | L1 | C1 | ...            late half:  -- | L0 | C0 | L1 | ...
+  // Tile p is read by the early half in tick 2p and by the late half in tick 2p + 1: its slot is refilled (with tile p + RING) from tick 2p + 2 on,
+  // i.e. in the load segment of step p + 1; and it has landed for everyone before tick 2p: every wave waits for its own pieces of tile p + 1 at the
+  // END of its load segment p (for the late half that is the last barrier before the early half reads them).
+  auto step = [&](auto mm_, auto ep_, int kt_, int ub) __attribute__((always_inline)) {
+    constexpr bool MM = decltype(mm_)::value, EP = decltype(ep_)::value;
+    const int kt = kt_;
+    if constexpr (MM) {
+#if !(NS2VC_GG_ABLATE & 4)
+      if (p >= 1 && p - 1 + RING < NP) issue_tile(p - 1 + RING, slot == 0 ? RING - 1 : slot - 1);
+#endif
+#if NS2VC_GG_ABLATE & 8
+      if (p == 0)
+#endif
+      read_frags(slot, fw[0]);
+      GG_ACC(2);
+      if constexpr (EP) { if (kt == 4) { store_block(ub - 1); GG_ACC(4); } }
+#if !(NS2VC_GG_ABLATE & 4)
+      if (p + 1 < NP) gg_wait_tiles<RING - 2>(min(RING - 2, NP - 2 - p));
+#endif
+      GG_ACC(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragments are in registers
+      __builtin_amdgcn_s_barrier();
+      GG_ACC(1);
+      if constexpr (EP) { if (kt < 4) chunk(ub - 1, kt); }
+#if !(NS2VC_GG_ABLATE & 2)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        MmaT<TM>::mma(av, fw[0][ks], tk[kt][ks]);
+        MmaT<TM>::mma(ag, fw[0][4 + ks], tk[kt][ks]);
+      }
+#endif
+      if constexpr (EP) {
+        if (kt < 4) asm volatile("" : "+v"(hp[2 * kt]), "+v"(hp[2 * kt + 1]));     // computed in THIS segment (not sunk to the store)
+        if (kt == 3) { stage_block(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }    // staged before the barrier, stored after it (load segment of step 4)
+      }
+      if (NS2VC_GEMM_TRACE) { asm volatile("" : "+v"(av), "+v"(ag)); }
+      GG_ACC(3);
+      __builtin_amdgcn_s_barrier();
+      GG_ACC(1);
+      ++p;
+      slot = slot + 1 == RING ? 0 : slot + 1;
+    } else {
+      if constexpr (EP) {
+        if (kt < 4) chunk(ub - 1, kt);
+        if (kt == 3) { stage_block(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }   // (the tail: one barrier, the same for everyone)
+        if (kt == 4) store_block(ub - 1);
+      }
+    }
+  };
+  if (wave >= 4) __builtin_amdgcn_s_barrier();      // the late half starts one tick later ...
+#else
   auto step = [&](auto mm_, auto ep_, int kt_, int ub) __attribute__((always_inline)) {
     constexpr bool MM = decltype(mm_)::value, EP = decltype(ep_)::value;
     const int kt = kt_;
@@ -282,12 +371,17 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     }
     if constexpr (EP) {
       if (kt < 4) asm volatile("" : "+v"(hp[2 * kt]), "+v"(hp[2 * kt + 1]));     // computed in THIS step (not sunk to the store four steps later)
+      if (kt == 3) {
+        stage_block();                                // (step 4 begins with lgkmcnt(0) and a barrier)
+        if constexpr (!MM) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+      }
     }
     if (NS2VC_GEMM_TRACE) { asm volatile("" : "+v"(av), "+v"(ag)); GG_ACC(3); }
     if constexpr (EP) {
       if (kt == 4) { store_block(ub - 1); GG_ACC(4); }
     }
   };
+#endif
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
 #pragma unroll
@@ -299,13 +393,16 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) step(T_{}, T_{}, kt, ub);
   }
+#if NS2VC_GG_PINGPONG
+  if (wave < 4) __builtin_amdgcn_s_barrier();       // ... and the early half waits for it once at the end: the same number of barriers for everyone
+#endif
 #pragma unroll
   for (int r = 0; r < 16; ++r) { pv[r] = av[r]; pg[r] = ag[r]; }
 #pragma unroll
   for (int kt = 0; kt < 5; ++kt) step(F_{}, T_{}, kt, UB);
 #if NS2VC_GEMM_TRACE
-  if (g_gg_trace && tid == 0) {
-    unsigned long long* tr = g_gg_trace + (size_t)blockIdx.x * 16;
+  if (g_gg_trace && lane == 0) {
+    unsigned long long* tr = g_gg_trace + ((size_t)blockIdx.x * 8 + wave) * 16;
     tr[0] = t_entry; tr[1] = t_pro;
     for (int i = 0; i < 5; ++i) tr[2 + i] = tacc[i];
     tr[7] = GG_NOW();

@@ -26,23 +26,24 @@ for _ in range(rot):
 f = GegluArgs()
 f.ldy = d; f.ln_stats = stats.ptr; f.ln_eps = 1e-5; f.wstream = stream.value; f.consts = consts.value; f.ldo = 4 * d; f.M = M; f.dim = d
 nblk = ((M + 127) // 128) * 4
-Tr = DevBuf(nblk * 16 * 8)
+Tr = DevBuf(nblk * 8 * 16 * 8)
 for i in range(rot + 2):
     f.yn = Ys[i % rot]; f.out_op = Hs[i % rot].ptr
     check(lib.ns2vc_k_geglu(C.byref(f), PREC, None), "k_geglu")
 sync()
-Tr.upload(np.zeros(nblk * 16, np.uint64))
+Tr.upload(np.zeros(nblk * 8 * 16, np.uint64))
 check(lib.ns2vc_debug_set_gemm_trace(Tr.ptr), "trace")
 f.yn = Ys[2]; f.out_op = Hs[2].ptr
 check(lib.ns2vc_k_geglu(C.byref(f), PREC, None), "k_geglu"); sync()
 check(lib.ns2vc_debug_set_gemm_trace(None), "trace")
-t = Tr.to_numpy((nblk, 16), dtype=np.uint64).astype(np.float64)
-t0 = t[:, 0].min()
-tot = t[:, 7] - t[:, 0]
-names = ["prologue (token rows, first ring, statistics)", "wait for the tile (vmcnt)", "barrier (+ own LDS reads done)", "tile issue + fragment reads issued",
-         "MFMAs + GEGLU chunk, to completion", "stores"]
-cols = [t[:, 1] - t[:, 0]] + [t[:, 2 + i] for i in range(5)]
-print(f"# geglu_kernel M={M}: {nblk} workgroups; entry spread {np.ptp(t[:, 0]):.0f}, exit - first entry max {np.max(t[:, 7]) - t0:.0f}, per-block total median {np.median(tot):.0f} (counter ticks)")
-for n, c in zip(names, cols):
-    print(f"  {n:48s} median {np.median(c):8.0f}  ({100 * np.median(c) / np.median(tot):5.1f} %)   min {c.min():8.0f} max {c.max():8.0f}")
-print(f"  {'unaccounted':48s} median {np.median(tot - sum(cols)):8.0f}")
+t = Tr.to_numpy((nblk, 8, 16), dtype=np.uint64).astype(np.float64)
+t0 = t[:, :, 0].min()
+names = ["prologue", "wait tile (vmcnt)", "barrier", "issue + reads issued", "MFMAs + GEGLU chunk", "stores", "total"]
+print(f"# geglu_kernel M={M}: {nblk} workgroups x 8 waves; entry spread {np.ptp(t[:, :, 0]):.0f}, last exit - first entry {t[:, :, 7].max() - t0:.0f} counter ticks (shader cycles)")
+print("# median over the workgroups, per wave (waves w and w + 4 share a SIMD):")
+print("  wave " + " ".join(f"{n:>22s}" for n in names))
+for w in range(8):
+    tw = t[:, w]
+    tot = tw[:, 7] - tw[:, 0]
+    cols = [tw[:, 1] - tw[:, 0]] + [tw[:, 2 + i] for i in range(5)] + [tot]
+    print(f"  {w:4d} " + " ".join(f"{np.median(c):22.0f}" for c in cols))
