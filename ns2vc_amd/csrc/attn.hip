@@ -419,8 +419,28 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   const auto lsw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o[LB][LR]), __float_as_uint(o[LB][LR]), false, false);
   const float l_tot = __uint_as_float(lsw[0]);
   const float inv = 1.0f / l_tot;
-  if (q < a.Lq) {
-    TM* op = reinterpret_cast<TM*>(a.out) + ((size_t)(b * a.Lq + q) * a.ldo + h * HD);
+  TM* op = reinterpret_cast<TM*>(a.out) + ((size_t)(b * a.Lq + min(q, a.Lq - 1)) * a.ldo + h * HD);
+  if constexpr (SZ == 2) {
+    // 16-bit results: the two lane halves of a query trade 4-element groups so that every lane stores 8 consecutive d (16 B) -- half the store
+    // instructions of the 8-byte form, and the output of a workgroup is nothing but row-per-lane pieces whose issue sets its tail (r5: without
+    // any output store the step ran 2.2 % faster)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {
+        if (d * 32 + 16 * gp < HD) {
+          const uint32_t a0 = Op16<TM>::pack(o[d][8 * gp] * inv, o[d][8 * gp + 1] * inv), a1 = Op16<TM>::pack(o[d][8 * gp + 2] * inv, o[d][8 * gp + 3] * inv);
+          const uint32_t b0 = Op16<TM>::pack(o[d][8 * gp + 4] * inv, o[d][8 * gp + 5] * inv), b1 = Op16<TM>::pack(o[d][8 * gp + 6] * inv, o[d][8 * gp + 7] * inv);
+          const auto x0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);      // lower half: group 2 gp of both halves; upper half: group 2 gp + 1
+          const auto x1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+#if defined(NS2VC_ATTN_ABLATE_STORE)      // diagnostic build (wrong results, timing only): no output stores
+          asm volatile("" :: "v"(x0[0]), "v"(x1[0]), "v"(x0[1]), "v"(x1[1]));
+#else
+          if (q < a.Lq) *reinterpret_cast<u32x4_t*>(op + d * 32 + 8 * (2 * gp + hi)) = u32x4_t{x0[0], x1[0], x0[1], x1[1]};
+#endif
+        }
+      }
+  } else if (q < a.Lq) {
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -509,7 +529,8 @@ hipError_t init_attn_attributes() {
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s) {
   const int al = prec == PREC_F32 ? 3 : 7;       // rows must start 16-B aligned
   if (!a.q || !a.k || !a.v || !a.out) return hipErrorInvalidValue;
-  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldq & al) || (a.ldk & al) || (a.ldv & al) || (a.ldo & 3)) return hipErrorInvalidValue;
+  if (a.Lq <= 0 || a.Lk <= 0 || (a.ldq & al) || (a.ldk & al) || (a.ldv & al) || (a.ldo & al)) return hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(a.out) & 15) return hipErrorInvalidValue;      // (results leave in 16-byte pieces)
   switch (prec) {
     case PREC_BF16: return launch_tm<bf16_t>(a, head_dim, s);
     case PREC_F16: return launch_tm<f16_t>(a, head_dim, s);

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     tr[0] = t_entry; tr[1] = t_pro;
     for (int i = 0; i < 5; ++i) tr[2 + i] = tacc[i];
     tr[7] = GG_NOW();
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    tr[8] = hwid;                                   // bits 0-3 wave slot, 4-5 SIMD, 8-11 CU, ...
   }
 #endif
 }

@@ -33,6 +33,12 @@ __device__ unsigned long long* g_rc_trace = nullptr;
 #ifndef NS2VC_GEMM_TRACE
 #define NS2VC_GEMM_TRACE 0
 #endif
+#ifndef NS2VC_RC_ABLATE
+#define NS2VC_RC_ABLATE 0
+#endif
+#ifndef NS2VC_RC_WT
+#define NS2VC_RC_WT 1       // stage-2 result stores write-through (sc1), as the GEMM epilogues' (common.h out_store16)
+#endif
 #if NS2VC_GEMM_TRACE
 #define RC_TR(i) do { if (tr && tid == 0) tr[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -383,40 +389,72 @@ __global__ __launch_bounds__(512) void rowchain_kernel(const RowchainArgs a) {
   }
 
   RC_TR(4);
-  // ---- stage-2 epilogue: LayerNorm fix-up + bias per element, operand rows out.  A lane holds 4 consecutive channels per
-  // register group g; the two lane halves trade groups so that every lane stores 8 consecutive channels (16 B)
+  // ---- stage-2 epilogue: LayerNorm fix-up + bias per element, operand rows out.  A lane holds 4 consecutive channels per register group g of
+  // ONE token: stored from the registers, every instruction is 32 rows x 32 bytes, and the issue of those pieces was the tail of the kernel (r5:
+  // without the stage-2 stores the step ran 3 % faster).  The weights and the panel are dead by now, so the whole result tile goes through their
+  // LDS ([token][RBP x 128 channels], row pitch + 16 B: the eight tokens of a write group land in different banks) and leaves as contiguous
+  // 1-KB runs, 64 lanes x 16 B.  RBP row blocks per pass (all of them where they fit).
   TM* const oo = reinterpret_cast<TM*>(a.out2_op);
+  constexpr int AVAIL = RING * RC_PAIR + G::PANEL;
+  constexpr int RBP = TOK * (R2 * 256 + 16) <= AVAIL ? R2 : (R2 + 1) / 2;
+  static_assert(TOK * (RBP * 256 + 16) <= AVAIL, "a pass of the staged result tile fits in the ring + panel");
+  constexpr int PB = RBP * 256 + 16;                // staged row pitch (bytes)
+  constexpr int CPR = RBP * 16;                     // 16-byte chunks per staged row
 #pragma unroll
-  for (int rb = 0; rb < R2; ++rb) {
-    float4 c0[4], c1[4];
+  for (int rb0 = 0; rb0 < R2; rb0 += RBP) {
+    lds_barrier();                                  // every wave is done with the ring / the panel (first pass), with reading the previous pass
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float* cv = consts + (size_t)(128 * rb + 32 * cg + 8 * g + 4 * hi) * 2;      // (rowsum, bias) x 4 rows
-      c0[g] = *reinterpret_cast<const float4*>(cv); c1[g] = *reinterpret_cast<const float4*>(cv + 4);
+    for (int rbi = 0; rbi < RBP; ++rbi) {
+      const int rb = rb0 + rbi;
+      if (rb < R2) {
+        float4 c0[4], c1[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float* cv = consts + (size_t)(128 * rb + 32 * cg + 8 * g + 4 * hi) * 2;      // (rowsum, bias) x 4 rows
+          c0[g] = *reinterpret_cast<const float4*>(cv); c1[g] = *reinterpret_cast<const float4*>(cv + 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (hazard guard, see the GroupNorm prologue above: no packed fp32 op under outstanding LDS reads here)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(c0[g].x), "+v"(c0[g].y), "+v"(c0[g].z), "+v"(c0[g].w), "+v"(c1[g].x), "+v"(c1[g].y), "+v"(c1[g].z), "+v"(c1[g].w));
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          uint32_t pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float z0 = rstd[u] * (acc2[rb][u][4 * g + 0] - mean[u] * c0[g].x) + c0[g].y;
+            const float z1 = rstd[u] * (acc2[rb][u][4 * g + 1] - mean[u] * c0[g].z) + c0[g].w;
+            const float z2 = rstd[u] * (acc2[rb][u][4 * g + 2] - mean[u] * c1[g].x) + c1[g].y;
+            const float z3 = rstd[u] * (acc2[rb][u][4 * g + 3] - mean[u] * c1[g].z) + c1[g].w;
+            pk[g][0] = Op16<TM>::pack(z0, z1);
+            pk[g][1] = Op16<TM>::pack(z2, z3);
+          }
+          char* srow = smem + (size_t)(tok0 + 32 * u) * PB + rbi * 256 + 64 * cg + 16 * hi;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {         // groups (2 gp, 2 gp + 1): lower half ends up with group 2 gp, upper half with 2 gp + 1 -- 8 channels, 16 B
+            const auto x0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
+            const auto x1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
+            *reinterpret_cast<u32x4_t*>(srow + 32 * gp) = u32x4_t{x0[0], x1[0], x0[1], x1[1]};
+          }
+        }
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (hazard guard, see the GroupNorm prologue above: no packed fp32 op under outstanding LDS reads here)
+    lds_barrier();                                  // the pass is staged
+    const int nb = min(RBP, R2 - rb0);              // row blocks really staged (the last pass may be short)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(c0[g].x), "+v"(c0[g].y), "+v"(c0[g].z), "+v"(c0[g].w), "+v"(c1[g].x), "+v"(c1[g].y), "+v"(c1[g].z), "+v"(c1[g].w));
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-      const int mtok = m0 + tok0 + 32 * u;
-      uint32_t pk[4][2];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float z0 = rstd[u] * (acc2[rb][u][4 * g + 0] - mean[u] * c0[g].x) + c0[g].y;
-        const float z1 = rstd[u] * (acc2[rb][u][4 * g + 1] - mean[u] * c0[g].z) + c0[g].w;
-        const float z2 = rstd[u] * (acc2[rb][u][4 * g + 2] - mean[u] * c1[g].x) + c1[g].y;
-        const float z3 = rstd[u] * (acc2[rb][u][4 * g + 3] - mean[u] * c1[g].z) + c1[g].w;
-        pk[g][0] = Op16<TM>::pack(z0, z1);
-        pk[g][1] = Op16<TM>::pack(z2, z3);
-      }
-#pragma unroll
-      for (int gp = 0; gp < 2; ++gp) {         // groups (2 gp, 2 gp + 1): lower half ends up with group 2 gp, upper half with 2 gp + 1
-        const auto x0 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][0], pk[2 * gp + 1][0], false, false);
-        const auto x1 = __builtin_amdgcn_permlane32_swap(pk[2 * gp][1], pk[2 * gp + 1][1], false, false);
-        const int n = 128 * (rb + sl * R2) + 32 * cg + 8 * (2 * gp + hi);
-        if (mtok < a.M && n < a.n2) *reinterpret_cast<u32x4_t*>(oo + (size_t)mtok * a.ldo2 + n) = u32x4_t{x0[0], x1[0], x0[1], x1[1]};
-      }
+    for (int i = 0; i < TOK * CPR / 512; ++i) {
+      const int id = i * 512 + tid;
+      const int row = id / CPR, col = id - row * CPR;
+      const int mt = m0 + row, n = 128 * (rb0 + sl * R2) + 8 * col;
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + (size_t)row * PB + col * 16);
+#if NS2VC_RC_ABLATE & 1     // diagnostic build (wrong results, timing only): no stage-2 stores
+      asm volatile("" :: "v"(v));
+#else
+#if NS2VC_RC_WT
+      if (mt < a.M && col < nb * 16 && n < a.n2) out_store16(oo + (size_t)mt * a.ldo2 + n, v.x, v.y, v.z, v.w);
+#else
+      if (mt < a.M && col < nb * 16 && n < a.n2) *reinterpret_cast<u32x4_t*>(oo + (size_t)mt * a.ldo2 + n) = v;
+#endif
+#endif
     }
   }
 #if NS2VC_GEMM_TRACE

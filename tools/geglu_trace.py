@@ -47,3 +47,8 @@ for w in range(8):
     tot = tw[:, 7] - tw[:, 0]
     cols = [tw[:, 1] - tw[:, 0]] + [tw[:, 2 + i] for i in range(5)] + [tot]
     print(f"  {w:4d} " + " ".join(f"{np.median(c):22.0f}" for c in cols))
+hw = t[:, :, 8].astype(np.int64)
+simd = (hw >> 4) & 3
+print("# SIMD of waves 0..7 (HW_REG_HW_ID bits 4-5), first workgroups:", [simd[b].tolist() for b in range(4)])
+print("# waves w and w + 4 on one SIMD in", int(np.sum(np.all(simd[:, :4] == simd[:, 4:], axis=1))), "of", nblk, "workgroups; waves 2k and 2k + 1 on one SIMD in",
+      int(np.sum(np.all(simd[:, 0::2] == simd[:, 1::2], axis=1))))
