@@ -459,7 +459,7 @@ template <typename TM> static hipError_t launch_geglu_t(const GegluArgs& a, hipS
 hipError_t launch_geglu(const GegluArgs& a, int prec, hipStream_t s) {
   if (!geglu_eligible(a.dim, 1, prec) || a.M <= 0) return hipErrorInvalidValue;
   if (!a.yn || !a.ln_stats || !a.wstream || !a.consts || !a.out_op) return hipErrorInvalidValue;
-  if ((a.ldy & 7) || (a.ldo & 7) || (unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull || (unsigned long long)a.M * a.ldo * 2ull > 0x7FF00000ull) return hipErrorInvalidValue;
+  if (a.ldy < a.dim || a.ldo < 4 * a.dim || (a.ldy & 7) || (a.ldo & 7) || (unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull || (unsigned long long)a.M * a.ldo * 2ull > 0x7FF00000ull) return hipErrorInvalidValue;
   if ((reinterpret_cast<uintptr_t>(a.out_op) & 15) != 0) return hipErrorInvalidValue;
   return prec == PREC_BF16 ? launch_geglu_t<bf16_t>(a, s) : launch_geglu_t<f16_t>(a, s);
 }

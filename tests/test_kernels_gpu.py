@@ -899,6 +899,8 @@ def test_geglu_token_stationary(M, ldo_extra, prec, diag):
     assert lib.ns2vc_k_geglu(C.byref(f), prec, None) != 0
     f.dim = d; f.out_op = d_h2.ptr + 2
     assert lib.ns2vc_k_geglu(C.byref(f), prec, None) != 0
+    f.out_op = d_h2.ptr; f.ldo = 4 * d - 8          # an output pitch narrower than the hidden width
+    assert lib.ns2vc_k_geglu(C.byref(f), prec, None) != 0
     lib.ns2vc_dev_free(stream); lib.ns2vc_dev_free(consts)
 
 
