@@ -30,6 +30,9 @@
 #ifndef NS2VC_GG_PRIO
 #define NS2VC_GG_PRIO 0
 #endif
+#ifndef NS2VC_GG_ROTATE
+#define NS2VC_GG_ROTATE 0     // 1: token block tb sweeps its unit blocks starting at block tb % UB (de-synchronises the L2 requests of an XCD's workgroups; measured: no gain -- the limit is the L2's aggregate rate, not a hot spot)
+#endif
 #ifndef NS2VC_GG_PINGPONG
 #define NS2VC_GG_PINGPONG 1   // 1: the two waves of a SIMD alternate between a load segment and a compute segment, half a step apart; 0: all eight waves in lock step
 #endif
@@ -116,9 +119,18 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
   const unsigned lane16 = (unsigned)(lane * 16);
   const unsigned wq0 = (unsigned)(q * NP) * GG_TILE;        // this quarter's tiles inside the stream
   // a tile = 16 pieces of 1 KB: two per wave, all addresses scalar
+#if NS2VC_GG_ROTATE
+  // the unit blocks of a quarter are independent: token block tb starts its sweep at unit block tb % UB, so the seven or eight workgroups of an XCD that
+  // share a quarter do not all ask its L2 for the same tile at the same moment (results unchanged: only the order of the blocks differs)
+  const int rot = __builtin_amdgcn_readfirstlane(tb % UB);
+#else
+  const int rot = 0;
+#endif
+  auto ubm = [&](int u) __attribute__((always_inline)) { const int v = u + rot; return v >= UB ? v - UB : v; };     // processing position -> unit block
   auto issue_tile = [&](int p, int slot) __attribute__((always_inline)) {
+    const int u = p / KT, pt = ubm(u) * KT + (p - u * KT);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) blds16(rW, lane16, wq0 + (unsigned)(p * GG_TILE + (j * 8 + wave) * 1024), lds0 + slot * GG_TILE + (j * 8 + wave) * 1024);
+    for (int j = 0; j < 2; ++j) blds16(rW, lane16, wq0 + (unsigned)(pt * GG_TILE + (j * 8 + wave) * 1024), lds0 + slot * GG_TILE + (j * 8 + wave) * 1024);
   };
   // ---- DMA: the token rows (96 KB = ring slots 3 .. 8 for now: whole 128-byte rows, each fetched once per workgroup; source-side swizzle, rows
   // past M read as zeros), the constants, the first three weight tiles
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
   // operations -- whatever the stores do (they can only make the wait longer).
   auto chunk = [&](int ubp, int j) __attribute__((always_inline)) {
     // register r <-> stream row (r&3) + 8 (r>>2) + 4 hi of this wave's 32 = unit 16 hi + r of the group; this is r = 4 j .. 4 j + 3
-    const float* cv = consts + (size_t)(128 * ubp + 64 * hg) * 2;           // (rowsum, bias) of the value rows; gate rows = + 32
+    const float* cv = consts + (size_t)(128 * ubm(ubp) + 64 * hg) * 2;      // (rowsum, bias) of the value rows; gate rows = + 32
     const float4 v0 = *reinterpret_cast<const float4*>(cv + (8 * j + 4 * hi) * 2);
     const float4 v1 = *reinterpret_cast<const float4*>(cv + (8 * j + 4 * hi) * 2 + 4);
     const float4 g0 = *reinterpret_cast<const float4*>(cv + (32 + 8 * j + 4 * hi) * 2);
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(512) void geglu_kernel(const GegluArgs a) {
     *reinterpret_cast<u32x4_t*>(row + (((c0 + 1) ^ x) * 16)) = v1;
   };
   auto store_block = [&](int ubp) __attribute__((always_inline)) {
-    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ubp * 128);
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane(ubm(ubp) * 128);
     const u32x4_t v0 = *reinterpret_cast<const u32x4_t*>(stage + srow * 128 + (((lane & 7) ^ (srow & 7)) * 16));
     const u32x4_t v1 = *reinterpret_cast<const u32x4_t*>(stage + (srow + 8) * 128 + (((lane & 7) ^ (srow & 7)) * 16));
     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen " NS2VC_WT_MOD "\n\tbuffer_store_dwordx4 %4, %5, %2, %3 offen " NS2VC_WT_MOD "\n\ts_nop 1"
