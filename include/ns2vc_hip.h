@@ -298,7 +298,7 @@ int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream);
 
 /* r5: token-stationary GEGLU projection (csrc/geglu.hip; 16-bit precisions, dim 384): h = (n W1v^T + b1v) * gelu(n W1g^T + b1g),
  * n = LayerNorm(y) by linearity -- BasicTransformerBlock.ff.net.0 (reference unet1d/attention.py:178-203, GEGLU 206-301) of the blocks
- * whose hidden tensor does not fit the fused ns2vc_k_ffn.  128 tokens stay in LDS, four workgroups per token block sweep a quarter of
+ * whose hidden tensor does not fit the fused ns2vc_k_ffn.  128 tokens stay in registers, four workgroups per token block sweep a quarter of
  * the hidden units each; out_op [M][ldo] (>= 4 dim columns) operand-typed.  yn = the RAW operand copy of y [M][ldy]; ln_stats as in
  * ns2vc_gemm_args.ln_stats ([M][dim/64] (sum, sumsq)); wstream / consts from ns2vc_pack_geglu. */
 typedef struct ns2vc_geglu_args {
