@@ -313,6 +313,9 @@ typedef struct ns2vc_geglu_args {
  * fp32 host.  Returns the device tile stream and the device constants ((rowsum of the rounded row, bias) per stream row). */
 int ns2vc_pack_geglu(const float* w1_packed_host, const float* bias1_packed_host, int dim, int precision, void** out_stream_dev, float** out_consts_dev);
 int ns2vc_k_geglu(const ns2vc_geglu_args* a, int precision, void* stream);
+/* the same packing on the host only (no GPU needed; tests): stream_out [8*dim*dim] operand-typed bit patterns in consumption order
+ * ([quarter][unit block][K tile][128 rows][64 k], rows of every 32-unit group permuted, 16-byte chunks XOR-swizzled), consts_out [8*dim][2] */
+int ns2vc_pack_geglu_host(const float* w1_packed_host, const float* bias1_packed_host, int dim, int precision, uint16_t* stream_out, float* consts_out);
 
 /* Two token-local GEMMs with a LayerNorm in between, in one launch (csrc/rowchain.hip; 16-bit precisions, dim 128 / 256):
  *   y = A W1^T + bias1 (+ res)  -> out1_f32 (optional);   z = LayerNorm(y) W2'^T + b2'  -> out2_op   (gamma/beta folded into W2' / b2')

@@ -2053,6 +2053,15 @@ int ns2vc_pack_geglu(const float* w1_packed_host, const float* bias1_packed_host
   *out_consts_dev = c;
   return 0;
 }
+int ns2vc_pack_geglu_host(const float* w1_packed_host, const float* bias1_packed_host, int dim, int precision, uint16_t* stream_out, float* consts_out) {
+  if (!w1_packed_host || !stream_out || !consts_out) return fail("null argument");
+  std::vector<unsigned short> st;
+  std::vector<float> cs;
+  if (pack_geglu_stream(w1_packed_host, bias1_packed_host, dim, precision, st, cs) != hipSuccess) return fail("geglu: dim must be 384 and the precision 16-bit");
+  memcpy(stream_out, st.data(), st.size() * 2);
+  memcpy(consts_out, cs.data(), cs.size() * 4);
+  return 0;
+}
 int ns2vc_k_geglu(const ns2vc_geglu_args* a, int precision, void* stream) {
   if (!a) return fail("null args");
   hipError_t e = launch_geglu(*a, precision, (hipStream_t)stream);

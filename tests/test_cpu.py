@@ -407,6 +407,46 @@ def test_host_operand_rounding_matches_ieee():
         assert np.isnan(out[0])
 
 
+def test_geglu_stream_packing_layout():
+    """r5: the weight tile stream of the token-stationary GEGLU kernel (csrc/geglu.hip), packed on the host (ns2vc_pack_geglu_host), against an
+    independent restatement of its layout: [quarter][unit block][K tile][128 rows][8 chunks of 8], the rows of every 32-unit group in the order that
+    makes a lane's 16 MFMA results 16 consecutive hidden units, 16-byte chunks XOR-swizzled by (row >> 1) & 7, constants in stream row order."""
+    import ctypes as C
+    from ns2vc_amd import _lib
+    from util import bf16_round, f16_round
+    lib = _lib.load()
+    d = 384
+    rng = np.random.default_rng(11)
+    W = (rng.standard_normal((8 * d, d)) / np.sqrt(d)).astype(np.float32)
+    b = rng.standard_normal(8 * d).astype(np.float32)
+    # the MFMA result layout the permutation is made for: register r of lane half hi holds tile row (r & 3) + 8 (r >> 2) + 4 hi
+    unit_of_row = lambda m: 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3)
+    assert sorted(unit_of_row(m) for m in range(32)) == list(range(32))
+    for hi in range(2):
+        assert [unit_of_row((r & 3) + 8 * (r >> 2) + 4 * hi) for r in range(16)] == list(range(16 * hi, 16 * hi + 16))
+    sr = np.arange(8 * d)                                               # stream row -> packed row
+    pr = (sr >> 6) * 64 + ((sr >> 5) & 1) * 32 + np.array([unit_of_row(int(m)) for m in sr & 31])
+    for prec, rnd, bits in ((2, f16_round, lambda a: a.astype(np.float16).view(np.uint16)), (1, bf16_round, lambda a: (a.view(np.uint32) >> 16).astype(np.uint16))):
+        stream = np.zeros(8 * d * d, dtype=np.uint16)
+        consts = np.zeros((8 * d, 2), dtype=np.float32)
+        assert lib.ns2vc_pack_geglu_host(W.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), d, prec, stream.ctypes.data_as(C.c_void_p),
+                                         consts.ctypes.data_as(C.c_void_p)) == 0
+        Wr = rnd(W)
+        tiles = stream.reshape(8 * d // 128, d // 64, 128, 8, 8)          # [unit block (all quarters)][K tile][row][chunk position][element]
+        want = np.empty_like(tiles)
+        r = np.arange(128)
+        for ubg in range(8 * d // 128):
+            rows = Wr[pr[ubg * 128:(ubg + 1) * 128]]                      # [128][d]
+            for kt in range(d // 64):
+                blk = rows[:, 64 * kt:64 * kt + 64].reshape(128, 8, 8)   # [row][logical chunk][element]
+                for pos in range(8):
+                    want[ubg, kt, :, pos, :] = bits(np.ascontiguousarray(blk[r, pos ^ ((r >> 1) & 7), :]))
+        assert np.array_equal(tiles, want), prec
+        assert np.array_equal(consts[:, 1], b[pr])
+        assert np.allclose(consts[:, 0], Wr[pr].astype(np.float64).sum(1), rtol=0, atol=1e-6)
+    assert lib.ns2vc_pack_geglu_host(W.ctypes.data_as(C.c_void_p), None, 256, 2, stream.ctypes.data_as(C.c_void_p), consts.ctypes.data_as(C.c_void_p)) != 0
+
+
 def test_no_cpu_fallback_engine_fails_loudly_without_gpu():
     from ns2vc_amd import engine
     if engine.device_count() > 0:
