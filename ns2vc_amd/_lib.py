@@ -182,6 +182,7 @@ PROTOTYPES = {
     "ns2vc_pack_geglu": (_I, [_P, _P, _I, _I, _PP, _PP]),
     "ns2vc_k_geglu": (_I, [C.POINTER(GegluArgs), _I, _P]),
     "ns2vc_pack_geglu_host": (_I, [_P, _P, _I, _I, _P, _P]),
+    "ns2vc_debug_set_geglu_min_rows": (_I, [_I]),
     "ns2vc_pack_rowchain": (_I, [_P, _P, _I, _I, _I, _PP]),
     "ns2vc_pack_rowchain_sliced": (_I, [_P, _P, _I, _I, _I, _I, _PP]),
     "ns2vc_k_rowchain": (_I, [C.POINTER(RowchainArgs), _I, _P]),
