@@ -345,7 +345,7 @@ typedef struct ns2vc_rowchain_args {
 int ns2vc_pack_rowchain(const float* w1_host, const float* w2_host, int dim, int n2, int precision, void** out_stream_dev);
 int ns2vc_pack_rowchain_sliced(const float* w1_host, const float* w2_host, int dim, int n2, int slices, int precision, void** out_stream_dev);
 int ns2vc_k_rowchain(const ns2vc_rowchain_args* a, int precision, void* stream);
-int ns2vc_debug_set_geglu_min_rows(int rows); /* tests / tuning: row count from which the planner picks ns2vc_k_geglu over the GEMM (default 3072; < 0 restores it); takes effect at the next plan build */
+int ns2vc_debug_set_geglu_min_rows(int rows); /* tests / tuning: row count from which the planner picks ns2vc_k_geglu over the GEMM (default 4608; < 0 restores it); takes effect at the next plan build */
 int ns2vc_debug_set_attn_keys(int keys); /* tests / tuning: 128 selects the 128-key K/V tile kernels (16-bit precisions, hd 16 / 32); 0 or 64 = the default 64-key tiles */
 int ns2vc_debug_set_attn_optimistic(int on); /* tests: 0 = every attention workgroup takes the exact (per-tile maximum) pass only; 1 = default */
 int ns2vc_debug_set_rowchain_tokens(int nt); /* tests: force 64-token (1) / 128-token (2, dim 128 only) workgroups; 0 = heuristic */

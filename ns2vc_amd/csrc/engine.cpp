@@ -40,7 +40,7 @@ void set_attn_optimistic(int on);
 
 namespace {
 
-int g_geglu_min_rows = 3072;   // rows from which the token-stationary GEGLU kernel replaces the GEMM (tests: ns2vc_debug_set_geglu_min_rows)
+int g_geglu_min_rows = 4608;   // rows from which the token-stationary GEGLU kernel replaces the GEMM (tests: ns2vc_debug_set_geglu_min_rows)
 
 thread_local std::string g_err;
 
@@ -993,7 +993,7 @@ struct Planner {
     }
     if (!r3) layernorm(t + ".norm3");
     // (a workgroup of that kernel sweeps a quarter of the hidden units for its 128 tokens -- 36 dependent tile steps: worth it once the token blocks
-    //  fill the chip; below ~96 workgroups the GEMM's 24 column tiles per row block finish sooner.  r5 batch sweep: batch 1-4 +0.1 ms/step without this)
+    //  fill the chip; below ~144 workgroups the GEMM's 24 column tiles per row block finish sooner.  r5 batch sweep: batch 1-4 +0.1 ms/step without this; crossover between 3760 and 5640 rows)
     if (r3 && h->fuse_geglu && a.geglu_stream && geglu_eligible(d, Tl, pr) && M >= g_geglu_min_rows) {
       // the token rows stay in LDS, only weights stream (csrc/geglu.hip): half the L2 -> LDS bytes of the GEMM below
       ns2vc_geglu_args f;
@@ -2057,7 +2057,7 @@ int ns2vc_pack_geglu(const float* w1_packed_host, const float* bias1_packed_host
   *out_consts_dev = c;
   return 0;
 }
-int ns2vc_debug_set_geglu_min_rows(int rows) { g_geglu_min_rows = rows < 0 ? 3072 : rows; return 0; }
+int ns2vc_debug_set_geglu_min_rows(int rows) { g_geglu_min_rows = rows < 0 ? 4608 : rows; return 0; }
 int ns2vc_pack_geglu_host(const float* w1_packed_host, const float* bias1_packed_host, int dim, int precision, uint16_t* stream_out, float* consts_out) {
   if (!w1_packed_host || !stream_out || !consts_out) return fail("null argument");
   std::vector<unsigned short> st;
