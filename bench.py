@@ -70,23 +70,31 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--attn-fp8", action="store_true", help="PV product of every attention on the fp8 MFMA (BASELINE config 5's fp8 path; "
                     "costs parity, see DESIGN.md section 4)")
+    ap.add_argument("--full", action="store_true", help="also run the long legs (self_check, fp32_parity_mode, bf16_as_stated, other_configs = BASELINE configs 2 and 5, "
+                    "strong_scaling, the larger CPU grid); their results go to the detail file, the stdout line stays the compact one "
+                    "(printed before the long legs start and again as the last line)")
+    ap.add_argument("--detail-json", default=os.path.join(ROOT, "bench_detail.json"), help="where rank 0 writes the full record (every block of the compact line "
+                    "unabridged + the --full legs); '' = do not write")
     ap.add_argument("--skip-cpu", action="store_true", help="skip the CPU-baseline / parity legs")
-    ap.add_argument("--skip-fp32", action="store_true", help="skip the fp32_parity_mode block")
-    ap.add_argument("--skip-others", action="store_true", help="skip the other_configs block (BASELINE configs 2 and 5)")
-    ap.add_argument("--skip-strong", action="store_true", help="skip the strong_scaling block (global batch 256 split over the ranks)")
+    ap.add_argument("--skip-fp32", action="store_true", help="(--full) skip the fp32_parity_mode block")
+    ap.add_argument("--skip-others", action="store_true", help="(--full) skip the other_configs block (BASELINE configs 2 and 5)")
+    ap.add_argument("--skip-strong", action="store_true", help="(--full) skip the strong_scaling block (global batch 256 split over the ranks)")
     ap.add_argument("--tail-fp32", type=int, default=0, help="last evaluations of the timed loop on a second, fp32 engine (mixed precision; "
                     "0 = the headline's pure 16-bit loop)")
     ap.add_argument("--strong-batch", type=int, default=256, help="global batch of the strong_scaling block (BASELINE config 4: 256)")
     ap.add_argument("--dry-dist", type=int, default=0, metavar="N", help="harness rehearsal WITHOUT GPUs: N ranks on the gloo backend, the engine replaced by "
                     "a sleep + deterministic fill; exercises the spawn, every barrier, the all-gather of latents, the per-rank reduction, the "
                     "strong_scaling block and the JSON line exactly as --gpus N does (tests/test_cpu.py runs it at N = 2 and 8)")
-    ap.add_argument("--cpu-budget", type=float, default=24.0, help="seconds of CPU work for the baseline legs")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of TIMED CPU work for the baseline grid (split over its legs; the parity "
+                    "references are extra and unbudgeted: one batch-B forward + the sampled latent of 2 utterances)")
     ap.add_argument("--ops", default="", help="write the per-launch table (name, kind, ms, GFLOP, MB) to this file")
     ap.add_argument("--detail", action="store_true", help="print the per-kernel-family table to stderr")
     ap.add_argument("--cpu-worker", type=float, default=0.0, help=argparse.SUPPRESS)     # internal: one all-core baseline worker
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-frames", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-pin", default="", help=argparse.SUPPRESS)                  # internal: "lo-hi" core range of one all-core worker
+    ap.add_argument("--cpu-batch", type=int, default=2, help=argparse.SUPPRESS)       # internal: batch of one all-core worker
+    ap.add_argument("--cpu-weights", default="", help=argparse.SUPPRESS)              # internal: flat fp32 weight file the workers map (written once by the parent)
     return ap.parse_args()
 
 
@@ -100,12 +108,59 @@ def _host_cores() -> int:
         return os.cpu_count() or 1
 
 
-def _oracle_setup(threads: int):
+def _cpu_quota() -> float | None:
+    """CPUs the container may actually burn: the cgroup CFS quota (cpu.max = "<quota> <period>").  The GPU boxes of this pool show
+    256 logical CPUs and a quota of 16 (measured r6): every thread beyond the quota only adds throttling, which is why the r1-r5 grids
+    got slower with more processes."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+        except Exception:
+            pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def _numa_layout() -> str:
+    try:
+        out = []
+        base = "/sys/devices/system/node"
+        for n in sorted(d for d in os.listdir(base) if d.startswith("node") and d[4:].isdigit()):
+            out.append(f"{n}={open(os.path.join(base, n, 'cpulist')).read().strip()}")
+        return " ".join(out) or "unknown"
+    except Exception:
+        return "unknown"
+
+
+def _weights_file(W, path):
+    """The oracle's weights as ONE flat fp32 file + an index, written once by the parent: the grid's workers map it (shared page cache)
+    instead of each regenerating 66 M parameters inside a CPU quota shared with the timed window."""
+    index, off = {}, 0
+    with open(path, "wb") as f:
+        for k, v in W.items():
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            index[k] = (off, list(a.shape))
+            f.write(a.tobytes())
+            off += a.size
+    with open(path + ".json", "w") as f:
+        json.dump(index, f)
+
+
+def _oracle_setup(threads: int, weights_path: str = ""):
     import torch
     from ns2vc_amd.spec import UNetConfig
-    from ns2vc_amd.weights import procedural_state_dict
     torch.set_num_threads(max(1, threads))
     cfg = UNetConfig()
+    if weights_path:
+        flat = np.memmap(weights_path, dtype=np.float32, mode="c")       # copy-on-write mapping: read-only in effect, shared between the workers
+        index = json.load(open(weights_path + ".json"))
+        return cfg, {k: torch.from_numpy(flat[o:o + int(np.prod(sh, dtype=np.int64))].reshape(sh)) for k, (o, sh) in index.items()}
+    from ns2vc_amd.weights import procedural_state_dict
     return cfg, {k: torch.from_numpy(v) for k, v in procedural_state_dict(cfg, 0).items()}
 
 
@@ -117,18 +172,18 @@ def bench_inputs(tag: str, B: int, T: int, Lp: int):
             hash_normal(tag + ".prompt", (B, Lp, cfg.cross_attention_dim)))
 
 
-def cpu_worker(seconds: float, threads: int, T: int, Lp: int, B: int = 4):
-    """One worker of the all-core leg: oracle forwards at batch B for `seconds`; prints samples and elapsed time."""
+def cpu_worker(seconds: float, threads: int, T: int, Lp: int, B: int = 2, weights_path: str = ""):
+    """One worker of a grid leg: oracle forwards at batch B for `seconds`; prints samples and elapsed time."""
     import torch
     from oracle import unet_ref
-    cfg, P = _oracle_setup(threads)
+    cfg, P = _oracle_setup(threads, weights_path)
     x, content, prompt = (torch.from_numpy(a) for a in bench_inputs(f"cpuw{os.getpid() % 97}", B, T, Lp))
     sample = torch.cat([x, content], dim=1)
     mask = torch.ones(B, Lp, dtype=torch.bool)
     t = torch.full((B,), 500.0)
-    unet_ref.unet_forward(P, cfg, sample, t, prompt, mask)            # warm-up
+    unet_ref.unet_forward(P, cfg, sample, t, prompt, mask)            # warm-up (also faults the weight pages in)
     print("READY", flush=True)
-    sys.stdin.readline()                                              # all workers start together
+    sys.stdin.readline()                                              # all workers of a leg start together
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         unet_ref.unet_forward(P, cfg, sample, t, prompt, mask)
@@ -136,98 +191,106 @@ def cpu_worker(seconds: float, threads: int, T: int, Lp: int, B: int = 4):
     print(json.dumps({"samples": n, "seconds": time.perf_counter() - t0}), flush=True)
 
 
-def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None):
-    """(1) one process at the bench batch (thread count = best of a short probe), whose output is also the parity
-    reference; (2) all cores: P processes x that thread count, started together, samples/s summed; (3) `sampler` =
-    (solver, steps, items): oracle.sampler_ref on the first `items` utterances of the same inputs = the reference of
-    parity.sampled_latent."""
+def cpu_grid(cores_eff: int, full: bool):
+    """(processes, threads, batch) legs of the baseline grid.  Many small processes is what a throughput-minded host would run (r5 review):
+    with E usable cores the default legs are E/8 x 8, E/4 x 4 and E/2 x 2 threads at batch 2 (= 32x8, 64x4, 128x2 on an unthrottled 256-CPU
+    host; 2x8, 4x4, 8x2 under this pool's 16-CPU quota); --full adds E x 1 at batch 1 and E/16 x 16 at batch 4."""
+    legs = [(max(1, cores_eff // t), t, 2) for t in (8, 4, 2) if t <= cores_eff]
+    if full:
+        legs += [(cores_eff, 1, 1)] + ([(cores_eff // 16, 16, 4)] if cores_eff >= 32 else [])
+    return [g for g in dict.fromkeys(legs) if g[0] >= 1]
+
+
+def cpu_baseline(T: int, Lp: int, B: int, budget_s: float, sampler=None, W=None, full=False):
+    """(1) one process at the bench batch (its output is also the parity reference, timed as the `single_process` leg); (2) the grid of
+    cpu_grid(): P processes x T threads, every worker pinned to its own disjoint cores, weights mapped from one shared file, started
+    together after their warm-up, samples/s summed, the best leg (or the single process, if faster) is `value`; (3) `sampler` = (solver,
+    steps, items): oracle.sampler_ref on the first `items` utterances of the same inputs = the reference of parity.sampled_latent.
+    Cores: what the cgroup lets the container burn (cpu.max), not what lscpu shows."""
     import torch
     from oracle import unet_ref
-    cores = _host_cores()
-    cfg, P = _oracle_setup(min(cores, 16))
-    x, content, prompt = (torch.from_numpy(a) for a in bench_inputs("bench.r0", B, T, Lp))
-    mask = torch.ones(B, Lp, dtype=torch.bool)
-    t_par = torch.linspace(40.0, 960.0, B)
-    sample = torch.cat([x, content], dim=1)
-
-    def run(bs, n, threads):
-        torch.set_num_threads(threads)
+    visible, quota = _host_cores(), _cpu_quota()
+    eff = max(1, min(visible, int(quota + 0.5))) if quota else visible
+    th = min(eff, 32)
+    wpath = ""
+    if W is not None:
+        shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+        wpath = os.path.join(shm, f"ns2vc_oracle_w_{os.getpid()}.f32")
+        _weights_file(W, wpath)
+    try:
+        cfg, P = _oracle_setup(th, wpath)
+        x, content, prompt = (torch.from_numpy(a) for a in bench_inputs("bench.r0", B, T, Lp))
+        mask = torch.ones(B, Lp, dtype=torch.bool)
+        t_par = torch.linspace(40.0, 960.0, B)
+        sample = torch.cat([x, content], dim=1)
+        unet_ref.unet_forward(P, cfg, sample[:2], t_par[:2], prompt[:2], mask[:2])     # warm-up
         t0 = time.perf_counter()
-        for _ in range(n):
-            y = unet_ref.unet_forward(P, cfg, sample[:bs], t_par[:bs], prompt[:bs], mask[:bs])
-        return time.perf_counter() - t0, y
+        y_ref = unet_ref.unet_forward(P, cfg, sample, t_par, prompt, mask)
+        dt = time.perf_counter() - t0
+        single = {"sample_steps_per_s": B / dt, "processes": 1, "threads_per_process": th, "batch_per_process": B, "seconds": dt}
+        # ---- the grid
+        sweep, agg = [], None
+        grid = cpu_grid(eff, full)
+        secs = max(2.5, budget_s / max(len(grid), 1))
+        avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(visible))
+        for nproc, tha, bw in grid:
+            cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(secs), "--cpu-threads", str(tha), "--cpu-frames", str(T),
+                   "--prompt-frames", str(Lp), "--cpu-batch", str(bw)] + (["--cpu-weights", wpath] if wpath else [])
+            env = dict(os.environ, OMP_NUM_THREADS=str(tha), MKL_NUM_THREADS=str(tha), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+            procs = [subprocess.Popen(cmd + ["--cpu-pin", f"{i * tha}-{(i + 1) * tha}"], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL, text=True) for i in range(nproc)]
+            leg = {"processes": nproc, "threads_per_process": tha, "batch_per_process": bw}
+            try:
+                for p in procs:
+                    if "READY" not in p.stdout.readline():
+                        raise RuntimeError("cpu worker failed to start")
+                for p in procs:
+                    p.stdin.write("go\n"); p.stdin.flush()
+                outs = [json.loads(p.stdout.readline()) for p in procs]
+                leg.update(sample_steps_per_s=sum(o["samples"] / o["seconds"] for o in outs), seconds=secs)
+            except Exception as ex:
+                leg["error"] = repr(ex)
+            finally:
+                for p in procs:
+                    try:
+                        p.kill()
+                    except Exception:
+                        pass
+            sweep.append(leg)
+            if "sample_steps_per_s" in leg and (agg is None or leg["sample_steps_per_s"] > agg["sample_steps_per_s"]):
+                agg = leg
+        use = agg if agg and agg["sample_steps_per_s"] > single["sample_steps_per_s"] else single
+        used = min(eff, use["processes"] * use["threads_per_process"])
+        # ---- the sampled latent of the timed solver on the first utterances (the oracle treats utterances independently)
+        samp = None
+        if sampler is not None:
+            from oracle import sampler_ref
+            solver, steps, nb = sampler
+            nb = max(1, min(nb, B))
+            torch.set_num_threads(th)
+            tc, tp, tm = content[:nb], prompt[:nb], mask[:nb]
 
-    best = None
-    for th in sorted({min(cores, v) for v in (8, 16, 32, 64)}):
-        run(2, 1, th)
-        dt, _ = run(4, 1, th)
-        if best is None or dt < best[1]:
-            best = (th, dt)
-    th = best[0]
-    n1 = int(max(1, min(8, (budget_s * 0.4) / max(best[1] * B / 4, 1e-3))))
-    dt, y_ref = run(B, n1, th)
-    single = {"sample_steps_per_s": B * n1 / dt, "threads": th, "batch": B, "forwards": n1, "seconds": dt}
-    # ---- all cores: a small grid of (processes x threads), every worker pinned to its own contiguous cores (= one NUMA-local block of
-    # the socket; unpinned, 16 x 16 threads ran SLOWER than one process in rounds 1-2).  r5: the best leg is the baseline, the grid is
-    # reported (`all_cores_sweep`), so the ratio is not against a configuration nobody tried to make fast.
-    agg, sweep = None, []
-    grid = sorted({(max(1, cores // t), t) for t in (8, 16, 32, 64) if t <= cores} | {(max(1, cores // th), th)})
-    grid = [g for g in grid if g[0] > 1]
-    secs = max(4.0, budget_s * 0.7 / max(len(grid), 1))
-    for nproc, tha in grid:
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", str(secs), "--cpu-threads", str(tha), "--cpu-frames", str(T),
-               "--prompt-frames", str(Lp)]
-        env = dict(os.environ, OMP_NUM_THREADS=str(tha), MKL_NUM_THREADS=str(tha), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
-        procs = [subprocess.Popen(cmd + ["--cpu-pin", f"{i * tha}-{(i + 1) * tha}"], env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-                 for i in range(nproc)]
-        leg = None
-        try:
-            for p in procs:
-                line = p.stdout.readline()
-                if "READY" not in line:
-                    raise RuntimeError("cpu worker failed to start")
-            for p in procs:
-                p.stdin.write("go\n"); p.stdin.flush()
-            outs = [json.loads(p.stdout.readline()) for p in procs]
-            leg = {"sample_steps_per_s": sum(o["samples"] / o["seconds"] for o in outs), "processes": nproc, "threads_per_process": tha,
-                   "batch_per_process": 4, "seconds": secs, "pinned": "each process on its own disjoint contiguous cores (sched_setaffinity)"}
-        except Exception as ex:
-            leg = {"error": repr(ex), "processes": nproc, "threads_per_process": tha}
-        finally:
-            for p in procs:
+            def x0(xx, tt):
+                return unet_ref.denoiser(P, cfg, xx, tc, tp, tm, tt)
+            t0 = time.perf_counter()
+            betas = sampler_ref.linear_betas(1000)
+            ys = (sampler_ref.unipc_bh2(x0, betas, x[:nb].clone(), steps) if solver == "unipc" else
+                  sampler_ref.dpm_solver_pp_2m(x0, betas, x[:nb].clone(), steps, 2 if steps >= 2 else 1))
+            samp = {"y": ys.numpy(), "items": nb, "seconds": time.perf_counter() - t0}
+        pinned = "workers pinned to disjoint contiguous logical CPUs (sched_setaffinity), weights mapped from one shared file"
+        out = {"value": use["sample_steps_per_s"] / B, "unit": f"denoiser-steps/s (batch {B})", "cores": used, "host_cores": visible,
+               "cgroup_cpu_quota": quota, "kind": "port", "sample_steps_per_s": use["sample_steps_per_s"],
+               "sample": (f"oracle UNet forward (torch CPU fp32), T={T}, Lp={Lp}: best of {len(sweep) + 1} legs = {use['processes']} proc x {use['threads_per_process']} thr x "
+                          f"batch {use['batch_per_process']}, {use['seconds']:.1f} s window; {visible} CPUs visible, cgroup quota {quota if quota else 'none'}"),
+               "numa": _numa_layout(), "pinning": pinned, "single_process": single, "all_cores": agg, "all_cores_sweep": sweep}
+        return out, (x.numpy(), content.numpy(), prompt.numpy(), mask.numpy(), t_par.numpy(), y_ref.numpy()), samp
+    finally:
+        for fpath in (wpath, wpath + ".json"):
+            if wpath and os.path.exists(fpath):
                 try:
-                    p.kill()
-                except Exception:
+                    os.remove(fpath)
+                except OSError:
                     pass
-        sweep.append(leg)
-        if "sample_steps_per_s" in leg and (agg is None or leg["sample_steps_per_s"] > agg["sample_steps_per_s"]):
-            agg = leg
-    nproc = agg["processes"] if agg else 1
-    use = agg if agg and "sample_steps_per_s" in agg and agg["sample_steps_per_s"] > single["sample_steps_per_s"] else single
-    used_cores = agg["processes"] * agg["threads_per_process"] if use is agg else th
-    # ---- the sampled latent of the timed solver on the first utterances (the oracle treats utterances independently)
-    samp = None
-    if sampler is not None:
-        from oracle import sampler_ref
-        solver, steps, nb = sampler
-        nb = max(1, min(nb, B))
-        torch.set_num_threads(th)
-        tc, tp, tm = content[:nb], prompt[:nb], mask[:nb]
-
-        def x0(xx, tt):
-            return unet_ref.denoiser(P, cfg, xx, tc, tp, tm, tt)
-        t0 = time.perf_counter()
-        betas = sampler_ref.linear_betas(1000)
-        ys = (sampler_ref.unipc_bh2(x0, betas, x[:nb].clone(), steps) if solver == "unipc" else
-              sampler_ref.dpm_solver_pp_2m(x0, betas, x[:nb].clone(), steps, 2 if steps >= 2 else 1))
-        samp = {"y": ys.numpy(), "items": nb, "seconds": time.perf_counter() - t0}
-    out = {"value": use["sample_steps_per_s"] / B, "unit": f"denoiser-steps/s (batch {B})", "cores": used_cores, "host_cores": cores, "kind": "port",
-           "sample_steps_per_s": use["sample_steps_per_s"],
-           "sample": (f"oracle UNet forward (torch CPU fp32) at T={T}, Lp={Lp}: " +
-                      (f"{agg['processes']} processes x {agg['threads_per_process']} threads x batch 4 for {agg['seconds']:.0f} s, samples/s summed (best of the all_cores_sweep grid)" if use is agg else
-                       f"one process, {th} threads, batch {B}, {n1} forwards in {dt:.1f} s")),
-           "single_process": single, "all_cores": agg, "all_cores_sweep": sweep}
-    return out, (x.numpy(), content.numpy(), prompt.numpy(), mask.numpy(), t_par.numpy(), y_ref.numpy()), samp
 
 
 # ------------------------------------------------------------------------------------------------
@@ -345,6 +408,64 @@ def roofline_block(fam, precision, step_ms, gflop_sample, B, shape):
     }
 
 
+def compact_line(d: dict) -> dict:
+    """The ONE stdout line (driver contract + roofline + cpu_baseline + parity), kept under 4 KB: the r5 line had grown to 21.5 KB and the
+    driver could no longer parse it.  Everything else is in the detail file (--detail-json)."""
+    def rnd(v, n=6):
+        return round(v, n) if isinstance(v, float) else v
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    o = {k: rnd(d[k]) for k in keep}
+    o["data"] = "synthetic" if d["data"].startswith("synthetic") else d["data"]
+    o["config"] = d["config"]
+    r = d.get("roofline")
+    if r:
+        o["roofline"] = {"bound": r["bound"], "kernel": "implicit-GEMM family: conv3ts + gemm4 + ffn + geglu + rowchain kernels (all MFMA launches but attention)",
+                         "achieved": rnd(r["achieved"], 2), "peak": r["peak"], "unit": r["unit"], "frac": rnd(r["frac"], 4),
+                         "frac_isolated": rnd(r["frac_isolated"], 4), "frac_rocprof": rnd(r["frac_rocprof"], 4), "rocprof_measured_at": r["rocprof_measured_at"],
+                         "traffic": r["traffic"], "traffic_source": (r["traffic_source"] or "").split(" ")[0] or None, "traffic_measured_at": r["traffic_measured_at"],
+                         "algorithmic_bytes_per_launch": rnd(r["algorithmic_bytes_per_launch"], 0), "algorithmic_gflop_per_launch": rnd(r["algorithmic_gflop_per_launch"], 4),
+                         "launches_per_step": r["launches_per_step"], "avg_launch_us": rnd(r["avg_launch_us"], 3), "family_ms_in_loop": rnd(r["family_ms_in_loop"], 4),
+                         "whole_step_frac_of_mfma_peak": rnd(r["whole_step"]["frac_of_mfma_peak"], 4)}
+    else:
+        o["roofline"] = None
+    c = d.get("cpu_baseline")
+    o["cpu_baseline"] = ({k: rnd(c.get(k), 5) for k in ("value", "unit", "cores", "host_cores", "cgroup_cpu_quota", "kind", "sample")} if c else None)
+    if d.get("speedup_vs_cpu_baseline"):
+        o["speedup_vs_cpu_baseline"] = rnd(d["speedup_vs_cpu_baseline"], 1)
+    pz = d.get("parity")
+    if pz:
+        sl = pz.get("sampled_latent")
+        o["parity"] = {"rel_l2_vs_oracle": rnd(pz["rel_l2_vs_oracle"], 8), "sampled_latent": rnd(sl["rel_l2_vs_oracle"], 8) if sl else None,
+                       "sampled_items": sl["items"] if sl else None, "tolerance": pz["tolerance"], "mode": pz["mode"],
+                       "reference": "oracle/unet_ref.py + oracle/sampler_ref.py (pinned to the reference by tests/golden), B=32 forward / timed loop"}
+    else:
+        o["parity"] = None
+    o["launches_per_step"] = d["launches_per_step"]
+    o["rccl_ranks"] = d["rccl_ranks"]
+    o["finite"] = d["finite"]
+    o["graph_equals_eager"] = (d["loop_check"] or {}).get("graph_loop_equals_eager_loop")
+    o["jobs_ms"] = [rnd(v, 3) for v in d["timing"]["jobs_ms"]]
+    o["per_rank_ms_per_step"] = [rnd(v, 4) for v in d["per_rank_ms_per_step"]]
+    for k in ("all_gather_ms", "all_gather_bytes", "spawned_by", "dry_dist"):
+        if k in d:
+            o[k] = rnd(d[k], 4)
+    o["device"] = d["device"]
+    o["detail"] = "bench_detail.json (every block unabridged; --full adds fp32 / bf16 / configs 2 and 5 / strong scaling)"
+    return o
+
+
+def write_detail(path: str, d: dict) -> None:
+    if not path:
+        return
+    try:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(d, f, indent=1)
+        os.replace(tmp, path)
+    except Exception as ex:                              # a read-only tree must not take the line down
+        print(f"bench.py: could not write {path}: {ex!r}", file=sys.stderr)
+
+
 class DryEngine:
     """--dry-dist: stands in for ns2vc_amd.engine.Engine with the same call sequence.  A job sleeps ~0.2 ms per step and utterance
     and returns x_T / 2 (deterministic, so the gathered latents can be checked on every rank)."""
@@ -404,7 +525,7 @@ def main():
                 os.sched_setaffinity(0, set(avail[lo:hi]))
             except Exception:
                 pass
-        cpu_worker(a.cpu_worker, a.cpu_threads or 8, a.cpu_frames or T_frames, a.prompt_frames)
+        cpu_worker(a.cpu_worker, a.cpu_threads or 8, a.cpu_frames or T_frames, a.prompt_frames, max(1, a.cpu_batch), a.cpu_weights)
         return
     if "RANK" not in os.environ and a.gpus > 1:
         spawn_ranks(a)
@@ -559,9 +680,23 @@ def main():
         per_rank_ms = [float(v[0]) for v in allr]
         gather_ms = max(float(v[1]) for v in allr)
 
-    out = None
+    out = line = None
+    ref = samp = None
+    gflop_sample = PUBLISHED_GFLOP.get((T, Lp), algorithmic_gflop_per_sample_step(T, Lp))
+    def parity_of(engine, precision):
+        xr, cr, pr, mr, tr, yr = ref
+        d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (xr, cr, pr, mr.astype(np.uint8), tr.astype(np.float32))]
+        out = torch.empty_like(d[0])
+        with torch.cuda.stream(stream):
+            engine.set_condition(d[1], d[2], d[3], stream=stream)
+            engine.forward(d[0], d[4], out, stream=stream)
+            stream.synchronize()
+        y = out.cpu().numpy().astype(np.float64)
+        return {"mode": precision, "rel_l2_vs_oracle": float(np.linalg.norm(y - yr) / np.linalg.norm(yr)),
+                "shape": {"batch": B, "frames": T, "prompt_frames": Lp}, "tolerance": 1e-3,
+                "reference": "oracle/unet_ref.py (pinned bit-exact to the reference by tests/golden), one UNet forward, per-item timesteps 40..960"}
+
     if rank == 0:
-        gflop_sample = PUBLISHED_GFLOP.get((T, Lp), algorithmic_gflop_per_sample_step(T, Lp))
         step_ms = wall * 1e3 / K
         fam = roof = None
         if not dry:
@@ -570,25 +705,11 @@ def main():
 
         # ---- CPU baseline (oracle on the host cores) + parity of the timed precision at the bench shape
         cpu = parity = None
-        ref = samp = None
         if world == 1 and not a.skip_cpu and not dry:
             try:
-                cpu, ref, samp = cpu_baseline(T, Lp, B, a.cpu_budget, sampler=(solver, K, 4 if K <= 20 else 2))
+                cpu, ref, samp = cpu_baseline(T, Lp, B, a.cpu_budget, sampler=(solver, K, 2), W=W, full=a.full)
             except Exception as ex:                      # the baseline leg must never take the GPU number down
                 cpu = {"value": None, "unit": f"denoiser-steps/s (batch {B})", "cores": _host_cores(), "kind": "port", "sample": f"failed: {ex!r}"}
-
-        def parity_of(engine, precision):
-            xr, cr, pr, mr, tr, yr = ref
-            d = [torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (xr, cr, pr, mr.astype(np.uint8), tr.astype(np.float32))]
-            out = torch.empty_like(d[0])
-            with torch.cuda.stream(stream):
-                engine.set_condition(d[1], d[2], d[3], stream=stream)
-                engine.forward(d[0], d[4], out, stream=stream)
-                stream.synchronize()
-            y = out.cpu().numpy().astype(np.float64)
-            return {"mode": precision, "rel_l2_vs_oracle": float(np.linalg.norm(y - yr) / np.linalg.norm(yr)),
-                    "shape": {"batch": B, "frames": T, "prompt_frames": Lp}, "tolerance": 1e-3,
-                    "reference": "oracle/unet_ref.py (pinned bit-exact to the reference by tests/golden), one UNet forward, per-item timesteps 40..960"}
         if ref is not None:
             parity = parity_of(eng, a.precision)
             if samp is not None:                       # the TIMED loop's output (same inputs: bench.r0) on the utterances the oracle sampled
@@ -599,10 +720,53 @@ def main():
                     "solver": solver, "steps": K, "tail_fp32": a.tail_fp32, "oracle_seconds": round(samp["seconds"], 1),
                     "reference": f"oracle/sampler_ref.py (pinned to the reference's own samplers by tests/golden) on utterances 0..{nb - 1} of the timed batch, identical noise"}
 
+        value = world * K / wall
+        out = {
+            "metric": METRIC, "value": value, "unit": "denoiser-steps/s (batch 32 per GPU, whole job)",
+            "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded hash inputs, procedural weights of the production UNet1DConditionModel)",
+            "config": {"workload": f"{a.seconds:g} s utterance (T={T} Vocos frames), batch {B}/GPU, prompt Lp={Lp}, {K}-step {solver} order {order}, "
+                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision} MFMA operands{' + fp8 PV in attention' if a.attn_fp8 else ''}"
+                                   f"{f' + last {a.tail_fp32} evaluations fp32' if a.tail_fp32 else ''}; timed job = set_condition + {K} steps"
+                                   + (" + all-gather of latents" if world > 1 else ""),
+                       "global_batch": B * world, "frames": T, "prompt_frames": Lp, "solver": solver, "parallelism": f"dp{world}"},
+            "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,
+                       "max_ms_per_step": max(walls) * 1e3 / K},
+            "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
+            "launches_per_step": launches, "workspace_gb": workspace_gb, "device": "none (dry run)" if dry else E.device_info(),
+            "attention_fallback_workgroups": attn_fb,
+            "gn_prologue_workgroups_alone": gn_alone,
+            "xcd_round_robin": (None if dry else E.xcd_round_robin()),
+            "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
+            "roofline": roof, "parity": parity, "cpu_baseline": cpu,
+            "self_check": None, "fp32_parity_mode": None, "bf16_as_stated": None, "other_configs": None, "strong_scaling": None,
+        }
+        if dry:
+            out["dry_dist"] = {"backend": "gloo", "engine": "stub (sleep + deterministic fill)", "note": "harness rehearsal, not a measurement"}
+            out["data"] = "dry run"
+        if world > 1:
+            out["all_gather_ms"] = gather_ms
+            out["all_gather_bytes"] = int(B * world * cfg.latent_channels * T * 4)     # what every rank receives: the finished latents of the global batch
+            out["spawned_by"] = "bench.py" if os.environ.get("NS2VC_BENCH_SPAWNED") else "launcher"
+        if cpu and cpu.get("value"):
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        if a.detail and roof:
+            for k, v in roof["families"].items():
+                print(f"  {k:14s} {v}", file=sys.stderr)
+        # ---- THE line: compact (< 4 KB), printed as soon as the headline, its roofline, parity and CPU baseline exist -- before any long leg
+        line = json.dumps(compact_line(out))
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
+        write_detail(a.detail_json, out)
+
+    # ---- the long legs (--full): results go to the detail file only ---------------------------------------------------------------------
+    full1 = bool(a.full and rank == 0 and world == 1 and not dry)
+    if full1:
+        t_full = time.perf_counter()
         # ---- what the served API measures about itself on this workload: Denoiser's precision self-check (16-bit vs exact-fp32 engine at
         # the first / middle / last evaluation point of the trajectory, batch figure and worst utterance) and the LayerNorm guard's ratio
         self_check = None
-        if world == 1 and not dry and a.precision != "fp32" and not a.skip_fp32:
+        if full1 and a.precision != "fp32" and not a.skip_fp32:
             try:
                 from ns2vc_amd.pipeline import Denoiser
                 den = Denoiser(W, cfg, precision=a.precision)
@@ -626,7 +790,7 @@ def main():
         fp32_block = None
         bf16_block = None
         e32 = None
-        if world == 1 and a.precision != "fp32" and not a.skip_fp32 and not dry:
+        if full1 and a.precision != "fp32" and not a.skip_fp32:
             eng.close()
             e32 = build("fp32")
             w32, _, _ = timed_jobs(e32, io, K, K, min(reps, 3), False)
@@ -673,7 +837,7 @@ def main():
 
         # ---- BASELINE configs 2 and 5, timed the same way (one GPU): parity against the exact-fp32 engine at the same shape
         others = None
-        if world == 1 and not a.skip_others and not dry:
+        if full1 and not a.skip_others:
             others = []
             try:
                 eng.close()
@@ -745,44 +909,14 @@ def main():
                 if k32 != "P":
                     v32[0].close()
 
-        value = world * K / wall
-        out = {
-            "metric": METRIC, "value": value, "unit": "denoiser-steps/s (batch 32 per GPU, whole job)",
-            "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.precision, "data": "synthetic (seeded hash inputs, procedural weights of the production UNet1DConditionModel)",
-            "config": {"workload": f"{a.seconds:g} s utterance (T={T} Vocos frames), batch {B}/GPU, prompt Lp={Lp}, {K}-step {solver} order {order}, "
-                                   f"{'hipGraph-captured' if use_graph else 'eager'} loop, {a.precision} MFMA operands{' + fp8 PV in attention' if a.attn_fp8 else ''}"
-                                   f"{f' + last {a.tail_fp32} evaluations fp32' if a.tail_fp32 else ''}; timed job = set_condition + {K} steps"
-                                   + (" + all-gather of latents" if world > 1 else ""),
-                       "global_batch": B * world, "frames": T, "prompt_frames": Lp, "solver": solver, "parallelism": f"dp{world}"},
-            "timing": {"jobs": reps, "statistic": "median", "jobs_ms": [w * 1e3 for w in walls], "min_ms_per_step": min(walls) * 1e3 / K,
-                       "max_ms_per_step": max(walls) * 1e3 / K},
-            "sample_steps_per_s": value * B, "rtf": wall / (B * a.seconds), "gpu_event_ms": gpu_ms, "finite": finite, "loop_check": loop_check,
-            "launches_per_step": launches, "workspace_gb": workspace_gb, "device": "none (dry run)" if dry else E.device_info(),
-            "attention_fallback_workgroups": attn_fb,
-            "gn_prologue_workgroups_alone": gn_alone,
-            "xcd_round_robin": (None if dry else E.xcd_round_robin()),
-            "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 0), "per_rank_ms_per_step": per_rank_ms,
-            "roofline": roof, "parity": parity, "self_check": self_check, "fp32_parity_mode": fp32_block, "bf16_as_stated": bf16_block, "other_configs": others, "strong_scaling": None,
-            "cpu_baseline": cpu,
-        }
-        if dry:
-            out["dry_dist"] = {"backend": "gloo", "engine": "stub (sleep + deterministic fill)", "note": "harness rehearsal, not a measurement"}
-            out["data"] = "dry run"
-        if world > 1:
-            out["all_gather_ms"] = gather_ms
-            out["all_gather_bytes"] = int(B * world * cfg.latent_channels * T * 4)     # what every rank receives: the finished latents of the global batch
-            out["spawned_by"] = "bench.py" if os.environ.get("NS2VC_BENCH_SPAWNED") else "launcher"
-        if cpu and cpu.get("value"):
-            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-        if a.detail and roof:
-            for k, v in roof["families"].items():
-                print(f"  {k:14s} {v}", file=sys.stderr)
+        out.update(self_check=self_check, fp32_parity_mode=fp32_block, bf16_as_stated=bf16_block, other_configs=others,
+                   full_legs_seconds=round(time.perf_counter() - t_full, 1))
+        write_detail(a.detail_json, out)
     # ---- strong scaling: BASELINE config 4's global batch split over the ranks (every rank takes part; rank 0 reports).  It runs
     # AFTER everything the headline needs (the headline engines are closed by now), and the ranks AGREE on having built their shard
     # engine before anyone enters the timed jobs' collectives: a rank that fails (e.g. out of memory) cannot leave the others in a barrier.
     strong = None
-    if not a.skip_strong:
+    if a.full and not a.skip_strong:
         from ns2vc_amd.dist import shard_range
         GB = a.strong_batch
         lo, hi = shard_range(GB, rank, world)
@@ -828,9 +962,17 @@ def main():
             es.close()
         del ios
 
-    if rank == 0:
+
+    if rank == 0 and a.full:
         out["strong_scaling"] = strong
-        print(json.dumps(out))
+        write_detail(a.detail_json, out)
+        print(line, flush=True)                     # the same compact line again, as the LAST line of stdout
+    for e_ in (eng, tail_eng):
+        try:
+            if e_ is not None:
+                e_.close()
+        except Exception:
+            pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
