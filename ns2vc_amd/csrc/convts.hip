@@ -71,6 +71,9 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #ifndef NS2VC_TS_KS_DEFAULT
 #define NS2VC_TS_KS_DEFAULT 0    // K-split consumer layout of the 64-column tile by default (set after the same-box A/B)
 #endif
+#ifndef NS2VC_TS_NL_DEFAULT
+#define NS2VC_TS_NL_DEFAULT 8    // loader waves (r5 session 6, tap-granular loop, same box: 3.564 ms/step with 8, 3.576 with 4)
+#endif
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
@@ -78,7 +81,22 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 // ahead (SW = 6) changed nothing against two (3.62 ms/step either way) -- the loop does not wait for latency: the DMA stream ALONE (consumers idle)
 // takes 95 % of the full kernel's time, i.e. the loop runs at the rate the L2 -> LDS path delivers tiles to all CUs at once (~22 B/clk/CU here).  So
 // the ring stays as shallow as the pipeline needs (72 / 96 KB: two 128 x 64 workgroups per CU); the counted-wait bookkeeping is written for any depth.
+//
+// r6 (tools/convoy_probe.hip, profiles/r06_convoy_probe.txt): the DMA-only replay of this loop's address stream runs 1637 / 1843 cycles per 64-channel chunk
+// (operands L2-warm / from the Infinity Cache) with one counted wait + one s_barrier per TAP step -- exactly the 262 ns per step of the r5 ablation build -- but
+// 783 / 1035 cycles per chunk with ONE wait + barrier per CHUNK (activation chunk and the chunk's three weight tiles issued back to back, two chunks ahead):
+// what bounded the K loop was neither the L2 hit rate (a run-ahead L2 prefetch of the XCD's unique lines made the replay 9 % SLOWER) nor an L2 -> LDS
+// ceiling, but the number of synchronisation points per byte in flight.  NS2VC_TS_CHUNK = 1 (default) runs the loop chunk-granular: the weight ring holds
+// whole chunks (9 tiles = 3 chunks at BN = 64, 6 tiles = 2 chunks at BN = 128: 120 / 144 KB of LDS), the consumers meet the loaders once per chunk and run the
+// chunk's taps back to back.  NS2VC_TS_CHUNK = 0 keeps the r5 tap-granular loop for A/B builds.
+#ifndef NS2VC_TS_CHUNK
+#define NS2VC_TS_CHUNK 1
+#endif
+#if NS2VC_TS_CHUNK
+template <int BN> struct TsRing { static constexpr int SW = BN == 64 ? 9 : 6; };
+#else
 template <int BN> struct TsRing { static constexpr int SW = 3; };
+#endif
 // s_waitcnt vmcnt(n) for a wave-uniform n in [LO, HI]: the count is an immediate, so a binary tree of scalar branches picks it
 template <int LO, int HI> struct TsWait {
   static __device__ __forceinline__ void run(int n) {
@@ -106,7 +124,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   constexpr int SW = TsRing<BN>::SW, D = SW - 1;                 // weight ring: a tile is issued D steps ahead
   constexpr unsigned SZB = sizeof(TM);
   static_assert(BN == 64 || BN == 128, "BN");
-  static_assert(LA >= 1 && LB >= 1 && D * LB + 3 * LA <= 60, "vmcnt range");
+  static_assert(LA >= 1 && LB >= 1 && (NS2VC_TS_CHUNK ? SW : D) * LB + 3 * LA <= 60, "vmcnt range");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const aring = smem;                                      // 3 activation chunks
   char* const wring = smem + 3 * TS_ASLOT;                       // SW weight tiles
@@ -194,9 +212,37 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   };
   // the first D weight tiles depend on nothing but the tile's column: in flight while the row offsets (a division per piece) and
   // the GroupNorm prologue are still being worked out
+#if NS2VC_TS_CHUNK
+  // Chunk-granular schedule, fixed: the weight tiles of chunk c go out DG chunks ahead (DG = 2 with the 9-tile ring, 1 with the 6-tile ring), its rows two
+  // chunks ahead; within a step weights first, rows second.  The loader's own instruction stream is what bounded the r5 loop (r6 trace: 140-250 cycles of
+  // mostly scalar cursor arithmetic and branches per DMA instruction, so that eight loader waves delivered no more than four): the cursors here are one
+  // running tile index (tile-major weights: soffset = index * 8 KB), one ring slot each, and the waits take one of four immediates.
+  constexpr int DG = SW / 3 - 1;
+  int wtile = 0, wslot = 0;                                      // next weight tile of the stream / its ring slot
+  auto issue_wchunk = [&](int c) __attribute__((always_inline)) {  // the tiles of chunk c: three taps, or the single tap of a 1x1-segment chunk
+    const int nt = c < ncm ? 3 : 1;
+    if (wtiled) {
+      if (loader) {
+        for (int t = 0; t < nt; ++t) {
+          const unsigned base = lds0 + 3 * TS_ASLOT + wslot * WSLOT + wave * 1024;
+#pragma unroll
+          for (int j = 0; j < LB; ++j) blds16(rWt, vwt[j], (unsigned)wtile * 8192u, base + j * PASSB);
+          ++wtile;
+          wslot = wslot == SW - 1 ? 0 : wslot + 1;
+        }
+      }
+    } else {
+      for (int t = 0; t < nt; ++t) { issue_w(wslot); wslot = wslot == SW - 1 ? 0 : wslot + 1; }
+    }
+  };
+#pragma unroll
+  for (int d = 0; d < DG; ++d)
+    if (d < NCH) issue_wchunk(d);
+#else
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < S) issue_w(d);
+#endif
 
   unsigned off0[LA], off1[LA], off2[LA];
 #pragma unroll
@@ -265,14 +311,16 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     const char* const brow = wring + (wn * 64 + l31) * TS_ROW;
     unsigned long long t_bar = 0, t_mma = 0, t0 = 0;
     (void)t_bar; (void)t_mma; (void)t0;
-    auto step = [&](auto TAU, int aoff, int woff) __attribute__((always_inline)) {
+    auto step = [&](auto TAU, int aoff, int woff, bool meet = true) __attribute__((always_inline)) {
       constexpr int tau = decltype(TAU)::value;
       const int swa = ((l31 + tau) >> 1) & 7;
       const char* ap = arow + aoff + tau * TS_ROW;
       const char* bp = brow + woff;
       TS_CLK(t0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my fragment reads of the slots about to be refilled are done
-      __builtin_amdgcn_s_barrier();
+      if (meet) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // my fragment reads of the slots about to be refilled are done
+        __builtin_amdgcn_s_barrier();
+      }
       TS_ACC(t_bar, t0);
       // every fragment read of the step first (one consumer wave per SIMD: nothing else hides the LDS round trip); the compiler's
       // counted waits then release the MFMAs one k-slab at a time
@@ -312,8 +360,8 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     auto nextw = [&]() __attribute__((always_inline)) { woff = woff == (SW - 1) * WSLOT ? 0 : woff + WSLOT; };
     for (int ch = 0; ch < ncm; ++ch) {
       step(std::integral_constant<int, 0>{}, aoff, woff); nextw();
-      step(std::integral_constant<int, 1>{}, aoff, woff); nextw();
-      step(std::integral_constant<int, 2>{}, aoff, woff); nextw();
+      step(std::integral_constant<int, 1>{}, aoff, woff, !NS2VC_TS_CHUNK); nextw();     // (chunk-granular: the chunk's taps back to back)
+      step(std::integral_constant<int, 2>{}, aoff, woff, !NS2VC_TS_CHUNK); nextw();
       aoff = aoff == 2 * TS_ASLOT ? 0 : aoff + TS_ASLOT;
     }
     for (int ch = 0; ch < ncs; ++ch) {
@@ -322,6 +370,30 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     }
     TS_PUT(8, t_bar); TS_PUT(9, t_mma);
   } else {
+#if NS2VC_TS_CHUNK
+    // One wait + one barrier per chunk.  Needed at chunk ch: its weight tiles and its rows.  Loads return in order, so what may stay in flight is what this
+    // wave issued after the later of the two: DG = 2: the tiles and rows of chunk ch + 1 (issued at step ch - 1; at ch = 0 only the rows of chunk 1 follow
+    // those of chunk 0 in the prologue); DG = 1: the rows of chunk ch + 1 (issued behind the tiles of chunk ch at step ch - 1).
+    unsigned long long t_wait = 0, t_bar = 0, t_iss = 0, t0 = 0;
+    (void)t_wait; (void)t_bar; (void)t_iss; (void)t0;
+    int aslot = 2;                                               // ring slot of the rows issued next (chunk ch + 2)
+    for (int ch = 0; ch < NCH; ++ch) {
+      TS_CLK(t0);
+      if (ch + 1 >= NCH) wait_vmcnt<0>();
+      else if (DG == 1 || ch == 0) wait_vmcnt<LA>();
+      else if (ch + 1 < ncm) wait_vmcnt<3 * LB + LA>();
+      else wait_vmcnt<LB + LA>();
+      TS_ACC(t_wait, t0);
+      __builtin_amdgcn_s_barrier();
+      TS_ACC(t_bar, t0);
+      if (!(NS2VC_TS_ABLATE & 2)) {
+        if (ch + DG < NCH) issue_wchunk(ch + DG);
+        if (ch + 2 < NCH) issue_a(ch + 2, aslot);
+      }
+      aslot = aslot == 2 ? 0 : aslot + 1;
+      TS_ACC(t_iss, t0);
+    }
+#else
     // Invariant: at step s everything issued before the weight tile of step s (issued FIRST at step s-D, or above) has landed.  Within a
     // step the weight tile goes before the activation chunk.  So what may still be in flight at step s is the chunk issued behind that
     // tile at step s-D and everything of steps s-D+1 .. s-1: hw / ha hold the piece counts of the last D steps ([0] = step s-1).  A chunk's
@@ -372,6 +444,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       if (++aslot == 3) aslot = 0;
       fs_m2 = fs_m1; fs_m1 = fs;
     }
+#endif
     TS_PUT(4, t_wait); TS_PUT(5, t_bar); TS_PUT(6, t_iss);
   }
   TS_STAMP(2);
@@ -564,7 +637,7 @@ template <typename TM> static hipError_t launch_ts_typed(const GemmArgs& g, int 
 hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, int ks, hipStream_t s) {
   if (!convts_eligible(g, prec)) return hipErrorInvalidValue;
   if (!bn) bn = convts_default_bn(g);
-  if (!nl) nl = 8;          // (r5 session 6, same box: 3.564 ms/step with 8 loader waves, 3.576 with 4)
+  if (!nl) nl = NS2VC_TS_NL_DEFAULT;
   if (ks < 0) ks = NS2VC_TS_KS_DEFAULT;
   if (g.N % bn) return hipErrorInvalidValue;
   switch (prec) {

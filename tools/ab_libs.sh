@@ -9,10 +9,10 @@ for r in 1 2; do
     set -- $cfg; lib=$1; shift
     ( for kv in "$@"; do export "$kv"; done
       if [ "$lib" != default ]; then export NS2VC_LIB=$PWD/ns2vc_amd/lib/variants/$lib/libns2vc_hip.so; fi
-      timeout 300 python bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 10 --reps 3 2>/dev/null | python -c "
+      timeout 300 python bench.py --skip-cpu --detail-json= --steps 20 --warmup 10 --reps 3 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l[:1]==chr(123)][-1])
-print('$cfg', round(d['ms_per_step'],4), d.get('launches_per_step'), d['loop_check']['graph_loop_equals_eager_loop'], {k: round(v2['ms_per_step_isolated'],4) for k,v2 in d['roofline']['families'].items() if k in ('implicit_gemm','norm_stats','attention')})
+print('$cfg', round(d['ms_per_step'],4), d.get('launches_per_step'), d['graph_equals_eager'], {'gemm_family_ms_in_loop': d['roofline']['family_ms_in_loop'], 'frac_isolated': d['roofline']['frac_isolated']})
 " )
   done
 done

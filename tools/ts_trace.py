@@ -54,6 +54,8 @@ for name, T, Cin, N in shapes:
         check(lib.ns2vc_debug_set_gemm_trace(None), "trace")
         t = Tr.to_numpy((nblk, W), dtype=np.uint64).astype(np.float64)
         t = t[t[:, (3 if ts else 6)] > 0]                         # (padding workgroups of a cooperative grid return at once)
+        if len(t) == 0:                                           # (this object was not built with TRACE=1)
+            continue
         t0 = t[:, 0].min()
         if ts:
             steps = 3 * (Cin // 64)
