@@ -109,13 +109,18 @@ template <int LO, int HI> struct TsWait {
 // 8 KB instead of 12 KB of fragment reads per wave and step (1 KB per MFMA instead of 1.5); the two K halves meet in the LDS-staged epilogue as
 // gemm4_kernel's do.  Measured (r5 session 11): 11.9 vs 11.5 us isolated, 3.543 vs 3.542 ms/step in situ -- the consumers hide under the DMA stream either
 // way (profiles/r05_ts_ablate.txt), so it stays a tested option (NS2VC_TS_KS_DEFAULT 0).
-template <typename TM, int BN, int NL, bool GNP, bool KS = false>
+// GNP: 0 = no GroupNorm in front, 1 = the materialising prologue (gnpro.h GnPrologue: rows written to a0, read back by DMA), 2 = the loader waves
+// normalise inside the K loop (gnpro.h GnInloop; chunk-granular loop only)
+template <typename TM, int BN, int NL, int GNP, bool KS = false>
 __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
   constexpr int BKE = 8 * EPC;                                   // channels per chunk
   constexpr int NW = NL + 4, EOFF = NW - 8;                      // waves; first wave with a role in the 8-wave epilogue
-  constexpr int LTH = NL * 64, RPP = LTH / 8, PASSB = RPP * TS_ROW;
+  // GNP == 2: the NL non-consumer waves split into NLD DMA waves (every LDS-DMA piece) and NL - NLD producer waves (the in-loop GroupNorm: only
+  // compiler-visible loads, so the compiler's own counted waits are exact there, while the DMA waves' inline-asm loads are counted by hand)
+  constexpr int NLD = GNP == 2 ? 4 : NL;
+  constexpr int LTH = NLD * 64, RPP = LTH / 8, PASSB = RPP * TS_ROW;
   constexpr int LA = TS_BM / RPP, LB = BN / RPP;                 // 16-B DMA pieces per loading thread: activation chunk / weight tile
   static_assert(!KS || BN == 64, "the K-split consumer layout is the 64-column tile's");
   constexpr int WGN = BN / 64, WGM = KS ? 2 : 4 / WGN, WM = TS_BM / WGM, MT = WM / 32, NT = 2;
@@ -128,11 +133,14 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const aring = smem;                                      // 3 activation chunks
   char* const wring = smem + 3 * TS_ASLOT;                       // SW weight tiles
+  char* const tabmem = smem + 3 * TS_ASLOT + SW * WSLOT;         // GNP == 2: the (mean, rstd) table, kept for the whole loop
+  static_assert(GNP != 2 || NS2VC_TS_CHUNK, "the in-loop GroupNorm rides the chunk-granular loop");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool loader = wave < NL, consumer = wave >= NL;
+  const bool loader = wave < NLD, consumer = wave >= NL;
+  const bool producer = GNP == 2 && wave >= NLD && wave < NL;
   const int ewave = wave - EOFF;                                 // role in the epilogue (< 0: none)
   const int cw = consumer ? wave - NL : 0;                       // consumer wave: its wave tile
   const int wm = KS ? cw >> 1 : cw / WGN, wn = KS ? 0 : cw % WGN;
@@ -278,7 +286,18 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     }
   };
 
-  if constexpr (GNP) {
+  using Gnl = GnInloop<TM, (NL - NLD) * 64 ? (NL - NLD) * 64 : 64>;
+  Gnl gnl;
+  typename Gnl::XSet xs;
+  const bool gnl_raw = GNP == 2 && g.gnp_raw != nullptr && tn == 0;     // the first column tile also writes the un-normalised operand copy
+  if constexpr (GNP == 2) {
+    auto real_below = [&](int q) __attribute__((always_inline)) { const int b = q / P; return b * T + min(q - b * P, T); };
+    const int rlo = real_below(max(q0 - 1, 0)), rhi = real_below(min(q0 + TS_BM - 1, MP));
+    gnl.setup(g, q0, producer ? tid - NLD * 64 : 0, rlo, rhi);
+    if (producer) gnl.load(g, 0, xs);                            // chunk 0's rows fly while the statistics are turned into (mean, rstd)
+    gnl.table(g, tid, tabmem);
+  }
+  if constexpr (GNP == 1) {
     if (g.gnp_x != nullptr) {
       // the real rows behind padded rows [q0 - 1, q0 + 127): f(q) = number of real rows with a padded index below q
       auto real_below = [&](int q) __attribute__((always_inline)) { const int b = q / P; return b * T + min(q - b * P, T); };
@@ -289,8 +308,17 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     }
   }
   TS_STAMP(7);
-  issue_a(0, 0);
-  if (NCH > 1) issue_a(1, 1);
+  if constexpr (GNP == 2) {
+    // chunk 0 is produced here (ncm >= 1), chunk 1's rows are requested; a single-tap chunk 1 (fused 1x1 segment behind ONE main chunk) comes by DMA
+    if (producer) {
+      gnl.produce(g, 0, xs, aring, tabmem, gnl_raw);
+      if (1 < ncm) gnl.load(g, 1, xs);
+    }
+    if (1 >= ncm && 1 < NCH) issue_a(1, 1);
+  } else {
+    issue_a(0, 0);
+    if (NCH > 1) issue_a(1, 1);
+  }
 
   f32x16_t acc[MT][NT];
 #pragma unroll
@@ -377,6 +405,40 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     unsigned long long t_wait = 0, t_bar = 0, t_iss = 0, t0 = 0;
     (void)t_wait; (void)t_bar; (void)t_iss; (void)t0;
     int aslot = 2;                                               // ring slot of the rows issued next (chunk ch + 2)
+    if constexpr (GNP == 2) {
+      if (producer) {
+        // producer waves: one chunk ahead of the consumers.  After barrier ch the consumers read chunk ch; chunk ch + 1 is built from the registers
+        // requested a step ago into the slot chunk ch - 2 left, then chunk ch + 2's rows are requested.  (All waits here are the compiler's.)
+        for (int ch = 0; ch < NCH; ++ch) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rows of chunk ch (written during step ch - 1) are in LDS
+          __builtin_amdgcn_s_barrier();
+          const int c1 = ch + 1;
+          if (c1 < ncm) {
+            gnl.produce(g, c1, xs, aring + (c1 % 3) * TS_ASLOT, tabmem, gnl_raw);
+            if (c1 + 1 < ncm) gnl.load(g, c1 + 1, xs);
+          }
+        }
+      } else {
+        // DMA waves: the tiles of chunk ch + DG, and the rows of a single-tap chunk ch + 2.  Behind the tiles (and DMA rows) of chunk ch: DG = 2: the tiles
+        // and DMA rows of chunk ch + 1 (step ch - 1, or the prologue); DG = 1: the DMA rows of chunk ch + 1.
+        auto nW = [&](int c) __attribute__((always_inline)) { return c < NCH ? (c < ncm ? 3 * LB : LB) : 0; };
+        auto nA = [&](int c) __attribute__((always_inline)) { return (c >= ncm && c < NCH) ? LA : 0; };
+        for (int ch = 0; ch < NCH; ++ch) {
+          const int allow = (DG == 2 ? nW(ch + 1) : 0) + nA(ch + 1);
+          TS_CLK(t0);
+          TsWait<0, 3 * LB + LA>::run(__builtin_amdgcn_readfirstlane(allow));
+          TS_ACC(t_wait, t0);
+          __builtin_amdgcn_s_barrier();
+          TS_ACC(t_bar, t0);
+          if (!(NS2VC_TS_ABLATE & 2)) {
+            if (ch + DG < NCH) issue_wchunk(ch + DG);
+            if (ch + 2 >= ncm && ch + 2 < NCH) issue_a(ch + 2, aslot);
+          }
+          aslot = aslot == 2 ? 0 : aslot + 1;
+          TS_ACC(t_iss, t0);
+        }
+      }
+    } else {
     for (int ch = 0; ch < NCH; ++ch) {
       TS_CLK(t0);
       if (ch + 1 >= NCH) wait_vmcnt<0>();
@@ -392,6 +454,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       }
       aslot = aslot == 2 ? 0 : aslot + 1;
       TS_ACC(t_iss, t0);
+    }
     }
 #else
     // Invariant: at step s everything issued before the weight tile of step s (issued FIRST at step s-D, or above) has landed.  Within a
@@ -600,7 +663,8 @@ hipError_t pack_conv3_tiled(const float* rows, int N, int ctot, int c2, int prec
   return hipSuccess;
 }
 
-static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)(bn == 64 ? TsRing<64>::SW : TsRing<128>::SW) * bn * TS_ROW; }
+// (+ 4 KB behind the rings: the (mean, rstd) table of the in-loop GroupNorm, which has to outlive the prologue)
+static constexpr size_t ts_lds_bytes(int bn) { return (size_t)3 * TS_ASLOT + (size_t)(bn == 64 ? TsRing<64>::SW : TsRing<128>::SW) * bn * TS_ROW + 4096; }
 
 bool convts_eligible(const GemmArgs& g, int prec) {
   const int bke = prec == PREC_F32 ? 32 : 64;
@@ -622,8 +686,14 @@ template <typename TM, int BN, int NL, bool KS> static hipError_t launch_ts_cfg(
   const int nbm = convts_row_blocks(g), nbn = g.N / BN;
   int nb = nbm * nbn;
   if (g.gnp_x && g.gnp_sync && nbn > 1) nb = 8 * ((nbm + 7) / 8) * nbn;      // cooperative prologue: row blocks per XCD, padded
-  if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, true, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
-  else hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, false, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  // GroupNorm in front: inside the loop (GnInloop: eight non-consumer waves = four DMA + four producer waves, chunk-granular loop, plain consumer layout) unless
+  // the caller asks for the materialising prologue (algo == 2)
+  constexpr bool HAS_INLOOP = NS2VC_TS_CHUNK && NL == 8 && !KS;
+  if (g.gnp_x && HAS_INLOOP && g.algo != 2) {
+    if constexpr (HAS_INLOOP) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 2, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  }
+  else if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 1, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+  else hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 0, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
   return hipGetLastError();
 }
 template <typename TM> static hipError_t launch_ts_typed(const GemmArgs& g, int bn, int nl, int ks, hipStream_t s) {
@@ -654,13 +724,17 @@ template <typename K> static hipError_t ts_set_lds(K kern, size_t bytes) {
 template <typename TM> static hipError_t ts_init_typed() {
   hipError_t e = hipSuccess;
 #define NS2VC_TS_SET(BN_, NL_)                                                                      \
-  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, false>, ts_lds_bytes(BN_));     \
-  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, true>, ts_lds_bytes(BN_))
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, 0>, ts_lds_bytes(BN_));     \
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, BN_, NL_, 1>, ts_lds_bytes(BN_))
   NS2VC_TS_SET(64, 4); NS2VC_TS_SET(128, 4); NS2VC_TS_SET(64, 8); NS2VC_TS_SET(128, 8);
-  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, false, true>, ts_lds_bytes(64));
-  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, true, true>, ts_lds_bytes(64));
-  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, false, true>, ts_lds_bytes(64));
-  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, true, true>, ts_lds_bytes(64));
+#if NS2VC_TS_CHUNK
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, 2>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 128, 8, 2>, ts_lds_bytes(128));
+#endif
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, 0, true>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, 1, true>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, 0, true>, ts_lds_bytes(64));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, 1, true>, ts_lds_bytes(64));
 #undef NS2VC_TS_SET
   return e;
 }

@@ -175,6 +175,9 @@ struct ns2vc_unet {
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
   bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
+  bool gn_inloop = false;      // ... normalising inside its K loop (gnpro.h GnInloop, r6) instead of materialising the rows in a prologue (GemmArgs.algo 0 vs 2).
+                               // Bit-identical results, measured SLOWER (profiles/r06_ab_gn_inloop.txt: 3.85 vs 3.61 ms/step; SiLU of a 128 x 64 chunk is 1.7 k VALU cycles per SIMD,
+                               // more than the consumers need for the chunk, and every column tile repeats it): a tested option, off
   int gn_coop_min = 2;         // fewest column tiles of a row block for which the cooperative prologue is used (tuning: NS2VC_GN_COOP_MIN under NS2VC_DEBUG_ENV)
   int cus = 256;               // compute units of this device (hipDeviceProp_t.multiProcessorCount): the "one round of workgroups" heuristics scale with it
   int xcd_probe = -1;          // misc.hip's placement probe of this device: 1 = workgroup ids 8 apart share an XCD
@@ -783,7 +786,7 @@ struct Planner {
     g.w_tiled = h->conv_wtiled ? w.wt : nullptr;     // (only the k = 3 / stride-1 launches of the tap-sharing kernel look at it)
     g.out_f32 = out_f32; g.ldo_f32 = ldo;
     g.out_op = out_op; g.ldo_op = ldo;
-    g.algo = h->conv_ts ? 0 : 1;
+    g.algo = h->conv_ts ? (h->gn_inloop ? 0 : 2) : 1;
     return g;
   }
   // GroupNorm of a (possibly concatenated) fp32 input: statistics -> per-(b,c) affine -> operand tensor `dst`
@@ -1315,6 +1318,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "slice_rows")) return &h->slice_rows;
   if (!strcmp(name, "conv_ts")) return &h->conv_ts;
   if (!strcmp(name, "conv_wtiled")) return &h->conv_wtiled;
+  if (!strcmp(name, "gn_inloop")) return &h->gn_inloop;
   return nullptr;
 }
 
@@ -1403,7 +1407,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1488,7 +1492,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }

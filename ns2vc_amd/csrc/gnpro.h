@@ -1,6 +1,7 @@
 // GroupNorm-apply prologue shared by the implicit-GEMM kernels (gemm.hip, convts.hip), gfx950.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace ns2vc {
 
@@ -246,6 +247,171 @@ template <typename TM, int XB_> struct GnPrologue {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();                                      // (the table area is free from here on)
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// r6: the GroupNorm-apply INSIDE the K loop of conv3ts_kernel (GemmArgs.algo == 0 with gnp_x set).
+//
+// The prologue above materialises a tile's normalised rows in global memory and reads them back by LDS-DMA: a chain of dependent round
+// trips (statistics + fp32 rows in, operand rows out and acknowledged, sibling arrival, first DMA) of 11-14 k cycles in front of a K loop
+// that at levels 0-1 is only 3-8 k cycles long (profiles/r05_ts_trace_gnp.txt) -- two thirds of the 31 level-0..2 conv launches of a step.
+// conv3ts_kernel's loader waves have nothing to do between their DMA issues, and an activation chunk is loaded ONCE per chunk there (not once
+// per tap as in the r1 conv3gn kernel, whose normalisation sat on the MFMA waves' critical path): so the loader waves now PRODUCE the chunk --
+// fp32 rows global -> VGPR (one step ahead), y = act(x * a + b) with exactly the prologue's / gn_apply_kernel's arithmetic (bit-identical
+// operand values), rounded to the operand type and written straight into the ring slot in the swizzled image the consumers read.  Nothing is
+// written to or re-read from global memory, no workgroup waits for another, and the first chunk is ready one load latency after the
+// statistics.  The column tiles of a row block each build the rows themselves (from the L2 they share); the redundant SiLU work that made
+// that form lose as a PROLOGUE (r4) runs beside the MFMAs here.  gnp_raw (the un-normalised operand copy a later 1x1 shortcut reads) is
+// written by the first column tile from the same registers.
+// ---------------------------------------------------------------------------
+template <typename TM, int LTH> struct GnInloop {
+  static constexpr int EPC = 16 / (int)sizeof(TM);                          // operand elements per 16-B piece
+  static constexpr int BKE = 8 * EPC;                                       // channels per chunk (a 128-B tile row)
+  static constexpr int QPR = BKE / 4;                                       // float4 quads per chunk row
+  static constexpr int RPQ = LTH / QPR;                                     // panel rows per pass of the LTH producer threads
+  static constexpr int NP = 128 / RPQ;                                      // passes = rows per thread and chunk
+  static constexpr int NX = NP + 8;                                         // loads per thread and chunk: rows + gamma, beta + 3 x (scale, shift)
+  static constexpr int TAB_BYTES = 4096;                                    // (mean, rstd) table [3][8] float2 | block sums [3][64] double2
+  static_assert(LTH % QPR == 0 && 128 % RPQ == 0, "producer geometry");
+  struct XSet { float4 x[NP], ga, be, ts[3], tf[3]; };
+
+  int quad, prow0, b_lo, nbi, Cg, C, c0a;
+  int roff[NP];                                                             // b * T + t of panel row prow0 + k * RPQ, or -1 (pad row / outside the tensor)
+  unsigned items;                                                           // 2 bits per row: its batch item - b_lo
+
+  // per-thread constants.  ltid = index among the LTH producer threads; panel row p holds padded row q0 - 1 + p
+  __device__ __forceinline__ void setup(const GemmArgs& g, int q0, int ltid, int rlo, int rhi) {
+    const int T = g.Tin, P = T + 1, MP = g.B * P;
+    C = g.c0; c0a = C - g.gnp_c1; Cg = C / g.gnp_G;
+    quad = ltid % QPR; prow0 = ltid / QPR;
+    b_lo = rlo / T;
+    nbi = (rhi - 1) / T - b_lo + 1;
+    items = 0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int qi = q0 - 1 + prow0 + k * RPQ;
+      const int b = qi > 0 ? qi / P : 0;
+      const int t = qi - b * P;
+      const bool ok = qi >= 0 && qi < MP && t < T;
+      roff[k] = ok ? qi - b : -1;
+      items |= (unsigned)(ok ? min(max(b - b_lo, 0), 2) : 0) << (2 * k);
+    }
+  }
+  // (mean, rstd) of every (item, group) the tile touches -> tab[item * 8 + group].  Every thread of the workgroup calls it (two barriers).
+  // Same finalisation as GnPrologue::finish / gn_apply_kernel: the block sums are exact, their order is free.
+  __device__ __forceinline__ void table(const GemmArgs& g, int tid, char* tabmem) {
+    const int T = g.Tin, G = g.gnp_G;
+    float2* const gtab = reinterpret_cast<float2*>(tabmem);
+    double2* const bsum = reinterpret_cast<double2*>(tabmem + 256);
+    const int nblk = C >> 4, nblk0 = c0a >> 4;
+    if (tid < nbi * nblk) {
+      const int bi = tid / nblk, blk = tid - bi * nblk;
+      const long long* st = blk < nblk0 ? g.gnp_stats + ((size_t)(b_lo + bi) * nblk0 + blk) * 2
+                                        : g.gnp_stats1 + ((size_t)(b_lo + bi) * (nblk - nblk0) + (blk - nblk0)) * 2;
+      bsum[tid] = make_double2((double)st[0] * (1.0 / GN_SUM_SCALE), (double)st[1] * (1.0 / GN_SQ_SCALE));
+    }
+    __syncthreads();
+    if (tid < nbi * G) {
+      const int bi = tid / G, gq = tid - bi * G;
+      const int nb = Cg >> 4;
+      double ds = 0.0, dq = 0.0;
+      for (int j = 0; j < nb; ++j) { const double2 e = bsum[bi * nblk + gq * nb + j]; ds += e.x; dq += e.y; }
+      const float inv_nf = 1.0f / ((float)T * (float)Cg);
+      const double inv_n = (double)inv_nf * (2.0 - (double)inv_nf * ((double)T * (double)Cg));
+      const double mean = ds * inv_n;
+      double var = dq * inv_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float ve = (float)var + g.gnp_eps;
+      float r = rsqrtf(ve);
+      r = r * (1.5f - 0.5f * ve * r * r);
+      gtab[bi * 8 + gq] = make_float2((float)mean, r);
+    }
+    __syncthreads();
+  }
+  // the NX loads of chunk ch (always NX of them, from clamped addresses: the counted waits rely on the number)
+  __device__ __forceinline__ void load(const GemmArgs& g, int ch, XSet& s) const {
+    const int cq = ch * BKE + quad * 4;
+    const float* xs; int xld;
+    if (cq < c0a) { xs = g.gnp_x + cq; xld = g.gnp_ldx; } else { xs = g.gnp_x1 + (cq - c0a); xld = g.gnp_ldx1; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) s.x[k] = *reinterpret_cast<const float4*>(xs + (size_t)max(roff[k], 0) * xld);
+    s.ga = *reinterpret_cast<const float4*>(g.gnp_gamma + cq);
+    s.be = *reinterpret_cast<const float4*>(g.gnp_beta + cq);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      // (item clamped to the tile's last one; without a time embedding the loads go to gamma: same count, values unused)
+      const float* tp = g.gnp_temb ? g.gnp_temb + (size_t)(b_lo + min(i, nbi - 1)) * g.gnp_ldtemb + cq : g.gnp_gamma + cq;
+      const float* tq = g.gnp_temb ? tp + C : tp;
+      if (((reinterpret_cast<uintptr_t>(tp) | reinterpret_cast<uintptr_t>(tq)) & 15) == 0) {
+        s.ts[i] = *reinterpret_cast<const float4*>(tp);
+        s.tf[i] = *reinterpret_cast<const float4*>(tq);
+      } else {                                                              // (an odd channel count / row stride: still two "loads" for the count's sake are 8 here -- the
+        s.ts[i] = make_float4(tp[0], tp[1], tp[2], tp[3]);                  //  counted waits then only wait longer than necessary)
+        s.tf[i] = make_float4(tq[0], tq[1], tq[2], tq[3]);
+      }
+    }
+  }
+  // act(x * a + b) of the loaded chunk -> ring slot `slot` (LDS address of its 16 KB), rows in the swizzled image the consumers read:
+  // byte r * 128 + ((c16 ^ ((r >> 1) & 7)) * 16) holds the 16-B piece c16 of panel row r.  `raw`: also store the un-normalised rows.
+  __device__ __forceinline__ void produce(const GemmArgs& g, int ch, const XSet& s, char* slot, const char* tabmem, bool raw) const {
+    const int cq = ch * BKE + quad * 4;
+    const int gg = cq / Cg;
+    float a[3][4], b[3][4];
+    const float gam[4] = {s.ga.x, s.ga.y, s.ga.z, s.ga.w}, bet[4] = {s.be.x, s.be.y, s.be.z, s.be.w};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i < nbi) {
+        float2 mr = reinterpret_cast<const float2*>(tabmem)[i * 8 + gg];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (the packed-product hazard of GnPrologue::affine: the pair lands before its first use)
+        asm volatile("" : "+v"(mr.x), "+v"(mr.y));
+        const float ts[4] = {s.ts[i].x, s.ts[i].y, s.ts[i].z, s.ts[i].w}, tf[4] = {s.tf[i].x, s.tf[i].y, s.tf[i].z, s.tf[i].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a[i][e] = mr.y * gam[e];
+          b[i][e] = bet[e] - mr.x * a[i][e];
+          if (g.gnp_temb) {
+            const float s1 = 1.0f + ts[e];
+            a[i][e] *= s1;
+            b[i][e] = b[i][e] * s1 + tf[e];
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[i][e] = a[0][e]; b[i][e] = b[0][e]; }
+      }
+    }
+    TM* const rawp = reinterpret_cast<TM*>(g.gnp_raw);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int p = prow0 + k * RPQ;
+      const int it = (items >> (2 * k)) & 3;
+      const float w4[4] = {s.x[k].x, s.x[k].y, s.x[k].z, s.x[k].w};
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ae = it == 0 ? a[0][e] : it == 1 ? a[1][e] : a[2][e];
+        const float be_ = it == 0 ? b[0][e] : it == 1 ? b[1][e] : b[2][e];
+        y[e] = w4[e] * ae + be_;
+      }
+      if (g.gnp_silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = silu_f(y[e]);
+      }
+      const bool ok = roff[k] >= 0;
+      if (!ok) { y[0] = y[1] = y[2] = y[3] = 0.f; }
+      if constexpr (sizeof(TM) == 4) {
+        const int phys = quad ^ ((p >> 1) & 7);
+        *reinterpret_cast<float4*>(slot + p * 128 + phys * 16) = make_float4(y[0], y[1], y[2], y[3]);
+      } else {
+        const int phys = (quad >> 1) ^ ((p >> 1) & 7);
+        uint2 v;
+        if constexpr (std::is_same<TM, f16_t>::value) { v.x = pack_f16x2(y[0], y[1]); v.y = pack_f16x2(y[2], y[3]); }
+        else { v.x = pack_bf16x2(y[0], y[1]); v.y = pack_bf16x2(y[2], y[3]); }
+        *reinterpret_cast<uint2*>(slot + p * 128 + phys * 16 + (quad & 1) * 8) = v;
+      }
+      if (raw && ok) out_op4<TM>(rawp + (size_t)roff[k] * g.lda0 + cq, w4[0], w4[1], w4[2], w4[3]);
     }
   }
 };
