@@ -74,6 +74,9 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #ifndef NS2VC_TS_NL_DEFAULT
 #define NS2VC_TS_NL_DEFAULT 8    // loader waves (r5 session 6, tap-granular loop, same box: 3.564 ms/step with 8, 3.576 with 4)
 #endif
+#ifndef NS2VC_TS_NLD4
+#define NS2VC_TS_NLD4 0          // four DMA waves in the chunk-granular loop of the eight-loader kernels: faster isolated (L2-warm operands), 0.8 % SLOWER in the step
+#endif                           // (3.645 vs 3.617 ms/step same box, profiles/r06_ab_chunk_loop.txt) -- off
 #ifndef NS2VC_CONS_PF
 #define NS2VC_CONS_PF 1          // consumer waves: every fragment read of a step before its first MFMA (0: the compiler's order)
 #endif
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
   constexpr int NW = NL + 4, EOFF = NW - 8;                      // waves; first wave with a role in the 8-wave epilogue
   // GNP == 2: the NL non-consumer waves split into NLD DMA waves (every LDS-DMA piece) and NL - NLD producer waves (the in-loop GroupNorm: only
   // compiler-visible loads, so the compiler's own counted waits are exact there, while the DMA waves' inline-asm loads are counted by hand)
-  constexpr int NLD = GNP == 2 ? 4 : NL;
+  // NS2VC_TS_NLD4 (diagnostic, off): four DMA waves also when all eight are loaders otherwise.  Isolated, with L2-warm operands, the level-3 convs run
+  // 16.5 / 11.2 us with four and 18.4 / 12.1 us with eight DMA waves; inside the step (operands from the Infinity Cache) eight are better.
+  constexpr int NLD = (GNP == 2 || (NS2VC_TS_CHUNK && NS2VC_TS_NLD4 && NL == 8)) ? 4 : NL;
   constexpr int LTH = NLD * 64, RPP = LTH / 8, PASSB = RPP * TS_ROW;
   constexpr int LA = TS_BM / RPP, LB = BN / RPP;                 // 16-B DMA pieces per loading thread: activation chunk / weight tile
   static_assert(!KS || BN == 64, "the K-split consumer layout is the 64-column tile's");
@@ -438,6 +443,8 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
           TS_ACC(t_iss, t0);
         }
       }
+    } else if (!loader) {
+      for (int ch = 0; ch < NCH; ++ch) __builtin_amdgcn_s_barrier();      // (prologue / epilogue waves)
     } else {
     for (int ch = 0; ch < NCH; ++ch) {
       TS_CLK(t0);
