@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NS2VC_ABI_VERSION 6
+#define NS2VC_ABI_VERSION 7
 #define NS2VC_MAX_LEVELS 8
 #define NS2VC_NCOEF 12 /* floats per row of the solver table, ns2vc_amd/schedule.py:COEF_COLUMNS */
 
@@ -253,6 +253,16 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * tap-sharing kernel then reads every (64-column group, step) weight block as 8 KB of consecutive bytes instead of 64 row segments
    * K * 2 bytes apart (-1.1 % of the step: the tiles come from beyond L2 every step); `w` is still required (other kernels, fallbacks). */
   const void* w_tiled;
+  /* ABI v7.  algo also takes 2: the tap-sharing kernel with the materialising GroupNorm prologue; with algo = 0 and gnp_x set it MAY normalise
+   * inside its K loop instead (nothing is written to a0 then; same values).
+   * ABI v7, optional (k = 3 / stride-1 launches of the tap-sharing kernel with ONE column tile, i.e. N == 128: the denoiser's conv_out): the
+   * solver update of the sampling loop (sampler/uni_pc.py:471-588, sampler/dpm_solver.py:433-442, 547-580 as restated in
+   * ns2vc_amd/schedule.py) applied to the result in the epilogue instead of by a separate ns2vc_k_solver_update launch: with x0 = the
+   * conv's result (bias added), row *sol_step of the coefficient table sol_coef [steps][sol_ncoef] and the solver state
+   * (sol_xe, sol_xbar, sol_d1, sol_mprev: fp32 [M][sol_ld], updated in place; sol_xe_op: the operand-typed copy of xe the next
+   * evaluation's conv_in reads) exactly the arithmetic of ns2vc_k_solver_update, element for element.  out_f32 / out_op may be NULL. */
+  const float* sol_coef; const int32_t* sol_step; int32_t sol_ncoef;
+  float* sol_xe; void* sol_xe_op; float* sol_xbar; float* sol_d1; float* sol_mprev; int32_t sol_ld;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libns2vc_hip.so")
 NCOEF = 12
 MAX_LEVELS = 8
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Ns2vcError(RuntimeError):
@@ -53,6 +53,8 @@ class GemmArgs(C.Structure):
         ("gnp_sync", C.c_void_p), ("gnp_alone", C.c_void_p),
         ("gnp_x1", C.c_void_p), ("gnp_ldx1", C.c_int32), ("gnp_c1", C.c_int32), ("gnp_stats1", C.c_void_p), ("gnp_raw", C.c_void_p),
         ("algo", C.c_int32), ("w_tiled", C.c_void_p),
+        ("sol_coef", C.c_void_p), ("sol_step", C.c_void_p), ("sol_ncoef", C.c_int32),
+        ("sol_xe", C.c_void_p), ("sol_xe_op", C.c_void_p), ("sol_xbar", C.c_void_p), ("sol_d1", C.c_void_p), ("sol_mprev", C.c_void_p), ("sol_ld", C.c_int32),
     ]
 
 

@@ -221,11 +221,26 @@ inline size_t operand_bytes(int prec) { return prec == PREC_F32 ? 4 : 2; }
 inline uint16_t f32_to_op16_bits(float v, int prec) { return prec == PREC_BF16 ? f32_to_bf16_bits(v) : f32_to_f16_bits(v); }
 inline float op16_bits_to_f32(uint16_t b, int prec) { return prec == PREC_BF16 ? bf16_bits_to_f32(b) : f16_bits_to_f32(b); }
 // fixed-point scales of the epilogue GroupNorm statistics (order-independent int64 atomics => deterministic)
+// One element of the fused solver update (ns2vc_amd/schedule.py documents the recurrence; sampler/dpm_solver.py:433-442, 547-580, sampler/uni_pc.py:471-588):
+// the x0 -> eps -> x0 round trip of the reference's model wrapper, literally, then the unified multistep update.  ONE definition, used by
+// solver_update_kernel (misc.hip) and by the conv_out epilogue of conv3ts_kernel (convts.hip): the two forms give the same bits.
+struct SolverCoef { float alpha, sigma, g0, g1, A, Bc, d1c, pc; };
+__device__ __forceinline__ SolverCoef solver_coef(const float* __restrict__ c) { return SolverCoef{c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8]}; }
+__device__ __forceinline__ void solver_upd(const SolverCoef& k, float vx0, float vxe, float vxb, float vd1, float vmp, float& oxe, float& oxb, float& od1, float& om) {
+  const float eps = (vxe - k.alpha * vx0) / k.sigma;
+  const float m = (vxe - k.sigma * eps) / k.alpha;
+  const float x = vxb - k.g0 * vd1 - k.g1 * (m - vmp);
+  const float nb = k.A * x - k.Bc * m;
+  const float nd = k.d1c * (vmp - m);
+  oxb = nb; od1 = nd; oxe = nb - k.pc * nd; om = m;
+}
+
 constexpr double GN_SUM_SCALE = 268435456.0;   // 2^28
 constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
+bool gemm_uses_convts(const GemmArgs& g, int prec);                        // would launch_gemm run this launch on the tap-sharing conv kernel (convts.hip)?
 int last_gemm_refusal_line();                                               // gemm.hip line of the argument check that refused the last launch on this thread (0: none), cleared by the call
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);
 hipError_t init_gemm_attributes();

@@ -601,6 +601,36 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       }
       vv[k] = v;
     }
+    if (g.sol_coef) {
+      // r6 (tested option, engine switch fuse_solver): the sampling loop's solver update on the tile this workgroup holds (conv_out: every latent row exactly
+      // once): the result is x0, the state rows are four more row loads -- one launch, 73 MB of reads and 15 MB of writes less per step than the separate
+      // kernel.  Measured time-neutral to 0.4 % slower (profiles/r06_ab_fuse_solver.txt): the separate kernel streams at HBM speed, these loads sit in the
+      // epilogue's dependent chain (hoisting them above the staging and pre-touching the lines from the loader waves moved nothing).
+      const SolverCoef sk = solver_coef(g.sol_coef + (size_t)(*g.sol_step) * g.sol_ncoef);
+      float4 sxe[NIT], sxb[NIT], sd1[NIT], smp[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const size_t o = (size_t)mrow[k] * g.sol_ld + ncol;
+        sxe[k] = *reinterpret_cast<const float4*>(g.sol_xe + o); sxb[k] = *reinterpret_cast<const float4*>(g.sol_xbar + o);
+        sd1[k] = *reinterpret_cast<const float4*>(g.sol_d1 + o); smp[k] = *reinterpret_cast<const float4*>(g.sol_mprev + o);
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        if (okr[k]) {
+          const size_t o = (size_t)mrow[k] * g.sol_ld + ncol;
+          float4 oxe, oxb, od1, om;
+          solver_upd(sk, vv[k].x, sxe[k].x, sxb[k].x, sd1[k].x, smp[k].x, oxe.x, oxb.x, od1.x, om.x);
+          solver_upd(sk, vv[k].y, sxe[k].y, sxb[k].y, sd1[k].y, smp[k].y, oxe.y, oxb.y, od1.y, om.y);
+          solver_upd(sk, vv[k].z, sxe[k].z, sxb[k].z, sd1[k].z, smp[k].z, oxe.z, oxb.z, od1.z, om.z);
+          solver_upd(sk, vv[k].w, sxe[k].w, sxb[k].w, sd1[k].w, smp[k].w, oxe.w, oxb.w, od1.w, om.w);
+          out_f4(g.sol_xe + o, oxe.x, oxe.y, oxe.z, oxe.w);
+          out_op4<TM>(reinterpret_cast<TM*>(g.sol_xe_op) + o, oxe.x, oxe.y, oxe.z, oxe.w);
+          out_f4(g.sol_xbar + o, oxb.x, oxb.y, oxb.z, oxb.w);
+          out_f4(g.sol_d1 + o, od1.x, od1.y, od1.z, od1.w);
+          out_f4(g.sol_mprev + o, om.x, om.y, om.z, om.w);
+        }
+      }
+    }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (okr[k]) {
@@ -678,6 +708,7 @@ bool convts_eligible(const GemmArgs& g, int prec) {
   if (g.taps != 3 || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.Tin < 66 || g.geglu || g.rowstats || g.ln_stats) return false;
   if ((g.N % 64) || (g.c0 % bke) || (g.c1 % bke) || (g.c2 % bke) || g.c0 + g.c1 < bke) return false;
   if ((unsigned long long)g.B * (g.Tin + 1) > 0x7fff0000ull) return false;
+  if (g.sol_coef && (g.N != 128 || !g.sol_step || !g.sol_xe || !g.sol_xe_op || !g.sol_xbar || !g.sol_d1 || !g.sol_mprev || (g.sol_ld & 3))) return false;
   return true;
 }
 // BN: 128-column tiles where they still give the chip one round of workgroups, 64 otherwise (and for N that is no multiple of 128)

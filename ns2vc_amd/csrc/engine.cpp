@@ -175,6 +175,10 @@ struct ns2vc_unet {
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
   bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
+  bool fuse_solver = false;    // the sampling loop's solver update runs in conv_out's epilogue (GemmArgs.sol_*, r6) instead of as its own launch: bit-identical,
+                               // one launch and 88 MB of HBM traffic less per step, but 0.1-0.4 % SLOWER in three same-box A/Bs (profiles/r06_ab_fuse_solver.txt) -- a tested option, off
+  GemmArgs conv_out_g;         // ... conv_out's launch arguments and its place in fwd_ops, kept by build_plan for that
+  int conv_out_idx = -1;
   bool gn_inloop = false;      // ... normalising inside its K loop (gnpro.h GnInloop, r6) instead of materialising the rows in a prologue (GemmArgs.algo 0 vs 2).
                                // Bit-identical results, measured SLOWER (profiles/r06_ab_gn_inloop.txt: 3.85 vs 3.61 ms/step; SiLU of a 128 x 64 chunk is 1.7 k VALU cycles per SIMD,
                                // more than the consumers need for the chunk, and every column tile repeats it): a tested option, off
@@ -1246,6 +1250,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     P.gn_fuse(g, pno);
     if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
     P.gemm("conv_out", g);
+    if (!sizing) { h->conv_out_g = g; h->conv_out_idx = (int)h->fwd_ops.size() - 1; }
     P.tap("out", h->x0, B * T, CP);
   }
   if (sizing) h->arena_bytes = P.off;
@@ -1319,6 +1324,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "conv_ts")) return &h->conv_ts;
   if (!strcmp(name, "conv_wtiled")) return &h->conv_wtiled;
   if (!strcmp(name, "gn_inloop")) return &h->gn_inloop;
+  if (!strcmp(name, "fuse_solver")) return &h->fuse_solver;
   return nullptr;
 }
 
@@ -1407,7 +1413,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1492,7 +1498,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -1635,7 +1641,23 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
   return 0;
 }
 
+// one evaluation + solver update.  r6: when conv_out is the plan's last launch and runs on the tap-sharing kernel, the update happens in its epilogue
+// (same arithmetic, element for element: common.h solver_upd) -- x0 is never written, the state tensors are read and written once instead of twice
+static bool solver_in_conv_out(ns2vc_unet* h, GemmArgs& g) {
+  if (!h->fuse_solver || h->debug || h->conv_out_idx < 0 || h->conv_out_idx != (int)h->fwd_ops.size() - 1) return false;
+  g = h->conv_out_g;
+  g.out_f32 = nullptr;
+  g.sol_coef = h->coef_dev; g.sol_step = h->step_dev; g.sol_ncoef = NS2VC_NCOEF;
+  g.sol_xe = h->xe; g.sol_xe_op = h->xe_op; g.sol_xbar = h->xbar; g.sol_d1 = h->d1; g.sol_mprev = h->mprev; g.sol_ld = h->CP;
+  return gemm_uses_convts(g, h->prec);
+}
 static int run_step(ns2vc_unet* h, hipStream_t s) {
+  GemmArgs g;
+  if (solver_in_conv_out(h, g)) {
+    if (run_ops(h->fwd_ops, s, 0, (size_t)h->conv_out_idx)) return 1;
+    HIPCHK(launch_gemm(g, h->prec, s));
+    return 0;
+  }
   if (run_ops(h->fwd_ops, s)) return 1;
   const size_t n = (size_t)h->B * h->T * h->CP;
   HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xe_op, h->prec, h->xbar, h->d1, h->mprev, n, s));

@@ -1081,7 +1081,7 @@ hipError_t launch_gemm(const GemmArgs& g_, int prec, hipStream_t s) {
   if (g.K % bke != 0 || g.c0 % bke != 0 || g.c1 % bke != 0 || g.c2 % bke != 0 || g.K != g.taps * (g.c0 + g.c1) + g.c2) return gemm_invalid(__LINE__);
   if (g.c2 && (!g.a2 || g.tmode != TMODE_SAME || (g.lda2 % (bke / 8)))) return gemm_invalid(__LINE__);
   if ((g.lda0 % (bke / 8)) || (g.c1 && (g.lda1 % (bke / 8)))) return gemm_invalid(__LINE__);    // 16-B aligned rows
-  if (!g.out_f32 && !g.out_op) return gemm_invalid(__LINE__);
+  if (!g.out_f32 && !g.out_op && !g.sol_coef) return gemm_invalid(__LINE__);     // (a solver epilogue's outputs are the state tensors)
   if (g.stats && (g.geglu || g.Tout < 64 || (g.N & 15))) return gemm_invalid(__LINE__);
   if (g.rowstats && g.geglu) return gemm_invalid(__LINE__);
   if (g.ln_stats && (!g.ln_wsum || g.ln_dim <= 0 || (g.ln_dim & 127) || g.ln_dim > 512)) return gemm_invalid(__LINE__);
@@ -1115,12 +1115,20 @@ hipError_t launch_gemm(const GemmArgs& g_, int prec, hipStream_t s) {
       return launch_convts(g, prec, forced_ts ? g_force_bn : 0, forced_ts ? g_force_st % 10 : g_ts_nl, forced_ts ? (forced_ks ? 1 : 0) : g_ts_ks, s);
     if (forced_ts) return gemm_invalid(__LINE__);
   }
+  if (g.sol_coef) return gemm_invalid(__LINE__);             // the solver epilogue exists in the tap-sharing kernel only
   switch (prec) {
     case PREC_BF16: return launch_typed<bf16_t>(g, s);
     case PREC_F16: return launch_typed<f16_t>(g, s);
     case PREC_F32: return launch_typed<float>(g, s);
     default: return gemm_invalid(__LINE__);
   }
+}
+
+// would launch_gemm hand this launch to the tap-sharing conv kernel right now?  (the engine asks before it folds the solver update into conv_out)
+bool gemm_uses_convts(const GemmArgs& g, int prec) {
+  const bool forced_ks = g_force_bm == 128 && g_force_bn == 64 && (g_force_st == 64 || g_force_st == 68);
+  const bool forced_ts = (g_force_bm == 128 && (g_force_st == 54 || g_force_st == 58)) || forced_ks;
+  return g.algo != 1 && (forced_ts || (g_ts && !g_force_bm)) && convts_eligible(g, prec);
 }
 
 template <typename K> static hipError_t set_lds(K kern, size_t bytes) {

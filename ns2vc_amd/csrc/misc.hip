@@ -521,8 +521,7 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
                                                             float* __restrict__ xbar, float* __restrict__ d1,
                                                             float* __restrict__ mprev, size_t n4) {
   op_mode_init<TM>();
-  const float* c = coef + (size_t)(*step_ptr) * ncoef;
-  const float alpha = c[1], sigma = c[2], g0 = c[3], g1 = c[4], A = c[5], Bc = c[6], d1c = c[7], pc = c[8];
+  const SolverCoef k = solver_coef(coef + (size_t)(*step_ptr) * ncoef);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 vx0 = reinterpret_cast<const float4*>(x0)[i];
     const float4 vxe = reinterpret_cast<const float4*>(xe)[i];
@@ -530,17 +529,10 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
     const float4 vd1 = reinterpret_cast<const float4*>(d1)[i];
     const float4 vmp = reinterpret_cast<const float4*>(mprev)[i];
     float4 oxe, oxb, od1, om;
-#define NS2VC_UPD(f)                                         \
-  {                                                          \
-    const float eps = (vxe.f - alpha * vx0.f) / sigma;       \
-    const float m = (vxe.f - sigma * eps) / alpha;           \
-    const float x = vxb.f - g0 * vd1.f - g1 * (m - vmp.f);   \
-    const float nb = A * x - Bc * m;                         \
-    const float nd = d1c * (vmp.f - m);                      \
-    oxb.f = nb; od1.f = nd; oxe.f = nb - pc * nd; om.f = m;  \
-  }
-    NS2VC_UPD(x) NS2VC_UPD(y) NS2VC_UPD(z) NS2VC_UPD(w)
-#undef NS2VC_UPD
+    solver_upd(k, vx0.x, vxe.x, vxb.x, vd1.x, vmp.x, oxe.x, oxb.x, od1.x, om.x);
+    solver_upd(k, vx0.y, vxe.y, vxb.y, vd1.y, vmp.y, oxe.y, oxb.y, od1.y, om.y);
+    solver_upd(k, vx0.z, vxe.z, vxb.z, vd1.z, vmp.z, oxe.z, oxb.z, od1.z, om.z);
+    solver_upd(k, vx0.w, vxe.w, vxb.w, vd1.w, vmp.w, oxe.w, oxb.w, od1.w, om.w);
     out_f4(xe + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
     out_op4<TM>(xe_op + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
     out_f4(xbar + 4 * i, oxb.x, oxb.y, oxb.z, oxb.w);

@@ -362,7 +362,7 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/ns2vc_hip.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert lib.ns2vc_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.ns2vc_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_no_packed_fp32_of_the_failing_form_under_outstanding_lds_reads():
