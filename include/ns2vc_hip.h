@@ -263,6 +263,10 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * evaluation's conv_in reads) exactly the arithmetic of ns2vc_k_solver_update, element for element.  out_f32 / out_op may be NULL. */
   const float* sol_coef; const int32_t* sol_step; int32_t sol_ncoef;
   float* sol_xe; void* sol_xe_op; float* sol_xbar; float* sol_d1; float* sol_mprev; int32_t sol_ld;
+  /* ABI v7: column tile of the tap-sharing kernel for this launch: 0 = the library's heuristic for the current device, 64 | 128 = fixed.  The engine
+   * decides per plan (from ITS device's CU count) and passes the choice along, so that two engines on different devices -- or a debug hook called
+   * between plan build and launch -- cannot change a launch's tiling relative to what its plan assumed. */
+  int32_t conv_bn;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

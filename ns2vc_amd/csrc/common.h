@@ -246,7 +246,8 @@ hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream
 hipError_t init_gemm_attributes();
 // tap-sharing k = 3 conv kernel (convts.hip)
 bool convts_eligible(const GemmArgs& g, int prec);
-int convts_default_bn(const GemmArgs& g);
+int convts_default_bn(const GemmArgs& g);                                  // g.conv_bn if set, else the heuristic with the process default (debug hooks)
+int convts_bn_for(const GemmArgs& g, int bn128_min);                       // the heuristic: 128-column tiles while they still give bn128_min workgroups
 void set_convts_bn128_min(int wgs);
 int convts_row_blocks(const GemmArgs& g);
 hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, int ks, hipStream_t s);

@@ -714,10 +714,11 @@ bool convts_eligible(const GemmArgs& g, int prec) {
 // BN: 128-column tiles where they still give the chip one round of workgroups, 64 otherwise (and for N that is no multiple of 128)
 static int g_bn128_min = 160;
 void set_convts_bn128_min(int wgs) { g_bn128_min = wgs > 0 ? wgs : 160; }
-int convts_default_bn(const GemmArgs& g) {
+int convts_bn_for(const GemmArgs& g, int bn128_min) {
   const long long nbm = ((long long)g.B * (g.Tin + 1) + TS_BMO - 1) / TS_BMO;
-  return ((g.N % 128) == 0 && nbm * (g.N / 128) >= g_bn128_min) ? 128 : 64;
+  return ((g.N % 128) == 0 && nbm * (g.N / 128) >= bn128_min) ? 128 : 64;
 }
+int convts_default_bn(const GemmArgs& g) { return (g.conv_bn == 64 || (g.conv_bn == 128 && g.N % 128 == 0)) ? g.conv_bn : convts_bn_for(g, g_bn128_min); }
 int convts_row_blocks(const GemmArgs& g) { return (int)(((long long)g.B * (g.Tin + 1) + TS_BMO - 1) / TS_BMO); }
 
 template <typename TM, int BN, int NL, bool KS> static hipError_t launch_ts_cfg(const GemmArgs& g, hipStream_t s) {

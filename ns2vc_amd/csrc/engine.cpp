@@ -179,6 +179,8 @@ struct ns2vc_unet {
                                // one launch and 88 MB of HBM traffic less per step, but 0.1-0.4 % SLOWER in three same-box A/Bs (profiles/r06_ab_fuse_solver.txt) -- a tested option, off
   GemmArgs conv_out_g;         // ... conv_out's launch arguments and its place in fwd_ops, kept by build_plan for that
   int conv_out_idx = -1;
+  bool warned_wtiled = false;
+  int bn128_min = 160;         // workgroups a 128-column tap-sharing tiling must still give on THIS engine's device (5/8 of its CUs); per engine, not process-global
   bool gn_inloop = false;      // ... normalising inside its K loop (gnpro.h GnInloop, r6) instead of materialising the rows in a prologue (GemmArgs.algo 0 vs 2).
                                // Bit-identical results, measured SLOWER (profiles/r06_ab_gn_inloop.txt: 3.85 vs 3.61 ms/step; SiLU of a 128 x 64 chunk is 1.7 k VALU cycles per SIMD,
                                // more than the consumers need for the chunk, and every column tile repeats it): a tested option, off
@@ -393,9 +395,13 @@ struct Packer {
     PackedW p;
     const int Np = round_up(N, 128);
     p.N = Np; p.K = K;
-    if (tile3_ctot > 0 && K == 3 * tile3_ctot + tile3_c2) {
+    // (the second, tile-major copy only when the tap-sharing kernel will read it; when the layout cannot be built the kernel falls back to the
+    //  [N][K] rows and the engine says so once)
+    if (tile3_ctot > 0 && K == 3 * tile3_ctot + tile3_c2 && h->conv_ts && h->conv_wtiled) {
       std::vector<unsigned char> img;
-      if (pack_conv3_tiled(rows.data(), N, tile3_ctot, tile3_c2, h->prec, img) == hipSuccess) {
+      if (pack_conv3_tiled(rows.data(), N, tile3_ctot, tile3_c2, h->prec, img) != hipSuccess) {
+        if (!h->warned_wtiled) { fprintf(stderr, "ns2vc: tile-major conv weights unavailable for a %d x %d weight (channels not a multiple of the chunk): row-major fallback\n", N, K); h->warned_wtiled = true; }
+      } else {
         void* dt = nullptr;
         if (hipMalloc(&dt, img.size()) != hipSuccess) { err = fail("hipMalloc failed (tile-major weights)"); return p; }
         h->weight_allocs.push_back(dt);
@@ -772,6 +778,7 @@ struct Planner {
                          (g.out_op ? g.M * nout * osz : 0.0) + (g.res ? g.M * nout * 4.0 : 0.0);
     // (a GroupNorm prologue reads the fp32 rows and writes + re-reads the operand rows it builds)
     const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz * (g.gnp_raw ? 2.0 : 1.0)) : 0.0;
+    if (g.taps == 3 && g.tmode == TMODE_SAME && !g.conv_bn) g.conv_bn = convts_bn_for(g, h->bn128_min);     // the column tile is a PLAN decision (this engine's device)
     add(g.gnp_x ? name + "[+norm]" : name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes + pro);
     if (!sizing && g.gnp_x && g.gnp_sync) {
       unsigned* words = g.gnp_sync;
@@ -833,7 +840,7 @@ struct Planner {
         GemmArgs t;
         memset(&t, 0, sizeof(t));
         t.B = Bq; t.Tin = t.Tout = Tl; t.N = consumer_n;
-        nshare = consumer_n / convts_default_bn(t);
+        nshare = consumer_n / convts_bn_for(t, h->bn128_min);
       }
       if (h->gn_coop && nshare >= std::max(2, h->gn_coop_min)) { p.sync = new_sync(((size_t)Bq * Tl + 63) / 64); p.alone = (p.sync && h->ln_health) ? h->ln_health + 48 : nullptr; }
       return p;
@@ -1400,7 +1407,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
-    set_convts_bn128_min(h->cus * 5 / 8);      // 128-column tap-sharing tiles while they still give 5/8 of the CUs a workgroup (160 of 256)
+    h->bn128_min = h->cus * 5 / 8;             // 128-column tap-sharing tiles while they still give 5/8 of the CUs a workgroup (160 of 256)
   }
   // rows shared between workgroups through an XCD's L2 only where the placement probe has SEEN ids 8 apart on one XCD (and even then
   // every workgroup checks its own placement, gnpro.h)
@@ -1425,7 +1432,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       if (nl || ks) set_forced_gemm_tile(-4, ks ? (atoi(ks) ? 1 : 2) : 0, nl ? atoi(nl) : 0);
     }
     if (const char* v = getenv("NS2VC_GN_COOP_MIN")) h->gn_coop_min = atoi(v);
-    if (const char* v = getenv("NS2VC_TS_BN128_MIN")) set_convts_bn128_min(atoi(v));        // workgroups a 128-column tiling must still give to be chosen
+    if (const char* v = getenv("NS2VC_TS_BN128_MIN")) h->bn128_min = atoi(v) > 0 ? atoi(v) : h->bn128_min;        // workgroups a 128-column tiling must still give to be chosen
   }
   h->blocks = make_topology(*cfg);
   build_expected(h);
@@ -1876,8 +1883,23 @@ int ns2vc_memcpy_h2d(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcp
 int ns2vc_memcpy_d2h(void* dst, const void* src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; }
 int ns2vc_dev_sync(void) { HIPCHK(hipDeviceSynchronize()); return 0; }
 int ns2vc_stream_create(void** out) { hipStream_t s; HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); *out = s; return 0; }
+// NOTE: hipExtStreamCreateWithCUMask makes a DEFAULT (blocking) stream: it synchronises implicitly with the legacy null stream, so work
+// queued on the null stream serialises with it (keep PyTorch work on explicit streams when overlapping stages).  The mask is validated against the
+// device: at least one bit set, and no bit at or beyond the CU count.
 int ns2vc_stream_create_cu_mask(void** out, const uint32_t* mask_words, int n_words) {
   if (!out || !mask_words || n_words <= 0) return fail("null argument");
+  int dev = 0, cus = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (n_words > (cus + 31) / 32) return fail("CU mask of %d words for a device with %d CUs (at most %d words)", n_words, cus, (cus + 31) / 32);
+  bool any = false;
+  for (int w = 0; w < n_words; ++w)
+    for (int b = 0; b < 32; ++b)
+      if (mask_words[w] >> b & 1u) {
+        if (w * 32 + b >= cus) return fail("CU mask bit %d set, the device has %d CUs", w * 32 + b, cus);
+        any = true;
+      }
+  if (!any) return fail("empty CU mask");
   hipStream_t s;
   HIPCHK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask_words));
   *out = s;

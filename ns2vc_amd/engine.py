@@ -80,7 +80,8 @@ def _ptr(x) -> int:
 
 
 class Stream:
-    """A non-blocking HIP stream.  ``cu_mask`` (an iterable of CU indices, or None): restrict the stream's kernels to those CUs
+    """A HIP stream: non-blocking without a mask; with ``cu_mask`` it is created by hipExtStreamCreateWithCUMask, which makes a DEFAULT
+    (blocking) stream -- it synchronises implicitly with the legacy null stream, so keep other work off the null stream when overlapping.  ``cu_mask`` (an iterable of CU indices, or None): restrict the stream's kernels to those CUs
     (``hipExtStreamCreateWithCUMask``) -- how a pipeline gives the PyTorch stages a slice of the chip beside the denoiser."""
 
     def __init__(self, cu_mask=None):

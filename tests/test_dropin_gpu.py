@@ -291,17 +291,23 @@ def test_dropin_default_precision_is_the_checked_fast_engine(state, diag):
     # r5: the same weights are measured once more at the first call late in a trajectory (t < late_check_below) -- and only once
     assert m.precision_checks == 1
     t_late = torch.tensor([49.95, 49.95]).cuda()
+    m.check_min_interval_s = 0.0                        # (r6: the late re-check obeys the rate limit too)
     with torch.no_grad():
         yl = m(torch.cat([x, content], dim=1), t_late, prompt, encoder_attention_mask=mask).sample
         yl2 = m(torch.cat([x, content], dim=1), t_late, prompt, encoder_attention_mask=mask).sample
     diag(f"... late-timestep re-check (t = 49.95): {m.precision_checks} measurements, worst seen {m.precision_error_seen:.2e} / {m.precision_error_worst_item:.2e}")
     assert m.precision_checks == 2 and m._engine.precision == "fp16" and torch.equal(yl, yl2) and m.precision_error_seen <= 1e-3
+    m.check_min_interval_s = 30.0
     # ... and weights that change again within check_min_interval_s are not measured again (the last verdict stands): evaluation between optimizer steps
     with torch.no_grad():
         m.conv_out.bias.add_(0.0)                       # an in-place update: new weights key, same values
         y4 = m(torch.cat([x, content], dim=1), t, prompt, encoder_attention_mask=mask).sample
     assert m.precision_checks == 2 and m._engine.precision == "fp16" and torch.equal(y4, y)
-    m.check_min_interval_s = 0.0                        # (from here on every new set of weights is measured, as before r5)
+    # r6: ... but the measurement is deferred, not waived: the first call after the interval measures the new weights
+    m.check_min_interval_s = 0.0
+    with torch.no_grad():
+        y5 = m(torch.cat([x, content], dim=1), t, prompt, encoder_attention_mask=mask).sample
+    assert m.precision_checks == 3 and m._engine.precision == "fp16" and torch.equal(y5, y)
     # a checkpoint outside the fp16 range
     hot = {k: v.clone() for k, v in state.items()}
     rng = np.random.default_rng(1)
@@ -324,6 +330,15 @@ def test_dropin_default_precision_is_the_checked_fast_engine(state, diag):
     diag(f"... hot-channel x32 checkpoint: self-measured {m.precision_error_seen:.2e} -> demoted to {m._engine.precision}; served result vs the fp32 module {eh:.2e}")
     assert m._engine.precision == "fp32" and any("serving from the fp32 engine" in str(i.message) for i in w)
     assert eh < 1e-5 and torch.equal(yh, yh2)
+    # r6: a weight change INSIDE the rate-limit interval right after a demotion must not turn into unchecked fp16 -- the hot
+    # checkpoint family stays on the fp32 engine until a measurement is due
+    m.check_min_interval_s = 3600.0
+    n_checks = m.precision_checks
+    with torch.no_grad():
+        m.conv_out.bias.add_(0.0)                       # new weights key, same (hot) values
+        yh3 = m(torch.cat([x, content], dim=1), t, prompt, encoder_attention_mask=mask).sample
+    assert m._engine.precision == "fp32" and m.precision_checks == n_checks and rel_l2(yh3.cpu().numpy(), yr.cpu().numpy()) < 1e-5
+    m.check_min_interval_s = 0.0
     # back to the sane weights: the verdict is per set of weights
     m.load_state_dict(state, strict=True)
     with torch.no_grad():

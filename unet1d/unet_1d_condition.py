@@ -123,6 +123,7 @@ class UNet1DConditionModel(nn.Module):
         self.check_min_interval_s: float = 30.0
         self._late_checked_key = None
         self._last_check_time = None
+        self._last_verdict_ok: Optional[bool] = None                         # outcome of the last measurement (None: none yet); r6: a demotion is NOT forgotten inside the interval
         self.precision_checks = 0                                             # fp16-vs-fp32 measurements taken so far (diagnostics / tests)
         self._engine = None
         self._engine_key = None
@@ -174,8 +175,12 @@ class UNet1DConditionModel(nn.Module):
         from ns2vc_amd.engine import Engine
         key = self._weights_key()
         if self._engine is None or self._engine_key != key:
-            if self._auto and self._precision != "fp16" and self._precision_checked_key is not None and key[1] != self._precision_checked_key:
-                # new weights (an optimizer step, a reloaded checkpoint): the fallback verdict belonged to the old ones -- measure again
+            if self._auto and self._precision != "fp16" and self._precision_checked_key is not None and key[1] != self._precision_checked_key \
+                    and self._check_due():
+                # new weights (an optimizer step, a reloaded checkpoint): the fallback verdict belonged to the old ones -- measure again.  r6 (ADVICE r5,
+                # medium): only when a measurement is DUE.  Inside check_min_interval_s the module keeps serving the new weights from the fp32 engine
+                # (the last verdict was a demotion: the rate limit must not turn it into unchecked fp16) and returns to fp16 -- and measures -- at the
+                # first weight change after the interval.
                 self._precision = "fp16"
                 self.ln_guard = 8.0
                 key = self._weights_key()
@@ -187,6 +192,10 @@ class UNet1DConditionModel(nn.Module):
             self._prompt_key = self._prompt_hold = None
             self._ln_checked = self._ln_pending = False
         return self._engine
+
+    def _check_due(self) -> bool:
+        import time as _time
+        return self._last_check_time is None or (_time.monotonic() - self._last_check_time) >= self.check_min_interval_s
 
     def _auto_check(self, eng, out16, x, ts, content, prompt, mask, shape, stream, late: bool = False):
         """engine_precision="auto": the fp16 result of this call against the exact-fp32 engine on the same inputs, once per set of
@@ -213,7 +222,8 @@ class UNet1DConditionModel(nn.Module):
         # (the figures reported are the worst over the measurements taken on these weights)
         self.precision_error_seen = max(seen, self.precision_error_seen) if (late and self.precision_error_seen is not None) else seen
         self.precision_error_worst_item = max(worst, self.precision_error_worst_item) if (late and self.precision_error_worst_item is not None) else worst
-        if seen <= self.precision_check and worst <= self.precision_check:
+        self._last_verdict_ok = bool(seen <= self.precision_check and worst <= self.precision_check)
+        if self._last_verdict_ok:
             e32.close()
             return out16
         warnings.warn(f"UNet1DConditionModel(engine_precision='auto'): the fp16 engine is {self.precision_error_seen:.2e} (relative L2 over the batch; worst "
@@ -333,17 +343,26 @@ class UNet1DConditionModel(nn.Module):
             eng.forward(x, ts, out, stream=stream)
             self.engine_calls += 1
             if self._auto and self._precision == "fp16" and self.precision_check is not None:
-                import time as _time
                 wkey = self._engine_key[1]
                 first = self._precision_checked_key != wkey
-                late = (not first) and self._late_checked_key != wkey and float(ts.max()) < self.late_check_below
-                due = self._last_check_time is None or (_time.monotonic() - self._last_check_time) >= self.check_min_interval_s
+                due = self._check_due()
+                # r6: a measurement that is not due is DEFERRED, not waived -- the weights stay "unchecked" (first stays true) and are measured
+                # at the first call after the interval; in between the fp16 engine serves on the strength of the last verdict, which was a pass (after a
+                # demotion _get_engine keeps the fp32 engine for the whole interval).  The late re-check obeys the same rate limit, reads the timestep
+                # on the host when it can, and costs a device round trip at most once per interval otherwise (never while a stream is capturing).
+                late = False
+                if not first and due and self._late_checked_key != wkey and not torch.cuda.is_current_stream_capturing():
+                    if not torch.is_tensor(timestep):
+                        t_max = float(timestep)
+                    elif timestep.device.type == "cpu":
+                        t_max = float(timestep.max())
+                    else:
+                        t_max = float(ts.max())
+                    late = t_max < self.late_check_below
                 if first and not due:
-                    # weights changed again within the interval: the previous verdict (fp16 inside the bar) stands for them too
-                    self._precision_checked_key = wkey
                     self._warn_once("auto-rate", "UNet1DConditionModel(engine_precision='auto'): the weights change more often than once per "
-                                    f"{self.check_min_interval_s:g} s; the fp16-vs-fp32 check is rate-limited and the last verdict stands in between "
-                                    "(set engine_precision explicitly for a module under training)")
+                                    f"{self.check_min_interval_s:g} s; the fp16-vs-fp32 check is rate-limited: new weights are measured at the first call after "
+                                    "the interval, and served meanwhile on the last verdict (set engine_precision explicitly for a module under training)")
                 elif first or late:
                     if late:
                         self._late_checked_key = wkey
