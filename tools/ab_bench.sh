@@ -8,6 +8,6 @@ VAR=${1:?path of the variant libns2vc_hip.so}
 for i in 1 2 3; do
   for v in A B; do
     if [ $v = B ]; then export NS2VC_LIB=$PWD/$VAR; else unset NS2VC_LIB; fi
-    python bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 3 2>> gpurun_out/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],4), {k:round(v['ms_per_step_isolated'],3) for k,v in d['roofline']['families'].items()})"
+    python bench.py --skip-cpu --detail-json= --steps 20 --warmup 3 2>> gpurun_out/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['ms_per_step'],4), {'gemm_family_ms_in_loop': d['roofline']['family_ms_in_loop']})"
   done
 done

@@ -3,7 +3,7 @@
 # Every run is under its own `timeout`: ROC_SYSTEM_SCOPE_SIGNAL=0 hangs the process on this image (it cost a 15-minute GPU call)
 export NS2VC_DEBUG_ENV=1   # the plan switches (NS2VC_FUSE_*, NS2VC_CONV_TS, ...) are only read under this (r5)
 run() {
-  env "$@" timeout 120 python bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 3 2>> gpurun_out/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],4), round(d['timing']['min_ms_per_step'],4), d['loop_check']['graph_loop_equals_eager_loop'])"
+  env "$@" timeout 120 python bench.py --skip-cpu --detail-json= --steps 20 --warmup 3 2>> gpurun_out/ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],4), round(min(d['jobs_ms'])/d['steps'],4), d['graph_equals_eager'])"
 }
 for i in 1 2; do
   run X=0

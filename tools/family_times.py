@@ -32,10 +32,13 @@ def commit():
 
 
 bench = None
-for line in open(f_bench):
-    line = line.strip()
-    if line.startswith("{"):
-        bench = json.loads(line)
+try:                                   # r6: the unabridged record (bench.py --detail-json), one JSON document
+    bench = json.load(open(f_bench))
+except Exception:
+    for line in open(f_bench):         # (r1-r5: the one long stdout line)
+        line = line.strip()
+        if line.startswith("{"):
+            bench = json.loads(line)
 fams = bench["roofline"]["families"]
 per_step = {k: v["launches"] for k, v in fams.items()}
 tot, calls = {}, {}
@@ -50,7 +53,7 @@ for r in csv.DictReader(open(f_stats)):
 # r4's last builds have no norm family left to count by
 n_fwd = calls.get("attention", 0) / max(per_step.get("attention", 1), 1)
 out = {"source": "rocprofv3 --kernel-trace --stats -- " + " ".join(["python bench.py"] + [f"--{k.replace('_', '-')} {v}" for k, v in (("steps", bench["steps"]), ("warmup", bench["warmup"]))])
-                 + " --skip-cpu --skip-fp32 --skip-others --skip-strong",
+                 + " --skip-cpu --reps 3",
        "precision": bench["dtype"], "shape": [bench["config"]["global_batch"], bench["config"]["frames"], bench["config"]["prompt_frames"]],
        "commit": commit(), "forward_equivalents_in_trace": n_fwd, "step_ms": bench["ms_per_step"],
        "families": {f: {"calls": calls[f], "ms_per_step": tot[f] / 1e6 / max(n_fwd, 1e-9)} for f in tot}}

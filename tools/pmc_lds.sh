@@ -7,5 +7,5 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_${TAG}_lds
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/prof_${TAG}_lds \
-  -- python $R/bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 4 --warmup 4 --reps 1 > /dev/null 2> /tmp/prof_${TAG}_lds.err
+  -- python $R/bench.py --skip-cpu --detail-json= --steps 4 --warmup 4 --reps 1 > /dev/null 2> /tmp/prof_${TAG}_lds.err
 python $R/tools/pmc_lds_summarize.py "$(find /tmp/prof_${TAG}_lds -name '*counter_collection.csv' | head -1)" $R/gpurun_out/${TAG}_pmc_lds.json

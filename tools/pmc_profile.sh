@@ -7,9 +7,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 4 --warmup 4 --reps 1"
+CMD="python $R/bench.py --skip-cpu --detail-json= --steps 4 --warmup 4 --reps 1"
 rm -rf /tmp/prof_$TAG*
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_stats -- python $R/bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 20 --reps 3 > $O/${TAG}_stats_bench.json 2> /tmp/prof_${TAG}_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_stats -- python $R/bench.py --skip-cpu --steps 20 --warmup 20 --reps 3 --detail-json $O/${TAG}_stats_bench.json > $O/${TAG}_stats_line.json 2> /tmp/prof_${TAG}_stats.err
 cp "$(find /tmp/prof_${TAG}_stats -name '*kernel_stats.csv' | head -1)" $O/${TAG}_kernel_stats_bench_steps20.csv
 python $R/tools/family_times.py $TAG $O/${TAG}_kernel_stats_bench_steps20.csv $O/${TAG}_stats_bench.json $O
 for C in FETCH_SIZE WRITE_SIZE; do

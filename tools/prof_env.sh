@@ -6,7 +6,7 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/prof_$TAG
-env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --skip-cpu --skip-fp32 --skip-others --skip-strong --steps 20 --warmup 20 --reps 3 > /tmp/prof_$TAG.out 2>/tmp/prof_$TAG.err
+env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -- python $R/bench.py --skip-cpu --detail-json= --steps 20 --warmup 20 --reps 3 > /tmp/prof_$TAG.out 2>/tmp/prof_$TAG.err
 f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/${TAG}_kernel_stats.csv
 tail -1 /tmp/prof_$TAG.out > $R/gpurun_out/${TAG}_bench.json
