@@ -302,6 +302,15 @@ typedef struct ns2vc_ffn_args {
   const void* pre_a; int32_t pre_lda;       /* attention output rows, operand-typed [M][pre_lda] */
   const float* pre_bias;                    /* [dim] */
   const float* pre_res; int32_t pre_ldres;  /* fp32 residual stream before the attention [M][pre_ldres] */
+  /* ABI v7, optional, with the pre-stage only: the prompt cross-attention itself (F.scaled_dot_product_attention of attn2,
+   * attention_processor.py:1032 with the mask bias of unet_1d_condition.py:816-818) computed INSIDE the kernel for the workgroup's 64 tokens -- the
+   * k | v of the prompt are hoisted per utterance, so attn2's SDPA is token-local work: one wave per head (8 heads), two passes over the Lk keys (row
+   * maximum, then exp2 / P V with the probabilities rounded to the operand type), the result written straight into the token panel; pre_a is ignored
+   * and no attention-output tensor exists.  att_q = attn2.to_q rows [M][att_ldq]; att_kv = ns2vc_k_xattn_pack's image of this layer's k | v rows (MFMA
+   * fragments in consumption order: every load of the kernel is 1 KB of consecutive bytes per wave); att_bias = additive mask bias [B][att_Lk] or NULL;
+   * att_scale = 1/sqrt(dim/8).  Token blocks are then cut per batch item (ceil(T / 64) workgroups per item). */
+  const void* att_q; int32_t att_ldq;
+  const void* att_kv; const float* att_bias; float att_scale; int32_t att_Lk;
 } ns2vc_ffn_args;
 /* w1_packed [8*dim][dim]: LayerNorm-folded ff.net.0 rows in the packed (32 value | 32 gate) order; w2f [dim][5*dim] =
  * [Wpo W2 | Wpo]; both fp32 host, row-major.  Returns the device tile stream the kernel consumes. */
@@ -309,6 +318,13 @@ int ns2vc_pack_ffn(const float* w1_packed_host, const float* w2f_host, int dim, 
 /* the same with the pre-stage matrix w0 [dim][dim] (attn2.to_out) in front */
 int ns2vc_pack_ffn_pre(const float* w1_packed_host, const float* w2f_host, const float* w0_host, int dim, int precision, void** out_stream_dev);
 int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream);
+/* ABI v7: the k | v image ns2vc_ffn_args.att_kv reads.  k, v = operand-typed rows [B*Lk][ldk / ldv] (head h at columns h*hd ..), 8 heads, hd = 16 | 32.
+ * out, per (batch item, head, tile of 32 keys): hd/16 K fragments and 2 V^T fragments of 1 KB each (lane l of a wave reads bytes 16 l ..): K fragment s, lane
+ * (key = l % 32, half = l / 32) = k[key][16 s + 8 half .. + 7]; V^T fragment j, lane (d = l % 32, half) = the values v[key(slot)][d] of slots 16 j + 8 half .. + 7,
+ * where inside every group of 16 slots key bits 2 and 3 are swapped (the order in which the score MFMA leaves a lane's probabilities); hd 16: row d = 16 is
+ * all ones (the softmax denominator rides the P V product), rows above zero; keys beyond Lk zero.  ns2vc_xattn_pack_bytes = size of `out`. */
+size_t ns2vc_xattn_pack_bytes(int B, int Lk, int hd);
+int ns2vc_k_xattn_pack(const void* k, int ldk, const void* v, int ldv, int B, int Lk, int hd, void* out, int precision, void* stream);
 
 /* r5: token-stationary GEGLU projection (csrc/geglu.hip; 16-bit precisions, dim 384): h = (n W1v^T + b1v) * gelu(n W1g^T + b1g),
  * n = LayerNorm(y) by linearity -- BasicTransformerBlock.ff.net.0 (reference unet1d/attention.py:178-203, GEGLU 206-301) of the blocks

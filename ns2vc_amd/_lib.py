@@ -73,6 +73,8 @@ class FfnArgs(C.Structure):
         ("pre_a", C.c_void_p), ("pre_lda", C.c_int32),
         ("pre_bias", C.c_void_p),
         ("pre_res", C.c_void_p), ("pre_ldres", C.c_int32),
+        ("att_q", C.c_void_p), ("att_ldq", C.c_int32),
+        ("att_kv", C.c_void_p), ("att_bias", C.c_void_p), ("att_scale", C.c_float), ("att_Lk", C.c_int32),
     ]
 
 
@@ -181,6 +183,8 @@ PROTOTYPES = {
     "ns2vc_k_attention": (_I, [C.POINTER(AttnArgs), _I, _I, _P]),
     "ns2vc_pack_ffn": (_I, [_P, _P, _I, _I, _PP]),
     "ns2vc_pack_ffn_pre": (_I, [_P, _P, _P, _I, _I, _PP]),
+    "ns2vc_xattn_pack_bytes": (C.c_size_t, [_I, _I, _I]),
+    "ns2vc_k_xattn_pack": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P]),
     "ns2vc_k_ffn": (_I, [C.POINTER(FfnArgs), _I, _P]),
     "ns2vc_pack_geglu": (_I, [_P, _P, _I, _I, _PP, _PP]),
     "ns2vc_k_geglu": (_I, [C.POINTER(GegluArgs), _I, _P]),

@@ -240,6 +240,8 @@ constexpr double GN_SQ_SCALE = 65536.0;        // 2^16
 
 // launchers (defined in the .hip files); return hipError_t
 hipError_t launch_gemm(const GemmArgs& g, int prec, hipStream_t s);
+size_t xattn_pack_bytes(int B, int Lk, int hd);                            // ffn.hip: the k | v fragment image of the in-kernel cross-attention
+hipError_t launch_xattn_pack(const void* k, int ldk, const void* v, int ldv, int B, int Lk, int hd, void* out, int prec, hipStream_t s);
 bool gemm_uses_convts(const GemmArgs& g, int prec);                        // would launch_gemm run this launch on the tap-sharing conv kernel (convts.hip)?
 int last_gemm_refusal_line();                                               // gemm.hip line of the argument check that refused the last launch on this thread (0: none), cleared by the call
 hipError_t launch_attention(const AttnArgs& a, int head_dim, int prec, hipStream_t s);

@@ -175,6 +175,9 @@ struct ns2vc_unet {
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
   bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
+  bool fuse_xattn = false;     // the prompt cross-attention of attn2 runs inside the fused feed-forward kernel (ffn.hip ATT, r6): no attn2.sdpa launch at dim 128 / 256.
+                               // Correct (kernel + engine tests), 10 launches fewer, measured SLOWER (3.53 vs 3.39 ms/step; profiles/r06_ab_fuse_xattn.txt): with 8 waves per workgroup
+                               // (2 per SIMD, 212-252 VGPRs) the attention phase runs 2-3x off its VALU bound -- a tested option, off
   bool fuse_solver = false;    // the sampling loop's solver update runs in conv_out's epilogue (GemmArgs.sol_*, r6) instead of as its own launch: bit-identical,
                                // one launch and 88 MB of HBM traffic less per step, but 0.1-0.4 % SLOWER in three same-box A/Bs (profiles/r06_ab_fuse_solver.txt) -- a tested option, off
   GemmArgs conv_out_g;         // ... conv_out's launch arguments and its place in fwd_ops, kept by build_plan for that
@@ -900,6 +903,14 @@ struct Planner {
         (double)opsz * B * a.H * hd * (2.0 * Lq + 2.0 * Lk));
   }
 
+  // r6: does this block run its prompt cross-attention inside the fused feed-forward kernel?  (the plan of the pre-stage form, 8 heads of 16 / 32 channels)
+  std::map<std::string, void*> xattn_vt;      // per transformer block: the k | v fragment image of its hoisted rows (built by the condition plan)
+  bool xattn_fused(const AttnW& a, int Tl) const {
+    const int d = a.dim;
+    const bool lin = h->ln_linear && (d % 128 == 0) && d <= 512;
+    return h->fuse_xattn && lin && h->fold_ff && h->fuse_ffn && a.ffn_stream && ffn_eligible(d, Tl, prec) && h->fuse_ffn_pre && a.ffn_pre_stream &&
+           h->cfg.heads == 8 && (d == 128 || d == 256);
+  }
   // Transformer2DModel + BasicTransformerBlock (transformer_1d.py:256-295, attention.py:130-203)
   void transformer(const AttnW& a, const float* x, int Tl, float* y, void* yn, void* qkv, void* ao, void* qb, void* ffh, float* out,
                    void* out_op) {
@@ -967,8 +978,10 @@ struct Planner {
     }
     // cross attention (k|v hoisted into h->kv by set_condition)
     const int nkv = h->kv_all.N;
-    attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
-              h->has_mask ? h->maskbias : nullptr, hd, ao, d);
+    const bool xatt = xattn_fused(a, Tl) && xattn_vt.count(a.prefix);
+    if (!xatt)
+      attention(t + ".attn2.sdpa", qb, d, op_off(h->kv, a.kv_off), nkv, op_off(h->kv, a.kv_off + d), nkv, Tl, Lp,
+                h->has_mask ? h->maskbias : nullptr, hd, ao, d);
     float* r3 = lin ? rs3 : nullptr;
     // With the feed-forward output folded into proj_out, proj_out reads the RAW operand copy of y next to the GEGLU
     // output.  LayerNorm by linearity writes that copy anyway (yn); the explicit-LayerNorm plan overwrites yn with the
@@ -995,14 +1008,20 @@ struct Planner {
         f.yn = nullptr; f.ln_stats = nullptr; f.wstream = a.ffn_pre_stream;
         f.pre_a = ao; f.pre_lda = d; f.pre_bias = a.o2.bias; f.pre_res = y; f.pre_ldres = d;
       }
+      if (xatt) {         // (implies ffn_pre) the cross-attention's output never exists: the kernel builds its token panel from q, the hoisted k rows and V^T
+        f.pre_a = nullptr;
+        f.att_q = qb; f.att_ldq = d; f.att_kv = xattn_vt[a.prefix];
+        f.att_bias = h->has_mask ? h->maskbias : nullptr; f.att_scale = 1.0f / std::sqrt((float)hd); f.att_Lk = Lp;
+      }
       f.res = x; f.ldres = d;
       f.out_f32 = out; f.ldo_f32 = d; f.out_op = out_op; f.ldo_op = d;
       f.stats = new_stats(out, Tl, d);
       f.B = B; f.T = Tl; f.M = M; f.dim = d; f.ln_health = h->ln_health;
-      const double fl = 2.0 * M * (double)d * ((ffn_pre ? 14.0 : 13.0) * d);
-      add(a.prefix + (ffn_pre ? ".ffn[attn2.to_out+geglu+ff.out+proj_out]" : ".ffn[geglu+ff.out+proj_out]"),
+      const double fl = 2.0 * M * (double)d * ((ffn_pre ? 14.0 : 13.0) * d) + (xatt ? 4.0 * B * h->cfg.heads * (double)Tl * Lp * hd : 0.0);
+      add(a.prefix + (xatt ? ".ffn[attn2.sdpa+to_out+geglu+ff.out+proj_out]" : ffn_pre ? ".ffn[attn2.to_out+geglu+ff.out+proj_out]" : ".ffn[geglu+ff.out+proj_out]"),
           [=](hipStream_t s) { return launch_ffn(f, pr, s); }, 1, fl,
-          (double)M * d * (opsz + 8.0 + (ffn_pre ? 4.0 : 0.0) + (out_op ? opsz : 0.0)) + (ffn_pre ? 14.0 : 13.0) * d * d * opsz);
+          (double)M * d * (opsz + 8.0 + (ffn_pre ? 4.0 : 0.0) + (out_op ? opsz : 0.0)) + (ffn_pre ? 14.0 : 13.0) * d * d * opsz +
+              (xatt ? (double)opsz * B * d * 2.0 * Lp : 0.0));
       return;
     }
     if (!r3) layernorm(t + ".norm3");
@@ -1123,6 +1142,17 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     P.add("cond.prompt.cast", [=](hipStream_t s) { return launch_cast_op(prompt, np, prompt_op, prec, s); });
     g = P.base(prompt_op, cross, cross, Lp, Lp, h->kv_all, nullptr, h->kv, h->kv_all.N);
     P.gemm("cond.cross_kv", g);
+    // r6: the V^T images of the blocks whose cross-attention runs inside the fused feed-forward kernel (ffn.hip ATT): one small launch each, once per utterance
+    for (const auto& b : h->blocks)
+      for (const auto& at : b.attn)
+        if (P.xattn_fused(at, Ts[b.level])) {
+          const int ldv = h->kv_all.N, hdv = at.dim / 8, Bq = B, Lq = Lp;
+          void* vt = P.alloc_op(xattn_pack_bytes(B, Lp, hdv) / 2);
+          P.xattn_vt[at.prefix] = vt;
+          const void* ksrc = P.op_off(h->kv, (size_t)at.kv_off);
+          const void* vsrc = P.op_off(h->kv, (size_t)(at.kv_off + at.dim));
+          P.add("cond.cross_kv_image." + at.prefix, [=](hipStream_t s) { return launch_xattn_pack(ksrc, ldv, vsrc, ldv, Bq, Lq, hdv, vt, prec, s); }, 4);
+        }
     // add_embedding = TextTimeEmbedding(prompt)
     const float *n1g = h->p_n1g, *n1b = h->p_n1b, *pos = h->p_pos, *projT = h->p_projT, *projb = h->p_projb, *n2g = h->p_n2g, *n2b = h->p_n2b;
     const int ph_ = c.pool_heads;
@@ -1332,6 +1362,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "conv_wtiled")) return &h->conv_wtiled;
   if (!strcmp(name, "gn_inloop")) return &h->gn_inloop;
   if (!strcmp(name, "fuse_solver")) return &h->fuse_solver;
+  if (!strcmp(name, "fuse_xattn")) return &h->fuse_xattn;
   return nullptr;
 }
 
@@ -1420,7 +1451,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1505,7 +1536,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -2080,6 +2111,12 @@ int ns2vc_k_rowchain(const ns2vc_rowchain_args* a, int precision, void* stream) 
   if (!a) return fail("null args");
   hipError_t e = launch_rowchain(*a, precision, (hipStream_t)stream);
   if (e != hipSuccess) return fail("launch_rowchain: %s", hipGetErrorString(e));
+  return 0;
+}
+size_t ns2vc_xattn_pack_bytes(int B, int Lk, int hd) { return xattn_pack_bytes(B, Lk, hd); }
+int ns2vc_k_xattn_pack(const void* k, int ldk, const void* v, int ldv, int B, int Lk, int hd, void* out, int precision, void* stream) {
+  hipError_t e = launch_xattn_pack(k, ldk, v, ldv, B, Lk, hd, out, precision, (hipStream_t)stream);
+  if (e != hipSuccess) return fail("xattn_pack: %s (16-bit precisions, head dim 16 | 32, 8 heads, 16-byte aligned k rows)", hipGetErrorString(e));
   return 0;
 }
 int ns2vc_k_ffn(const ns2vc_ffn_args* a, int precision, void* stream) {

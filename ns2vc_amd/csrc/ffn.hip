@@ -24,6 +24,7 @@
 // hidden-unit groups: every wave accumulates O^T[all dim channels][its 32 tokens] over ITS hidden units; the four
 // partials meet in the LDS-staged epilogue (bias, fp32 residual, fp32 + operand stores, GroupNorm statistics).
 #include "common.h"
+#include <type_traits>
 #include "mma.h"
 #include <vector>
 
@@ -62,6 +63,16 @@ __device__ unsigned long long* g_ffn_trace = nullptr;
 #endif
 void set_ffn_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ffn_trace), &p, sizeof(p)); }
 
+#ifndef NS2VC_XATT_ABLATE
+#define NS2VC_XATT_ABLATE 0      // diagnostic builds of the in-kernel cross-attention (wrong results): 1 = no pass 1, 2 = no exponentials, 4 = no P V products, 8 = fragments loaded once
+#endif
+// helpers of the in-kernel cross-attention: combine a value with lane ^ 32; 2^x on v_exp_f32
+__device__ __forceinline__ float half_max_f(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float exp2f_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // tile stream geometry (host packer below and kernel must agree)
 constexpr int FFN_TILE = 128 * 128;        // bytes: [128 rows][128 B of K]
 constexpr int FFN_PAIR = 2 * FFN_TILE;     // the kernel consumes tiles two at a time
@@ -87,9 +98,12 @@ template <int D, bool PRE = false> struct FfnGeom {
   static_assert(NB * 512 * 8 <= PANEL, "per-lane statistics partials fit in the panel");
 };
 
-template <typename TM, int D, bool PRE>
+// ATT (with PRE): the prompt cross-attention of attn2 computed here too (r6, FfnArgs.att_*): the panel the pre-stage multiplies is PRODUCED by the eight
+// waves -- one per head -- instead of being fetched from an attention launch's output.
+template <typename TM, int D, bool PRE, bool ATT = false>
 __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   op_mode_init<TM>();
+  static_assert(!ATT || PRE, "the in-kernel cross-attention feeds the pre-stage");
   using G = FfnGeom<D, PRE>;
   constexpr int KT = G::KT, NB = G::NB, NSS = G::NSS, NB128 = G::NB128, NP = G::PAIRS, EP = G::EP, RING = G::RING;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,7 +117,12 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int sw = (l31 >> 1) & 7;                    // read-side XOR swizzle of every fragment row this lane touches
   const unsigned lds0 = (unsigned)(size_t)smem;
-  const int m0 = blockIdx.x * 64;
+  // token block: 64 consecutive rows of the B*T tokens; with the in-kernel cross-attention the blocks are cut per batch item (a block's queries share
+  // one item's keys): ceil(T / 64) workgroups per item, rows past the item's end are masked like rows past M
+  const int nbi = ATT ? (a.T + 63) >> 6 : 1;
+  const int ab = ATT ? (int)blockIdx.x / nbi : 0;
+  const int m0 = ATT ? ab * a.T + ((int)blockIdx.x - ab * nbi) * 64 : (int)blockIdx.x * 64;
+  const int mlim = ATT ? (ab + 1) * a.T : a.M;      // first row that is not this block's any more
   const int mtok = m0 + 32 * tw + l31;              // this lane's token (both lane halves)
   unsigned long long* const tr = (NS2VC_GEMM_TRACE && g_ffn_trace) ? g_ffn_trace + (size_t)blockIdx.x * 8 : nullptr;
   unsigned long long t_ff1 = 0, t_gg = 0, t_ff2 = 0, t_mark = 0;
@@ -112,6 +131,142 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
 
   const i32x4_t rW = make_rsrc(a.wstream, (unsigned long long)NP * FFN_PAIR);
   const unsigned lane16 = (unsigned)(lane * 16);
+  if constexpr (ATT) {
+    // ---- prompt cross-attention of this block's 64 tokens, one wave per head (r6).  The k | v of the prompt are hoisted per utterance, so the SDPA of
+    // attn2 is token-local: S^T = K Q^T per 32 keys x 32 queries (a lane then holds 16 keys of ONE query: the row maximum is lane-local plus one exchange
+    // with lane ^ 32), two passes over the keys -- maximum first, then p = exp2(s - max) rounded to the operand type and O^T += V^T P^T -- no running
+    // rescale, no LDS, no barrier: K and V^T fragments come from the per-utterance fragment image (ns2vc_k_xattn_pack), 1 KB of consecutive bytes per wave
+    // and load (a first build read the k rows in place: 32 cache lines of 17 KB stride per load for 1 KB of data -- the phase ran at the L2 request rate).  The mask bias (and -inf for the keys past Lk) enters through one more MFMA k-slab: K_aux = {bias / scale},
+    // Q_aux = {1}.  The softmax scale is applied in fp32 (fma(s, scale*log2e, -max)), the denominator is the sum of the ROUNDED probabilities (hd 16: the
+    // ones row of V^T inside the P V product; hd 32: a product with a constant ones fragment).
+    constexpr int HD = D / 8, NSL = HD / 16;
+    const int Lk = a.att_Lk, Lpad = (Lk + 31) & ~31, ntile = Lpad >> 5;
+    const int hd0 = wave * HD;                                   // this wave's head = its first channel
+    // this (item, head)'s fragment image: per tile NSL K fragments + 2 V^T fragments of 1 KB, lane-linear (ns2vc_k_xattn_pack)
+    const char* const KV = reinterpret_cast<const char*>(a.att_kv) + ((size_t)(ab * 8 + wave) * ntile) * ((NSL + 2) * 1024) + lane * 16;
+    const float* const bias = a.att_bias ? a.att_bias + (size_t)ab * Lk : nullptr;
+    const float sc2 = a.att_scale * 1.4426950408889634f, rsc = 1.0f / a.att_scale;
+    const u32x4_t qaux = hi == 0 ? u32x4_t{Op16<TM>::pack(1.0f, 0.f), 0u, 0u, 0u} : u32x4_t{0u, 0u, 0u, 0u};
+    const u32x4_t ones = l31 == 0 ? u32x4_t{Op16<TM>::pack(1.0f, 1.0f), Op16<TM>::pack(1.0f, 1.0f), Op16<TM>::pack(1.0f, 1.0f), Op16<TM>::pack(1.0f, 1.0f)}
+                                  : u32x4_t{0u, 0u, 0u, 0u};
+    (void)ones;
+    // One pass over the key tiles serves BOTH 32-query halves of the block (the K / V^T fragments are loaded once), and the fragments are requested PD tiles
+    // ahead: a tile's arithmetic is ~500 cycles, a fragment load from L2 with every CU streaming 1-2 k (first build: one tile ahead, one half at a time --
+    // 70 us per launch, the loop ran at load latency).
+    constexpr int PD = 3;
+    auto load_k = [&](int t, u32x4_t (&kf)[NSL], float& kb) __attribute__((always_inline)) {
+      // (branch-free: tiles past the end re-read the last one and get -inf for every key, so the loop body below has no predicates around its loads and the
+      //  compiler can count them -- with `if (t < ntile)` around the loads it fell back to vmcnt(0) before every tile: no prefetch at all)
+      const int key = 32 * t + l31;
+      const char* kp = KV + (size_t)min(t, ntile - 1) * ((NSL + 2) * 1024);
+#pragma unroll
+      for (int s2 = 0; s2 < NSL; ++s2) kf[s2] = *reinterpret_cast<const u32x4_t*>(kp + s2 * 1024);
+      const float bvv = bias ? bias[min(key, Lk - 1)] * rsc : 0.f;
+      kb = key < Lk ? bvv : -__builtin_inff();
+    };
+    auto scores = [&](const u32x4_t (&kf)[NSL], float kb, const u32x4_t (&qf)[NSL]) __attribute__((always_inline)) {
+      const u32x4_t kaux = hi == 0 ? u32x4_t{Op16<TM>::pack(kb, 0.f), 0u, 0u, 0u} : u32x4_t{0u, 0u, 0u, 0u};
+      f32x16_t sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      MmaT<TM>::mma(sacc, kaux, qaux);
+#pragma unroll
+      for (int s2 = 0; s2 < NSL; ++s2) MmaT<TM>::mma(sacc, kf[s2], qf[s2]);
+      return sacc;
+    };
+    u32x4_t qf[2][NSL];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const TM* qp = reinterpret_cast<const TM*>(a.att_q) + (size_t)min(m0 + 32 * qs + l31, mlim - 1) * a.att_ldq + hd0 + 8 * hi;
+#pragma unroll
+      for (int s2 = 0; s2 < NSL; ++s2) qf[qs][s2] = *reinterpret_cast<const u32x4_t*>(qp + 16 * s2);
+    }
+    // pass 1: the row maxima (raw scores; the scale is positive)
+    float mx[2] = {-__builtin_inff(), -__builtin_inff()};
+    {
+      u32x4_t kf[PD][NSL];
+      float kb[PD];
+#pragma unroll
+      for (int j = 0; j < PD; ++j) load_k(j, kf[j], kb[j]);
+#pragma unroll 1
+      for (int t0 = 0; t0 < ((NS2VC_XATT_ABLATE & 1) ? 0 : ntile); t0 += PD) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+#pragma unroll
+          for (int qs = 0; qs < 2; ++qs) {
+            const f32x16_t sa = scores(kf[j], kb[j], qf[qs]);
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx[qs] = fmaxf(mx[qs], fmaxf(sa[r], sa[r + 1]));
+          }
+          if (!(NS2VC_XATT_ABLATE & 8)) load_k(t0 + j + PD, kf[j], kb[j]);
+        }
+      }
+    }
+    float m2[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) m2[qs] = half_max_f(mx[qs]) * sc2;
+    // pass 2: probabilities and P V
+    constexpr int NO = HD == 16 ? 1 : 2;
+    f32x16_t oacc[2][NO];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+      for (int i = 0; i < NO; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[qs][i][r] = 0.f;
+    {
+      u32x4_t kf[PD][NSL], vf[PD][2];
+      float kb[PD];
+      auto load_v = [&](int t, u32x4_t (&v)[2]) __attribute__((always_inline)) {
+        const char* vp = KV + (size_t)min(t, ntile - 1) * ((NSL + 2) * 1024) + NSL * 1024;
+        v[0] = *reinterpret_cast<const u32x4_t*>(vp); v[1] = *reinterpret_cast<const u32x4_t*>(vp + 1024);
+      };
+#pragma unroll
+      for (int j = 0; j < PD; ++j) { load_k(j, kf[j], kb[j]); load_v(j, vf[j]); }
+#pragma unroll 1
+      for (int t0 = 0; t0 < ntile; t0 += PD) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+          {
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+              const f32x16_t sa = scores(kf[j], kb[j], qf[qs]);
+              float pr[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) pr[r] = (NS2VC_XATT_ABLATE & 2) ? sa[r] : exp2f_fast(fmaf(sa[r], sc2, -m2[qs]));
+              const u32x4_t p0 = u32x4_t{Op16<TM>::pack(pr[0], pr[1]), Op16<TM>::pack(pr[2], pr[3]), Op16<TM>::pack(pr[4], pr[5]), Op16<TM>::pack(pr[6], pr[7])};
+              const u32x4_t p1 = u32x4_t{Op16<TM>::pack(pr[8], pr[9]), Op16<TM>::pack(pr[10], pr[11]), Op16<TM>::pack(pr[12], pr[13]), Op16<TM>::pack(pr[14], pr[15])};
+              if (NS2VC_XATT_ABLATE & 4) { oacc[qs][0][0] += __uint_as_float(p0.x ^ p1.y ^ vf[j][0].x ^ vf[j][1].w); }
+              else {
+              MmaT<TM>::mma(oacc[qs][0], vf[j][0], p0);
+              MmaT<TM>::mma(oacc[qs][0], vf[j][1], p1);
+              if constexpr (HD == 32) { MmaT<TM>::mma(oacc[qs][1], ones, p0); MmaT<TM>::mma(oacc[qs][1], ones, p1); }
+              }
+            }
+            if (!(NS2VC_XATT_ABLATE & 8)) { load_k(t0 + j + PD, kf[j], kb[j]); load_v(t0 + j + PD, vf[j]); }
+          }
+        }
+      }
+    }
+    // normalise and write this head's columns of the panel: lane (q, hi) holds d = 8 (r >> 2) + 4 hi + (r & 3)
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const int tokq = 32 * qs + l31;
+      float den = HD == 16 ? oacc[qs][0][8] : oacc[qs][NO - 1][0];     // (row 16 = the ones row / row 0 of the ones product: in the hi = 0 lanes)
+      den = __shfl(den, l31);
+      const float inv = m0 + tokq < mlim ? 1.0f / den : 0.f;
+      const int swt = (tokq >> 1) & 7;
+#pragma unroll
+      for (int g = 0; g < HD / 8; ++g) {
+        const int n = hd0 + 8 * g + 4 * hi;
+        char* dst = panel + (n >> 6) * 8192 + tokq * 128 + ((((n & 63) >> 3) ^ swt) * 16) + 8 * hi;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(Op16<TM>::pack(oacc[qs][0][4 * g] * inv, oacc[qs][0][4 * g + 1] * inv),
+                                                    Op16<TM>::pack(oacc[qs][0][4 * g + 2] * inv, oacc[qs][0][4 * g + 3] * inv));
+      }
+    }
+    // (the panel is complete for everybody at the first step's barrier: step_begin waits for this wave's LDS writes and meets the others.  The phase runs
+    //  BEFORE any LDS-DMA is issued: its loads are ordinary ones, whose compiler-placed waits would otherwise also cover every DMA issued before them)
+  }
 #if NS2VC_FFN_WARM
   // ---- L2 warm-up.  In the captured step this layer's weights are cold (every layer's weights are read once per step and
   // 132 MB of them pass through the 4 MB L2s in between), every workgroup consumes the SAME tiles at the same pace, and a
@@ -132,10 +287,12 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     const int prow = 8 * wave + (lane >> 3), pchunk = lane & 7;           // one 1-KB piece per wave = 8 rows x 128 B
     const int m = m0 + prow;
     const int ldp = PRE ? a.pre_lda : a.ldy;          // PRE: the panel starts as the attention output rows (pre-stage A operand)
-    const unsigned voff = m < a.M ? (unsigned)m * (unsigned)ldp * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
+    const unsigned voff = m < mlim ? (unsigned)m * (unsigned)ldp * 2u + (unsigned)((pchunk ^ ((prow >> 1) & 7)) * 16) : DMA_OOB;
     const i32x4_t rY = make_rsrc(PRE ? a.pre_a : a.yn, (unsigned long long)a.M * ldp * 2ull);
+    if constexpr (!ATT) {
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) blds16(rY, voff, (unsigned)(kt * 128), lds0 + RING * FFN_PAIR + kt * 8192 + wave * 1024);
+      for (int kt = 0; kt < KT; ++kt) blds16(rY, voff, (unsigned)(kt * 128), lds0 + RING * FFN_PAIR + kt * 8192 + wave * 1024);
+    }
     const i32x4_t rC = make_rsrc(a.consts, (unsigned long long)G::CONSTS);
 #pragma unroll
     for (int j = 0; j < G::CONSTS / 8192; ++j)
@@ -151,7 +308,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int n = 128 * rb + 32 * hw + 8 * g + 4 * hi;
         b0[rb][g] = *reinterpret_cast<const float4*>(a.pre_bias + n);
-        rr0[rb][g] = mtok < a.M ? *reinterpret_cast<const float4*>(a.pre_res + (size_t)mtok * a.pre_ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rr0[rb][g] = mtok < mlim ? *reinterpret_cast<const float4*>(a.pre_res + (size_t)mtok * a.pre_ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
   }
   // a pair = 32 pieces of 1 KB: four per wave, all addresses scalar
@@ -178,7 +335,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
     if (var < 0.0) var = 0.0;
     rstd = 1.0f / sqrtf((float)var + a.ln_eps);
     if (a.ln_health && hw == 0) {          // same health report as the LayerNorm-consumer GEMMs (gemm.hip ln_row_finish)
-      float ratio = mtok < a.M ? fabsf(mean) * rstd : 0.f;
+      float ratio = mtok < mlim ? fabsf(mean) * rstd : 0.f;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) ratio = fmaxf(ratio, __shfl_xor(ratio, o));
       if (lane == 0 && ratio > __uint_as_float(__hip_atomic_load(a.ln_health, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
@@ -270,7 +427,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
         v.y = acc0[rb][4 * g + 1] + b0[rb][g].y + rr0[rb][g].y;
         v.z = acc0[rb][4 * g + 2] + b0[rb][g].z + rr0[rb][g].z;
         v.w = acc0[rb][4 * g + 3] + b0[rb][g].w + rr0[rb][g].w;
-        if (mtok >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mtok >= mlim) v = make_float4(0.f, 0.f, 0.f, 0.f);
         ps += (v.x + v.y) + (v.z + v.w);
         pq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         const int n = 128 * rb + 32 * hw + 8 * g + 4 * hi;
@@ -396,7 +553,7 @@ __global__ __launch_bounds__(512) void ffn_kernel(const FfnArgs a) {
   constexpr int EBLK = 2 * 4 * 32 * EP;                   // floats per staged 32-channel block
   const int L = tid, eth = L >> 8, etok = (L >> 3) & 31, equad = L & 7;
   const int em = m0 + 32 * eth + etok;
-  const bool eok = em < a.M;
+  const bool eok = em < mlim;
   float4 rr[NB];                                          // residual rows + bias: every load in flight before the first store
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
@@ -514,7 +671,10 @@ hipError_t pack_ffn_stream(const float* w1p, const float* w2f, const float* w0, 
 bool ffn_eligible(int dim, int T, int prec) { return (dim == 128 || dim == 256) && T >= 64 && (prec == PREC_BF16 || prec == PREC_F16); }
 
 template <typename TM, int D> static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t s) {
-  if (a.pre_a) {
+  if (a.att_q) {
+    const size_t lds = FfnGeom<D, true>::LDS;
+    hipLaunchKernelGGL((ffn_kernel<TM, D, true, true>), dim3(a.B * ((a.T + 63) / 64)), dim3(512), lds, s, a);
+  } else if (a.pre_a) {
     const size_t lds = FfnGeom<D, true>::LDS;
     hipLaunchKernelGGL((ffn_kernel<TM, D, true>), dim3((a.M + 63) / 64), dim3(512), lds, s, a);
   } else {
@@ -527,13 +687,61 @@ template <typename TM, int D> static hipError_t launch_ffn_t(const FfnArgs& a, h
 hipError_t launch_ffn(const FfnArgs& a, int prec, hipStream_t s) {
   if (!ffn_eligible(a.dim, a.T, prec) || a.M <= 0 || a.M != a.B * a.T) return hipErrorInvalidValue;
   if (!a.wstream || !a.consts || !a.bias2 || !a.res || (!a.out_f32 && !a.out_op)) return hipErrorInvalidValue;
-  if (a.pre_a ? (!a.pre_bias || !a.pre_res || (a.pre_lda & 7) || (a.pre_ldres & 3) || (unsigned long long)a.M * a.pre_lda * 2ull > 0xFFF00000ull)
+  if (a.att_q) {      // in-kernel cross-attention: with the pre-stage's weights, bias and residual; 8 heads of dim / 8 channels, 16-byte aligned fragments
+    if (!a.pre_bias || !a.pre_res || (a.pre_ldres & 3) || !a.att_kv || a.att_Lk < 1 || (a.att_ldq & 7) ||
+        ((reinterpret_cast<uintptr_t>(a.att_q) | reinterpret_cast<uintptr_t>(a.att_kv)) & 15) || !(a.att_scale > 0.f))
+      return hipErrorInvalidValue;
+  } else if (a.pre_a ? (!a.pre_bias || !a.pre_res || (a.pre_lda & 7) || (a.pre_ldres & 3) || (unsigned long long)a.M * a.pre_lda * 2ull > 0xFFF00000ull)
               : (!a.yn || !a.ln_stats))
     return hipErrorInvalidValue;
-  if ((!a.pre_a && (a.ldy & 7)) || (a.ldres & 3) || (a.out_f32 && (a.ldo_f32 & 3)) || (a.out_op && (a.ldo_op & 3))) return hipErrorInvalidValue;
-  if (!a.pre_a && (unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
+  if ((!a.pre_a && !a.att_q && (a.ldy & 7)) || (a.ldres & 3) || (a.out_f32 && (a.ldo_f32 & 3)) || (a.out_op && (a.ldo_op & 3))) return hipErrorInvalidValue;
+  if (!a.pre_a && !a.att_q && (unsigned long long)a.M * a.ldy * 2ull > 0xFFF00000ull) return hipErrorInvalidValue;
   if (prec == PREC_BF16) return a.dim == 128 ? launch_ffn_t<bf16_t, 128>(a, s) : launch_ffn_t<bf16_t, 256>(a, s);
   return a.dim == 128 ? launch_ffn_t<f16_t, 128>(a, s) : launch_ffn_t<f16_t, 256>(a, s);
+}
+
+// ---------------------------------------------------------------------------
+// k | v fragment image for the in-kernel cross-attention (FfnArgs.att_kv; once per utterance, beside the hoisted k | v projection)
+// ---------------------------------------------------------------------------
+template <typename TM>
+__global__ __launch_bounds__(256) void xattn_pack_kernel(const TM* __restrict__ k, int ldk, const TM* __restrict__ v, int ldv, int Lk, int ntile, int hd, uint4* __restrict__ out) {
+  // one thread per 16-byte piece: piece = ((bh * ntile + t) * (nsl + 2) + frag) * 64 + lane
+  const int nsl = hd >> 4, nfr = nsl + 2;
+  const size_t piece = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)gridDim.y * ntile * nfr * 64;         // gridDim.y = B * 8 heads (pieces of one (b, h) never straddle: see the launcher)
+  (void)total;
+  const int bh = blockIdx.y;
+  if (piece >= (size_t)ntile * nfr * 64) return;
+  const int lane = (int)(piece & 63), frag = (int)((piece >> 6) % nfr), t = (int)((piece >> 6) / nfr);
+  const int b = bh >> 3, hh = bh & 7, l31 = lane & 31, hi = lane >> 5;
+  union { uint4 u; uint16_t e[8]; } r;
+  r.u = make_uint4(0u, 0u, 0u, 0u);
+  const uint16_t one = std::is_same<TM, f16_t>::value ? (uint16_t)0x3C00 : (uint16_t)0x3F80;
+  if (frag < nsl) {                      // K fragment: key = 32 t + l31, channels 16 frag + 8 hi ..
+    const int key = 32 * t + l31;
+    if (key < Lk) r.u = *reinterpret_cast<const uint4*>(k + (size_t)(b * Lk + key) * ldk + hh * hd + 16 * frag + 8 * hi);
+  } else {                               // V^T fragment j: row d = l31, slots 16 j + 8 hi + e of the tile; key bits 2 and 3 swapped inside a group of 16
+    const int j = frag - nsl, d = l31;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int slot = 16 * j + 8 * hi + e;
+      const int key = 32 * t + ((slot & ~12) | ((slot & 4) << 1) | ((slot & 8) >> 1));
+      if (d < hd) { if (key < Lk) r.e[e] = v[(size_t)(b * Lk + key) * ldv + hh * hd + d].v; }
+      else if (d == hd && hd == 16) r.e[e] = one;
+    }
+  }
+  out[((size_t)bh * ntile * nfr) * 64 + piece] = r.u;
+}
+size_t xattn_pack_bytes(int B, int Lk, int hd) { return (size_t)B * 8 * (size_t)((Lk + 31) >> 5) * (size_t)((hd >> 4) + 2) * 1024; }
+hipError_t launch_xattn_pack(const void* k, int ldk, const void* v, int ldv, int B, int Lk, int hd, void* out, int prec, hipStream_t s) {
+  if (!k || !v || !out || B < 1 || Lk < 1 || (hd != 16 && hd != 32) || (prec != PREC_BF16 && prec != PREC_F16) || (ldk & 7) ||
+      (reinterpret_cast<uintptr_t>(k) & 15))
+    return hipErrorInvalidValue;
+  const int ntile = (Lk + 31) >> 5, nfr = (hd >> 4) + 2;
+  dim3 grid((ntile * nfr * 64 + 255) / 256, B * 8);
+  if (prec == PREC_BF16) hipLaunchKernelGGL(xattn_pack_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, Lk, ntile, hd, (uint4*)out);
+  else hipLaunchKernelGGL(xattn_pack_kernel<f16_t>, grid, dim3(256), 0, s, (const f16_t*)k, ldk, (const f16_t*)v, ldv, Lk, ntile, hd, (uint4*)out);
+  return hipGetLastError();
 }
 
 hipError_t init_ffn_attributes() {
@@ -544,6 +752,11 @@ hipError_t init_ffn_attributes() {
   NS2VC_FFN_ATTR(bf16_t, 128, false); NS2VC_FFN_ATTR(bf16_t, 256, false); NS2VC_FFN_ATTR(f16_t, 128, false); NS2VC_FFN_ATTR(f16_t, 256, false);
   NS2VC_FFN_ATTR(bf16_t, 128, true); NS2VC_FFN_ATTR(bf16_t, 256, true); NS2VC_FFN_ATTR(f16_t, 128, true); NS2VC_FFN_ATTR(f16_t, 256, true);
 #undef NS2VC_FFN_ATTR
+#define NS2VC_FFN_ATTR2(TM, D_)                                                                                                      \
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<TM, D_, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               (int)FfnGeom<D_, true>::LDS)) != hipSuccess) return e
+  NS2VC_FFN_ATTR2(bf16_t, 128); NS2VC_FFN_ATTR2(bf16_t, 256); NS2VC_FFN_ATTR2(f16_t, 128); NS2VC_FFN_ATTR2(f16_t, 256);
+#undef NS2VC_FFN_ATTR2
   return hipSuccess;
 }
 

@@ -1112,6 +1112,111 @@ def test_ffn_fused(dim, B, T, prestage, prec, diag):
     lib.ns2vc_dev_free(stream)
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("dim,B,T,Lk,masked", [(128, 3, 150, 69, True), (256, 2, 97, 130, True), (128, 2, 64, 469, False), (256, 3, 200, 33, True), (128, 1, 70, 1, False)], ids=str)
+def test_ffn_fused_with_cross_attention(dim, B, T, Lk, masked, prec, diag):
+    """r6 (ns2vc_ffn_args.att_*): the prompt cross-attention of attn2 (attention_processor.py:1032, mask bias unet_1d_condition.py:816-818) computed INSIDE the
+    fused feed-forward kernel -- one wave per head, two passes over the keys, K and V^T fragments from ns2vc_k_xattn_pack's image of the hoisted k | v rows -- in front of
+    attn2.to_out + residual -> LayerNorm -> GEGLU -> ff.net.2 -> proj_out.  Against (a) numpy fp64 of the whole chain with the kernel's rounding points (q, k, v,
+    the probabilities and the attention output rounded to the operand type) and (b) the two-launch path on the device (ns2vc_k_attention + the pre-stage kernel):
+    token blocks are cut per batch item (T no multiple of 64), keys no multiple of 32, ragged masks, a single key."""
+    from scipy.special import erf
+    from ns2vc_amd._lib import AttnArgs, FfnArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    rng = np.random.default_rng(dim * 1000 + B * 10 + T + Lk)
+    d, M, H = dim, B * T, 8
+    hd = d // H
+    q = rnd(rng.standard_normal((B, T, d)), prec)
+    kv_ld = 2 * d + 64                                             # k | v side by side inside wider rows, as in the engine's hoisted projection
+    kv = np.zeros((B, Lk, kv_ld), np.float32)
+    kv[..., :2 * d] = rnd(rng.standard_normal((B, Lk, 2 * d)), prec)
+    k, v = kv[..., :d], kv[..., d:2 * d]
+    bias = None
+    if masked:
+        lens = np.maximum(1, (Lk * (0.4 + 0.6 * rng.random(B))).astype(int)); lens[0] = Lk
+        bias = ((np.arange(Lk)[None, :] >= lens[:, None]) * -10000.0).astype(np.float32)
+    # attention reference with the kernel's rounding: probabilities relative to the row maximum, rounded; denominator from the rounded ones; output rounded
+    qh = q.reshape(B, T, H, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    kh = k.reshape(B, Lk, H, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    vh = v.reshape(B, Lk, H, hd).transpose(0, 2, 1, 3).astype(np.float64)
+    sc = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(hd)
+    if bias is not None:
+        sc = sc + bias[:, None, None, :]
+    p = np.exp(sc - sc.max(-1, keepdims=True))
+    pr_ = rnd(p.astype(np.float32), prec).astype(np.float64)
+    o = ((pr_ @ vh) / pr_.sum(-1, keepdims=True)).transpose(0, 2, 1, 3).reshape(M, d)
+    o_r = rnd(o.astype(np.float32), prec)
+    y_prev = (rng.standard_normal((M, d)) + 1.5 * rng.standard_normal((M, 1))).astype(np.float32)
+    x = rng.standard_normal((M, d)).astype(np.float32)
+    Wo, bo = (rng.standard_normal((d, d)) / np.sqrt(d)).astype(np.float32), (0.3 * rng.standard_normal(d)).astype(np.float32)
+    y = (o_r.astype(np.float64) @ rnd(Wo, prec).astype(np.float64).T + bo + y_prev).astype(np.float32)
+    gamma, beta = (1.0 + 0.2 * rng.standard_normal(d)), 0.2 * rng.standard_normal(d)
+    W1, b1 = rng.standard_normal((8 * d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(8 * d)
+    W2, b2 = rng.standard_normal((d, 4 * d)) / np.sqrt(4 * d), 0.3 * rng.standard_normal(d)
+    Wpo, bpo = rng.standard_normal((d, d)) / np.sqrt(d), 0.3 * rng.standard_normal(d)
+    W1f, b1f = W1 * gamma[None, :], b1 + W1 @ beta
+    order = np.concatenate([np.concatenate([np.arange(32 * g, 32 * g + 32), 4 * d + np.arange(32 * g, 32 * g + 32)]) for g in range(4 * d // 32)])
+    W1p, b1p = W1f[order].astype(np.float32), b1f[order].astype(np.float32)
+    w2f = np.concatenate([Wpo @ W2, Wpo], axis=1).astype(np.float32)
+    bias2 = (Wpo @ b2 + bpo).astype(np.float32)
+    W1r, w2r, yr = rnd(W1p, prec).astype(np.float64), rnd(w2f, prec).astype(np.float64), rnd(y, prec).astype(np.float64)
+    consts = np.stack([W1r.sum(1), b1p.astype(np.float64)], axis=1).astype(np.float32)
+    y64 = y.astype(np.float64)
+    mean, var = y64.mean(1, keepdims=True), y64.var(1, keepdims=True)
+    pre = (1.0 / np.sqrt(var + 1e-5)) * (yr @ W1r.T - mean * consts[:, 0].astype(np.float64)[None, :]) + b1p.astype(np.float64)[None, :]
+    pg = pre.reshape(M, 4 * d // 32, 2, 32)
+    hcol = (pg[:, :, 0] * 0.5 * pg[:, :, 1] * (1.0 + erf(pg[:, :, 1] / np.sqrt(2.0)))).reshape(M, 4 * d)
+    ref = rnd(hcol.astype(np.float32), prec).astype(np.float64) @ w2r[:, :4 * d].T + yr @ w2r[:, 4 * d:].T + bias2 + x
+    # ---- device
+    stream = C.c_void_p()
+    check(lib.ns2vc_pack_ffn_pre(np.ascontiguousarray(W1p).ctypes.data, np.ascontiguousarray(w2f).ctypes.data, np.ascontiguousarray(Wo).ctypes.data,
+                                 d, prec, C.byref(stream)), "pack_ffn_pre")
+    d_q, d_kv = OpBuf(q.reshape(M, d), prec), OpBuf(kv.reshape(B * Lk, kv_ld), prec)
+    d_bias = _dev(bias) if bias is not None else None
+    d_vt = DevBuf(int(lib.ns2vc_xattn_pack_bytes(B, Lk, hd)))
+    check(lib.ns2vc_k_xattn_pack(d_kv.ptr, kv_ld, d_kv.ptr + 2 * d, kv_ld, B, Lk, hd, d_vt.ptr, prec, None), "xattn_pack")
+    d_c, d_b2, d_x, d_bo, d_yp = _dev(consts), _dev(bias2), _dev(x), _dev(bo), _dev(y_prev)
+    outs = []
+    for fused in (1, 0):
+        d_o = DevBuf(M * d * 4)
+        d_o.upload(np.full((M, d), np.nan, dtype=np.float32))
+        d_gs = DevBuf.from_numpy(np.zeros((B, d // 16, 2), dtype=np.int64))
+        f = FfnArgs()
+        f.wstream = stream.value; f.consts = d_c.ptr; f.bias2 = d_b2.ptr
+        f.res = d_x.ptr; f.ldres = d
+        f.out_f32 = d_o.ptr; f.ldo_f32 = d
+        f.stats = d_gs.ptr
+        f.B, f.T, f.M, f.dim = B, T, M, d
+        f.ln_eps = 1e-5
+        f.pre_bias = d_bo.ptr; f.pre_res = d_yp.ptr; f.pre_ldres = d
+        if fused:
+            f.att_q = d_q.ptr; f.att_ldq = d; f.att_kv = d_vt.ptr
+            f.att_bias = d_bias.ptr if d_bias is not None else None
+            f.att_scale = 1.0 / np.sqrt(hd); f.att_Lk = Lk
+        else:
+            d_ao = OpBuf(np.full((M, d), np.nan, dtype=np.float32), prec)
+            a = AttnArgs()
+            a.q = d_q.ptr; a.k = d_kv.ptr; a.v = d_kv.ptr + 2 * d; a.ldq = d; a.ldk = kv_ld; a.ldv = kv_ld
+            a.B, a.H, a.Lq, a.Lk = B, H, T, Lk
+            a.bias = d_bias.ptr if d_bias is not None else None
+            a.scale = 1.0 / np.sqrt(hd); a.out = d_ao.ptr; a.ldo = d
+            check(lib.ns2vc_k_attention(C.byref(a), hd, prec, None), "k_attention")
+            f.pre_a = d_ao.ptr; f.pre_lda = d
+        check(lib.ns2vc_k_ffn(C.byref(f), prec, None), "k_ffn")
+        sync()
+        outs.append((d_o.to_numpy((M, d)), d_gs.to_numpy((B, d // 16, 2), dtype=np.int64).astype(np.float64)))
+    out, gs = outs[0]
+    e, e2, e12 = rel_l2(out, ref), rel_l2(outs[1][0], ref), rel_l2(out, outs[1][0])
+    blk = out.astype(np.float64).reshape(B, T, d // 16, 16)
+    e_s = np.abs(gs[..., 0] / 2 ** 28 - blk.sum(axis=(1, 3))).max() / np.abs(blk.sum(axis=(1, 3))).max()
+    diag(f"ffn + in-kernel cross-attention dim={d} B={B} T={T} Lk={Lk} mask={masked} prec={prec}: vs fp64 {e:.3e} (two-launch path {e2:.3e}; fused vs two-launch {e12:.3e})  "
+         f"nan={int(np.isnan(out).sum())}  stats sum {e_s:.2e}")
+    assert np.isfinite(out).all() and e < (4e-4 if prec == 2 else 3e-3) and e12 < (6e-4 if prec == 2 else 5e-3)
+    assert e_s < 1e-5
+    lib.ns2vc_dev_free(stream)
+
+
 def ref_attention(q, k, v, bias, H, prec):
     B, Lq, D = q.shape
     Lk = k.shape[1]
