@@ -175,6 +175,12 @@ struct ns2vc_unet {
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
   bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
+  bool fork_temb = false;      // (measured: +3 % -- a graph with a parallel branch replays SLOWER than the linear chain, 3.696 vs 3.587 ms/step, profiles/r06_ab_fork_temb.txt; off)
+                               // r6: inside the captured step graph the timestep-embedding branch (time_embed + time_emb_proj.all: two small launches that depend on the step
+                               // counter only) runs BESIDE conv_in and the first resnet's conv1 on a forked stream and joins in front of the first consumer of the scale / shift rows
+  int temb_begin = -1, temb_end = -1, temb_join = -1;        // ... their places in fwd_ops (build_plan)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool fuse_xattn = false;     // the prompt cross-attention of attn2 runs inside the fused feed-forward kernel (ffn.hip ATT, r6): no attn2.sdpa launch at dim 128 / 256.
                                // Correct (kernel + engine tests), 10 launches fewer, measured SLOWER (3.53 vs 3.39 ms/step; profiles/r06_ab_fuse_xattn.txt): with 8 waves per workgroup
                                // (2 per SIMD, 212-252 VGPRs) the attention phase runs 2-3x off its VALU bound -- a tested option, off
@@ -225,6 +231,9 @@ struct ns2vc_unet {
   ~ns2vc_unet() {
     if (step_graph) (void)hipGraphExecDestroy(step_graph);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     if (ln_event) (void)hipEventDestroy(ln_event);
     if (ln_mail) (void)hipHostFree(ln_mail);
     if (arena) (void)hipFree(arena);
@@ -782,6 +791,7 @@ struct Planner {
     // (a GroupNorm prologue reads the fp32 rows and writes + re-reads the operand rows it builds)
     const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz * (g.gnp_raw ? 2.0 : 1.0)) : 0.0;
     if (g.taps == 3 && g.tmode == TMODE_SAME && !g.conv_bn) g.conv_bn = convts_bn_for(g, h->bn128_min);     // the column tile is a PLAN decision (this engine's device)
+    if (!sizing && g.gnp_temb && ops == &h->fwd_ops && h->temb_join < 0) h->temb_join = (int)ops->size();    // first launch that reads the time scale / shift rows
     add(g.gnp_x ? name + "[+norm]" : name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes + pro);
     if (!sizing && g.gnp_x && g.gnp_sync) {
       unsigned* words = g.gnp_sync;
@@ -1188,6 +1198,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     float *emb = h->emb, *tdev = h->t_dev;
     void* emb_act = h->emb_act_op;
     const int tdim = c0;
+    if (!sizing) { h->temb_begin = (int)h->fwd_ops.size(); h->temb_join = -1; }
     P.add("time_embed", [=](hipStream_t s) {
       // sampling loop: the MLP of every step's timestep was evaluated once for the table (ns2vc_sampler_run), a step adds aug
       if (hh->use_step_table) return launch_emb_from_table(hh->temb_table, hh->step_dev, aug, emb, emb_act, prec, B, E, s);
@@ -1197,6 +1208,7 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     // every resnet's time_emb_proj(SiLU(emb)) in one GEMM (M = B)
     GemmArgs g = P.base(emb_act, E, E, 1, 1, h->temb_all, h->temb, nullptr, h->temb_all.N);
     P.gemm("time_emb_proj.all", g);
+    if (!sizing) h->temb_end = (int)h->fwd_ops.size();
   }
   // skip stack
   struct Skip { float* p; int C; int l; };
@@ -1363,6 +1375,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "gn_inloop")) return &h->gn_inloop;
   if (!strcmp(name, "fuse_solver")) return &h->fuse_solver;
   if (!strcmp(name, "fuse_xattn")) return &h->fuse_xattn;
+  if (!strcmp(name, "fork_temb")) return &h->fork_temb;
   return nullptr;
 }
 
@@ -1451,7 +1464,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}, {"NS2VC_FORK_TEMB", "fork_temb"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1536,7 +1549,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn, fork_temb)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -1689,14 +1702,31 @@ static bool solver_in_conv_out(ns2vc_unet* h, GemmArgs& g) {
   g.sol_xe = h->xe; g.sol_xe_op = h->xe_op; g.sol_xbar = h->xbar; g.sol_d1 = h->d1; g.sol_mprev = h->mprev; g.sol_ld = h->CP;
   return gemm_uses_convts(g, h->prec);
 }
-static int run_step(ns2vc_unet* h, hipStream_t s) {
+static int run_step(ns2vc_unet* h, hipStream_t s, bool capturing = false) {
   GemmArgs g;
-  if (solver_in_conv_out(h, g)) {
-    if (run_ops(h->fwd_ops, s, 0, (size_t)h->conv_out_idx)) return 1;
+  const bool fold = solver_in_conv_out(h, g);
+  const size_t last = fold ? (size_t)h->conv_out_idx : h->fwd_ops.size();
+  size_t first = 0;
+  // r6: under capture the timestep-embedding branch becomes a parallel branch of the graph (fork after the statistics clear, which advances the step counter
+  // the branch reads; join in front of the first launch that reads the scale / shift rows).  Eager loops keep one stream: same launches, same results.
+  if (capturing && h->fork_temb && !h->debug && h->temb_begin > 0 && h->temb_end > h->temb_begin && h->temb_join >= h->temb_end && (size_t)h->temb_join <= last) {
+    if (!h->side_stream) HIPCHK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    if (!h->ev_fork) HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    if (!h->ev_join) HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    if (run_ops(h->fwd_ops, s, 0, (size_t)h->temb_begin)) return 1;
+    HIPCHK(hipEventRecord(h->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    if (run_ops(h->fwd_ops, h->side_stream, (size_t)h->temb_begin, (size_t)h->temb_end)) return 1;
+    HIPCHK(hipEventRecord(h->ev_join, h->side_stream));
+    if (run_ops(h->fwd_ops, s, (size_t)h->temb_end, (size_t)h->temb_join)) return 1;
+    HIPCHK(hipStreamWaitEvent(s, h->ev_join, 0));
+    first = (size_t)h->temb_join;
+  }
+  if (run_ops(h->fwd_ops, s, first, last)) return 1;
+  if (fold) {
     HIPCHK(launch_gemm(g, h->prec, s));
     return 0;
   }
-  if (run_ops(h->fwd_ops, s)) return 1;
   const size_t n = (size_t)h->B * h->T * h->CP;
   HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xe_op, h->prec, h->xbar, h->d1, h->mprev, n, s));
   return 0;
@@ -1739,7 +1769,7 @@ int ns2vc_sampler_steps(ns2vc_unet* h, int n_steps, int use_graph, void* stream)
     if (!h->cap_stream) HIPCHK(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     HIPCHK(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = run_step(h, h->cap_stream);
+    const int rc = run_step(h, h->cap_stream, true);
     hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
     if (e != hipSuccess) return fail("hipStreamEndCapture: %s", hipGetErrorString(e));
