@@ -136,6 +136,7 @@ struct ns2vc_unet {
   // packed weights
   std::vector<BlockW> blocks;
   PackedW conv_in_x, conv_in_c, conv_out, temb_all, kv_all, pool_qkv;
+  PackedW conv_in_x32, conv_in_c32, conv_out32, temb_all32;      // r6, 16-bit engines: the same four in fp32 (option exact_io)
   float *t_w1t = nullptr, *t_b1 = nullptr, *t_w2t = nullptr, *t_b2 = nullptr;
   float *p_n1g = nullptr, *p_n1b = nullptr, *p_pos = nullptr, *p_projT = nullptr, *p_projb = nullptr, *p_n2g = nullptr, *p_n2b = nullptr;
   float *out_ng = nullptr, *out_nb = nullptr;
@@ -175,6 +176,11 @@ struct ns2vc_unet {
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
   bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
+  bool exact_io = false;       // r6 (16-bit engines): conv_in, conv_out and the time_emb_proj GEMM -- three single launches that carry 23 + 6 % of the forward error's energy
+                               // (profiles/r06_error_budget.txt) -- with fp32 operands on the fp32 MFMA: a precision-for-time knob
+  float* content_f32 = nullptr;      // ... their fp32 inputs: the content rows, SiLU(emb)
+  float* emb_act_f32 = nullptr;
+  int conv_out_prec = -1;
   bool fork_temb = false;      // (measured: +3 % -- a graph with a parallel branch replays SLOWER than the linear chain, 3.696 vs 3.587 ms/step, profiles/r06_ab_fork_temb.txt; off)
                                // r6: inside the captured step graph the timestep-embedding branch (time_embed + time_emb_proj.all: two small launches that depend on the step
                                // counter only) runs BESIDE conv_in and the first resnet's conv1 on a forked stream and joins in front of the first consumer of the scale / shift rows
@@ -403,7 +409,9 @@ struct Packer {
   float* vec(const std::string& k) { return upload_f32(T(k).data); }
   // rows: [N][K] fp32, bias: [N] or empty.  Pads N to a multiple of 128 with zero rows.
   // tile3_ctot > 0: a k = 3 conv weight (K = 3 * tile3_ctot + tile3_c2): also packed tile-major for the tap-sharing kernel
+  int prec_override = -1;      // pack the next weights in this precision instead of the engine's (exact_io: fp32 copies of four weights of a 16-bit engine)
   PackedW pack(const std::vector<float>& rows, int N, int K, const std::vector<float>& bias, bool want_wsum = false, int tile3_ctot = 0, int tile3_c2 = 0) {
+    const int wprec = prec_override >= 0 ? prec_override : h->prec;
     PackedW p;
     const int Np = round_up(N, 128);
     p.N = Np; p.K = K;
@@ -411,7 +419,7 @@ struct Packer {
     //  [N][K] rows and the engine says so once)
     if (tile3_ctot > 0 && K == 3 * tile3_ctot + tile3_c2 && h->conv_ts && h->conv_wtiled) {
       std::vector<unsigned char> img;
-      if (pack_conv3_tiled(rows.data(), N, tile3_ctot, tile3_c2, h->prec, img) != hipSuccess) {
+      if (pack_conv3_tiled(rows.data(), N, tile3_ctot, tile3_c2, wprec, img) != hipSuccess) {
         if (!h->warned_wtiled) { fprintf(stderr, "ns2vc: tile-major conv weights unavailable for a %d x %d weight (channels not a multiple of the chunk): row-major fallback\n", N, K); h->warned_wtiled = true; }
       } else {
         void* dt = nullptr;
@@ -421,11 +429,11 @@ struct Packer {
         p.wt = dt;
       }
     }
-    if (want_wsum) p.wsum = upload_f32(rounded_rowsum(rows.data(), N, K, Np, h->prec));
+    if (want_wsum) p.wsum = upload_f32(rounded_rowsum(rows.data(), N, K, Np, wprec));
     void* d = nullptr;
-    if (h->prec != PREC_F32) {
+    if (wprec != PREC_F32) {
       std::vector<uint16_t> q((size_t)Np * K, 0);
-      for (size_t i = 0; i < (size_t)N * K; ++i) q[i] = f32_to_op16_bits(rows[i], h->prec);
+      for (size_t i = 0; i < (size_t)N * K; ++i) q[i] = f32_to_op16_bits(rows[i], wprec);
       if (hipMalloc(&d, q.size() * 2) != hipSuccess) { err = fail("hipMalloc failed (weights)"); return p; }
       h->weight_allocs.push_back(d);
       if (hipMemcpy(d, q.data(), q.size() * 2, hipMemcpyHostToDevice) != hipSuccess) err = fail("hipMemcpy failed");
@@ -521,6 +529,12 @@ int pack_all(ns2vc_unet* h) {
     if (P.err) return 1;
     h->conv_in_x = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {}, false, CP, 0);
     h->conv_in_c = P.pack(P.conv_rows(w, lat, lat + c.content_channels, c.content_channels), c0, 3 * c.content_channels, P.T("conv_in.bias").data);
+    if (h->prec != PREC_F32) {
+      P.prec_override = PREC_F32;
+      h->conv_in_x32 = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {}, false, CP, 0);
+      h->conv_in_c32 = P.pack(P.conv_rows(w, lat, lat + c.content_channels, c.content_channels), c0, 3 * c.content_channels, P.T("conv_in.bias").data);
+      P.prec_override = -1;
+    }
   }
   // time MLP, transposed to [in][out] for coalesced GEMV reads
   auto transpose = [&](const HostTensor& w) {
@@ -700,6 +714,7 @@ int pack_all(ns2vc_unet* h) {
   }
   h->n_temb = temb_off;
   h->temb_all = P.pack(temb_rows, temb_off, temb, temb_bias);
+  if (h->prec != PREC_F32) { P.prec_override = PREC_F32; h->temb_all32 = P.pack(temb_rows, temb_off, temb, temb_bias); P.prec_override = -1; }
   h->n_kv = kv_off;
   h->kv_all = P.pack(kv_rows, kv_off, cross, {});
   h->out_ng = P.vec("conv_norm_out.weight"); h->out_nb = P.vec("conv_norm_out.bias");
@@ -707,6 +722,7 @@ int pack_all(ns2vc_unet* h) {
     const HostTensor& w = P.T("conv_out.weight");
     if (P.err) return 1;
     h->conv_out = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data, false, c0, 0);
+    if (h->prec != PREC_F32) { P.prec_override = PREC_F32; h->conv_out32 = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data, false, c0, 0); P.prec_override = -1; }
   }
   return P.err;
 }
@@ -780,8 +796,8 @@ struct Planner {
     add("tap:" + name, [=](hipStream_t s) { return hipMemcpyAsync(cp, src, bytes, hipMemcpyDeviceToDevice, s); }, 4, 0.0, 2.0 * bytes);
   }
 
-  void gemm(const std::string& name, GemmArgs g) {
-    const int pr = prec;
+  void gemm(const std::string& name, GemmArgs g, int pr_override = -1) {
+    const int pr = pr_override >= 0 ? pr_override : prec;
     const double osz = (double)opsz;
     const double nout = g.geglu ? g.N / 2 : g.N;
     const double flops = 2.0 * g.M * (double)g.N * g.K;
@@ -1102,6 +1118,9 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   h->x0 = P.alloc<float>((size_t)B * T * CP);
   h->xe_op = P.alloc_op((size_t)B * T * CP);
   h->content_op = P.alloc_op((size_t)B * T * c.content_channels);
+  const bool xio = h->exact_io && prec != PREC_F32;            // conv_in / conv_out / time_emb_proj with fp32 operands inside a 16-bit engine
+  h->content_f32 = xio ? P.alloc<float>((size_t)B * T * c.content_channels) : nullptr;
+  h->emb_act_f32 = xio ? P.alloc<float>((size_t)B * E) : nullptr;
   h->content_conv = P.alloc<float>((size_t)B * T * c0);
   h->prompt = P.alloc<float>((size_t)B * Lp * cross);
   h->prompt_op = P.alloc_op((size_t)B * Lp * cross);
@@ -1143,9 +1162,10 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     float *prompt = h->prompt, *seq = h->seq, *pq = h->pool_qkv_buf, *pooled = h->pooled, *aug = h->aug;
     void *prompt_op = h->prompt_op, *seq_op = h->seq_op;
     // content half of conv_in (+ conv_in bias)
-    GemmArgs g = P.base(h->content_op, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, nullptr, c0);
+    GemmArgs g = xio ? P.base(h->content_f32, c.content_channels, c.content_channels, T, T, h->conv_in_c32, h->content_conv, nullptr, c0)
+                     : P.base(h->content_op, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, nullptr, c0);
     g.taps = 3;
-    P.gemm("cond.conv_in.content", g);
+    P.gemm("cond.conv_in.content", g, xio ? PREC_F32 : -1);
     if (!sizing) h->cond_split = h->cond_ops.size();
     // all cross-attention k|v projections in one GEMM: prompt [B*Lp][cross] x [n_kv][cross]^T -> operand tensor
     const size_t np = (size_t)B * Lp * cross;
@@ -1196,18 +1216,19 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     ns2vc_unet* hh = h;
     const float *w1t = h->t_w1t, *b1 = h->t_b1, *w2t = h->t_w2t, *b2 = h->t_b2, *aug = h->aug;
     float *emb = h->emb, *tdev = h->t_dev;
-    void* emb_act = h->emb_act_op;
+    void* emb_act = xio ? (void*)h->emb_act_f32 : h->emb_act_op;
+    const int eprec = xio ? PREC_F32 : prec;                    // type SiLU(emb) is written in
     const int tdim = c0;
     if (!sizing) { h->temb_begin = (int)h->fwd_ops.size(); h->temb_join = -1; }
     P.add("time_embed", [=](hipStream_t s) {
       // sampling loop: the MLP of every step's timestep was evaluated once for the table (ns2vc_sampler_run), a step adds aug
-      if (hh->use_step_table) return launch_emb_from_table(hh->temb_table, hh->step_dev, aug, emb, emb_act, prec, B, E, s);
-      return launch_time_embed(tdev, 1, nullptr, 0, w1t, b1, w2t, b2, aug, emb, emb_act, prec, B, tdim, E, s);
+      if (hh->use_step_table) return launch_emb_from_table(hh->temb_table, hh->step_dev, aug, emb, emb_act, eprec, B, E, s);
+      return launch_time_embed(tdev, 1, nullptr, 0, w1t, b1, w2t, b2, aug, emb, emb_act, eprec, B, tdim, E, s);
     });
     P.tap("emb", emb, B, E);
     // every resnet's time_emb_proj(SiLU(emb)) in one GEMM (M = B)
-    GemmArgs g = P.base(emb_act, E, E, 1, 1, h->temb_all, h->temb, nullptr, h->temb_all.N);
-    P.gemm("time_emb_proj.all", g);
+    GemmArgs g = P.base(emb_act, E, E, 1, 1, xio ? h->temb_all32 : h->temb_all, h->temb, nullptr, h->temb_all.N);
+    P.gemm("time_emb_proj.all", g, xio ? PREC_F32 : -1);
     if (!sizing) h->temb_end = (int)h->fwd_ops.size();
   }
   // skip stack
@@ -1216,10 +1237,11 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   auto new_skip = [&](int l) { float* p = P.alloc<float>((size_t)B * Ts[l] * c.block_out_channels[l]); skips.push_back({p, c.block_out_channels[l], l}); return p; };
   {
     float* s0 = new_skip(0);
-    GemmArgs g = P.base(h->xe_op, CP, CP, T, T, h->conv_in_x, s0, nullptr, c0);
+    GemmArgs g = xio ? P.base(h->xe, CP, CP, T, T, h->conv_in_x32, s0, nullptr, c0)          // (the fp32 solver state IS the fp32 operand: no copy involved)
+                     : P.base(h->xe_op, CP, CP, T, T, h->conv_in_x, s0, nullptr, c0);
     g.taps = 3; g.res = h->content_conv; g.ldres = c0;
     g.stats = P.new_stats(s0, T, c0);
-    P.gemm("conv_in", g);
+    P.gemm("conv_in", g, xio ? PREC_F32 : -1);
     P.tap("conv_in", s0, B * T, c0);
   }
   const float* cur = skips.back().p;
@@ -1294,12 +1316,14 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   if (!skips.empty()) return fail("internal: %zu skips left over", skips.size());
   {
     const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N, 3);
-    GemmArgs g = P.base(P.xn, curC, curC, T, T, h->conv_out, h->x0, nullptr, CP);
+    // exact_io: only where the norm is the conv's prologue (it then writes fp32 operand rows: xn holds 2-byte elements of up to 3 x 128 channels per row, i.e. room for 128 fp32)
+    const bool xo = xio && pno.x != nullptr && (size_t)curC * 4 <= (size_t)3 * c0 * P.opsz;
+    GemmArgs g = P.base(P.xn, curC, curC, T, T, xo ? h->conv_out32 : h->conv_out, h->x0, nullptr, CP);
     g.taps = 3;
     P.gn_fuse(g, pno);
     if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
-    P.gemm("conv_out", g);
-    if (!sizing) { h->conv_out_g = g; h->conv_out_idx = (int)h->fwd_ops.size() - 1; }
+    P.gemm("conv_out", g, xo ? PREC_F32 : -1);
+    if (!sizing) { h->conv_out_g = g; h->conv_out_idx = (int)h->fwd_ops.size() - 1; h->conv_out_prec = xo ? PREC_F32 : prec; }
     P.tap("out", h->x0, B * T, CP);
   }
   if (sizing) h->arena_bytes = P.off;
@@ -1376,6 +1400,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "fuse_solver")) return &h->fuse_solver;
   if (!strcmp(name, "fuse_xattn")) return &h->fuse_xattn;
   if (!strcmp(name, "fork_temb")) return &h->fork_temb;
+  if (!strcmp(name, "exact_io")) return &h->exact_io;
   return nullptr;
 }
 
@@ -1464,7 +1489,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}, {"NS2VC_FORK_TEMB", "fork_temb"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}, {"NS2VC_FORK_TEMB", "fork_temb"}, {"NS2VC_EXACT_IO", "exact_io"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1549,7 +1574,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn, fork_temb)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn, fork_temb, exact_io)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -1624,7 +1649,7 @@ int ns2vc_unet_set_content(ns2vc_unet* h, const float* content_bct, void* stream
   if (!content_bct) return fail("null condition tensor");
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
-  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, nullptr, h->content_op, h->prec, c.content_channels, c.content_channels, s));
+  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, h->content_f32, h->content_op, h->prec, c.content_channels, c.content_channels, s));
   return run_ops(h->cond_ops, s, 0, h->cond_split);
 }
 
@@ -1696,11 +1721,12 @@ int ns2vc_sampler_load(ns2vc_unet* h, int steps, const float* coef_host) {
 // (same arithmetic, element for element: common.h solver_upd) -- x0 is never written, the state tensors are read and written once instead of twice
 static bool solver_in_conv_out(ns2vc_unet* h, GemmArgs& g) {
   if (!h->fuse_solver || h->debug || h->conv_out_idx < 0 || h->conv_out_idx != (int)h->fwd_ops.size() - 1) return false;
+  if (h->conv_out_prec != h->prec) return false;      // (exact_io: conv_out runs in fp32 there, the operand copy of the state is 16-bit)
   g = h->conv_out_g;
   g.out_f32 = nullptr;
   g.sol_coef = h->coef_dev; g.sol_step = h->step_dev; g.sol_ncoef = NS2VC_NCOEF;
   g.sol_xe = h->xe; g.sol_xe_op = h->xe_op; g.sol_xbar = h->xbar; g.sol_d1 = h->d1; g.sol_mprev = h->mprev; g.sol_ld = h->CP;
-  return gemm_uses_convts(g, h->prec);
+  return gemm_uses_convts(g, h->conv_out_prec);
 }
 static int run_step(ns2vc_unet* h, hipStream_t s, bool capturing = false) {
   GemmArgs g;
@@ -1724,7 +1750,7 @@ static int run_step(ns2vc_unet* h, hipStream_t s, bool capturing = false) {
   }
   if (run_ops(h->fwd_ops, s, first, last)) return 1;
   if (fold) {
-    HIPCHK(launch_gemm(g, h->prec, s));
+    HIPCHK(launch_gemm(g, h->conv_out_prec, s));
     return 0;
   }
   const size_t n = (size_t)h->B * h->T * h->CP;
