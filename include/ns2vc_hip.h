@@ -267,6 +267,13 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * decides per plan (from ITS device's CU count) and passes the choice along, so that two engines on different devices -- or a debug hook called
    * between plan build and launch -- cannot change a launch's tiling relative to what its plan assumed. */
   int32_t conv_bn;
+  /* ABI v7, 16-bit precisions: hi + lo operand pairs (x = hi(x) + lo(x) with hi = the operand type's rounding of x, lo = the rounding of the rest).  A GEMM
+   * over [hi | lo | hi] activation columns against [hi(w) | hi(w) | lo(w)] weight columns (the caller packs them so) gives x * w to ~2^-21 relative instead of
+   * 2^-11 for 3x the K -- the engine's `split_io` option uses it for conv_in and conv_out (23 % of the fp16 forward error's energy, profiles/r06_error_budget.txt).
+   *   gnp_pair = 1: the GroupNorm prologue normalises c0 / 2 channels and writes the pair: hi at a0[r][c], lo at a0[r][c0 / 2 + c]; the launch may then
+   *                  carry a1 = a0, c1 = c0 / 2 (the hi plane once more) -- the one case where c1 != 0 goes with gnp_x.  Materialising prologue only.
+   *   sol_op_pair = 1: sol_xe_op rows hold such a pair, [hi(sol_ld) | lo(sol_ld)], row stride 2 * sol_ld (what ns2vc_k_solver_update writes for the engine). */
+  int32_t gnp_pair, sol_op_pair;
 } ns2vc_gemm_args;
 
 typedef struct ns2vc_attn_args {

@@ -56,6 +56,7 @@ class GemmArgs(C.Structure):
         ("sol_coef", C.c_void_p), ("sol_step", C.c_void_p), ("sol_ncoef", C.c_int32),
         ("sol_xe", C.c_void_p), ("sol_xe_op", C.c_void_p), ("sol_xbar", C.c_void_p), ("sol_d1", C.c_void_p), ("sol_mprev", C.c_void_p), ("sol_ld", C.c_int32),
         ("conv_bn", C.c_int32),
+        ("gnp_pair", C.c_int32), ("sol_op_pair", C.c_int32),
     ]
 
 

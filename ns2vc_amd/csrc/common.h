@@ -124,6 +124,10 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
+// what the operand type drops of v: v - float(TM(v)) -- the `lo` plane of a hi + lo operand pair (r6 split_io: conv_in / conv_out with
+// x*w ~= hi(x)*hi(w) + lo(x)*hi(w) + hi(x)*lo(w) on the 16-bit MFMA, 2^-22-ish relative instead of 2^-11)
+template <typename TM> __device__ __forceinline__ float op_rest(float v) { return v - Op16<TM>::lo(Op16<TM>::pack(v, 0.f)); }
+template <> __device__ __forceinline__ float op_rest<float>(float) { return 0.f; }
 template <typename TM> __device__ __forceinline__ void store_op4(TM* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store_op4<float>(float* p, float a, float b, float c, float d) {
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
@@ -272,7 +276,7 @@ hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, i
                            const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, void* raw_op,
                            int prec, hipStream_t s);
 hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s);
-hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s);
+hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s, int split = 0);   // split: as launch_solver_update
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride,
                              const float* w1t, const float* b1, const float* w2t, const float* b2,
                              const float* aug, float* emb, void* emb_act_op, int prec, int B, int tdim, int edim, hipStream_t s);
@@ -287,7 +291,8 @@ int probe_xcd_round_robin(unsigned* map8 = nullptr);
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s, int* counter = nullptr);                                  // bytes: any; p 16-byte aligned
 hipError_t launch_copy16(const void* src, void* dst, size_t bytes, hipStream_t s);           // bytes % 16 == 0
 hipError_t launch_poison(unsigned pattern, int lds_bytes, unsigned* sink, hipStream_t s);
-hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s);
+hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s,
+                             int ldd_op = 0, int split = 0);   // split > 0 (16-bit): dst_op rows of ldd_op columns hold a hi + lo pair, lo at column split + c
 hipError_t launch_btc_to_nct(const float* src, int lds, int C, int T, int B, float* dst, hipStream_t s);
 hipError_t launch_mask_bias(const uint8_t* mask, int n, float* bias, hipStream_t s);
 hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float* gamma, const float* beta,
@@ -297,7 +302,8 @@ hipError_t launch_pool_attn(const float* qkv, int B, int L1, int C, int heads, f
 hipError_t launch_pool_proj(const float* pooled, int B, int C, const float* wt, const float* b, int E,
                             const float* gamma, const float* beta, float eps, float* out, hipStream_t s);
 hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0,
-                                float* xe, void* xe_op, int prec, float* xbar, float* d1, float* mprev, size_t n, hipStream_t s);
+                                float* xe, void* xe_op, int prec, float* xbar, float* d1, float* mprev, size_t n, hipStream_t s,
+                                int split = 0);                 // split > 0 (16-bit): xe_op rows are [hi(split) | lo(split)] of state rows of `split` columns
 hipError_t launch_fill_i32(int* p, int v, hipStream_t s);
 hipError_t launch_placement(unsigned* dev_out, int n_blocks, int spin, hipStream_t s);
 hipError_t launch_snapshot_u32(unsigned* src, unsigned* dst, hipStream_t s);   // *dst = atomicExch(src, 0)

@@ -112,9 +112,11 @@ template <int LO, int HI> struct TsWait {
 // 8 KB instead of 12 KB of fragment reads per wave and step (1 KB per MFMA instead of 1.5); the two K halves meet in the LDS-staged epilogue as
 // gemm4_kernel's do.  Measured (r5 session 11): 11.9 vs 11.5 us isolated, 3.543 vs 3.542 ms/step in situ -- the consumers hide under the DMA stream either
 // way (profiles/r05_ts_ablate.txt), so it stays a tested option (NS2VC_TS_KS_DEFAULT 0).
-// GNP: 0 = no GroupNorm in front, 1 = the materialising prologue (gnpro.h GnPrologue: rows written to a0, read back by DMA), 2 = the loader waves
+// GNP: 0 = no GroupNorm in front, 1 (3: writing hi + lo operand pairs, gnp_pair) = the materialising prologue (gnpro.h GnPrologue: rows written to a0, read back by DMA), 2 = the loader waves
 // normalise inside the K loop (gnpro.h GnInloop; chunk-granular loop only)
-template <typename TM, int BN, int NL, int GNP, bool KS = false>
+// SOL: with the solver-update epilogue (GemmArgs.sol_*; its own instantiations: compiled into every kernel it cost the 128-column tiles 26 spilled registers and the
+// step 0.2 %, profiles/r06_ab_split_io.txt)
+template <typename TM, int BN, int NL, int GNP, bool KS = false, bool SOL = false>
 __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g) {
   op_mode_init<TM>();
   constexpr int EPC = MmaT<TM>::EPC;
@@ -302,12 +304,12 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
     if (producer) gnl.load(g, 0, xs);                            // chunk 0's rows fly while the statistics are turned into (mean, rstd)
     gnl.table(g, tid, tabmem);
   }
-  if constexpr (GNP == 1) {
+  if constexpr (GNP == 1 || GNP == 3) {
     if (g.gnp_x != nullptr) {
       // the real rows behind padded rows [q0 - 1, q0 + 127): f(q) = number of real rows with a padded index below q
       auto real_below = [&](int q) __attribute__((always_inline)) { const int b = q / P; return b * T + min(q - b * P, T); };
       const int rlo = real_below(max(q0 - 1, 0)), rhi = real_below(min(q0 + TS_BM - 1, MP));
-      GnPrologue<TM, NS2VC_GNP_XB> gpro;
+      GnPrologue<TM, NS2VC_GNP_XB, GNP == 3> gpro;
       gpro.begin(g, rlo, rhi, tm, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
       gpro.finish(g, tid, aring);                                // (its table lives in the activation ring: nothing has been issued into it yet)
     }
@@ -601,7 +603,8 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       }
       vv[k] = v;
     }
-    if (g.sol_coef) {
+    if constexpr (SOL) {
+     if (g.sol_coef) {
       // r6 (tested option, engine switch fuse_solver): the sampling loop's solver update on the tile this workgroup holds (conv_out: every latent row exactly
       // once): the result is x0, the state rows are four more row loads -- one launch, 73 MB of reads and 15 MB of writes less per step than the separate
       // kernel.  Measured time-neutral to 0.4 % slower (profiles/r06_ab_fuse_solver.txt): the separate kernel streams at HBM speed, these loads sit in the
@@ -624,12 +627,19 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
           solver_upd(sk, vv[k].z, sxe[k].z, sxb[k].z, sd1[k].z, smp[k].z, oxe.z, oxb.z, od1.z, om.z);
           solver_upd(sk, vv[k].w, sxe[k].w, sxb[k].w, sd1[k].w, smp[k].w, oxe.w, oxb.w, od1.w, om.w);
           out_f4(g.sol_xe + o, oxe.x, oxe.y, oxe.z, oxe.w);
-          out_op4<TM>(reinterpret_cast<TM*>(g.sol_xe_op) + o, oxe.x, oxe.y, oxe.z, oxe.w);
+          if (g.sol_op_pair) {                             // hi + lo operand pair, rows of 2 * sol_ld columns
+            TM* const q = reinterpret_cast<TM*>(g.sol_xe_op) + o + (size_t)mrow[k] * g.sol_ld;
+            out_op4<TM>(q, oxe.x, oxe.y, oxe.z, oxe.w);
+            out_op4<TM>(q + g.sol_ld, op_rest<TM>(oxe.x), op_rest<TM>(oxe.y), op_rest<TM>(oxe.z), op_rest<TM>(oxe.w));
+          } else {
+            out_op4<TM>(reinterpret_cast<TM*>(g.sol_xe_op) + o, oxe.x, oxe.y, oxe.z, oxe.w);
+          }
           out_f4(g.sol_xbar + o, oxb.x, oxb.y, oxb.z, oxb.w);
           out_f4(g.sol_d1 + o, od1.x, od1.y, od1.z, od1.w);
           out_f4(g.sol_mprev + o, om.x, om.y, om.z, om.w);
         }
       }
+     }
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -728,7 +738,22 @@ template <typename TM, int BN, int NL, bool KS> static hipError_t launch_ts_cfg(
   // GroupNorm in front: inside the loop (GnInloop: eight non-consumer waves = four DMA + four producer waves, chunk-granular loop, plain consumer layout) unless
   // the caller asks for the materialising prologue (algo == 2)
   constexpr bool HAS_INLOOP = NS2VC_TS_CHUNK && NL == 8 && !KS;
-  if (g.gnp_x && HAS_INLOOP && g.algo != 2) {
+  if (g.sol_coef) {                                               // the solver-update epilogue: its own instantiations (one 128-column tile, eight loaders)
+    constexpr bool HAS_SOL = BN == 128 && NL == 8 && !KS;
+    if constexpr (HAS_SOL) {
+      if (g.gnp_x && g.gnp_pair) {
+        if constexpr (!std::is_same<TM, float>::value) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 3, KS, true>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+        else return hipErrorInvalidValue;
+      }
+      else if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 1, KS, true>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);     // (always the materialising prologue)
+      else hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 0, KS, true>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+    } else return hipErrorInvalidValue;
+  }
+  else if (g.gnp_x && g.gnp_pair) {                                    // a hi + lo operand pair is something the materialising prologue writes (its own instantiation)
+    if constexpr (!std::is_same<TM, float>::value && NL == 8 && !KS) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 3, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
+    else return hipErrorInvalidValue;
+  }
+  else if (g.gnp_x && HAS_INLOOP && g.algo != 2) {
     if constexpr (HAS_INLOOP) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 2, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
   }
   else if (g.gnp_x) hipLaunchKernelGGL((conv3ts_kernel<TM, BN, NL, 1, KS>), dim3(nb), dim3(64 * (NL + 4)), ts_lds_bytes(BN), s, g);
@@ -748,6 +773,7 @@ hipError_t launch_convts(const GemmArgs& g, int prec, int bn, int nl, int ks, hi
   if (!bn) bn = convts_default_bn(g);
   if (!nl) nl = NS2VC_TS_NL_DEFAULT;
   if (ks < 0) ks = NS2VC_TS_KS_DEFAULT;
+  if (g.sol_coef) { bn = 128; nl = 8; ks = 0; }                   // (the one configuration the solver epilogue is instantiated for)
   if (g.N % bn) return hipErrorInvalidValue;
   switch (prec) {
     case PREC_BF16: return launch_ts_typed<bf16_t>(g, bn, nl, ks, s);
@@ -770,6 +796,13 @@ template <typename TM> static hipError_t ts_init_typed() {
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, 2>, ts_lds_bytes(64));
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 128, 8, 2>, ts_lds_bytes(128));
 #endif
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 128, 8, 0, false, true>, ts_lds_bytes(128));
+  if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 128, 8, 1, false, true>, ts_lds_bytes(128));
+  if constexpr (!std::is_same<TM, float>::value) {
+    if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 128, 8, 3, false, true>, ts_lds_bytes(128));
+    if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, 3>, ts_lds_bytes(64));
+    if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 128, 8, 3>, ts_lds_bytes(128));
+  }
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, 0, true>, ts_lds_bytes(64));
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 4, 1, true>, ts_lds_bytes(64));
   if (e == hipSuccess) e = ts_set_lds(conv3ts_kernel<TM, 64, 8, 0, true>, ts_lds_bytes(64));

@@ -136,6 +136,7 @@ struct ns2vc_unet {
   // packed weights
   std::vector<BlockW> blocks;
   PackedW conv_in_x, conv_in_c, conv_out, temb_all, kv_all, pool_qkv;
+  PackedW conv_in_xp, conv_in_cp, conv_outp;                     // r6, 16-bit engines: the first three against hi + lo operand pairs (option split_io; K = 3 x)
   PackedW conv_in_x32, conv_in_c32, conv_out32, temb_all32;      // r6, 16-bit engines: the same four in fp32 (option exact_io)
   float *t_w1t = nullptr, *t_b1 = nullptr, *t_w2t = nullptr, *t_b2 = nullptr;
   float *p_n1g = nullptr, *p_n1b = nullptr, *p_pos = nullptr, *p_projT = nullptr, *p_projb = nullptr, *p_n2g = nullptr, *p_n2b = nullptr;
@@ -176,6 +177,9 @@ struct ns2vc_unet {
   bool gn_coop = true;                    // the column tiles of one row block split the GroupNorm prologue's rows between them (ns2vc_gemm_args.gnp_sync)
   bool conv_ts = true;         // k = 3 convolutions on the tap-sharing kernel (convts.hip, r5)
   bool conv_wtiled = true;     // ... reading tile-major weights (PackedW.wt)
+  bool split_io = true;       // r6 (16-bit engines): conv_in and conv_out -- 23 % of the forward error's energy in two launches (profiles/r06_error_budget.txt) -- on hi + lo operand
+                              //   pairs: x * w ~= hi(x) hi(w) + lo(x) hi(w) + hi(x) lo(w), three times the K of two small convolutions instead of their fp32 MFMA rate (exact_io)
+                              //   ON: forward error 8.08e-4 -> 7.10e-4 at the bench shape for +0.3 % of the step (profiles/r06_ab_split_io.txt)
   bool exact_io = false;       // r6 (16-bit engines): conv_in, conv_out and the time_emb_proj GEMM -- three single launches that carry 23 + 6 % of the forward error's energy
                                // (profiles/r06_error_budget.txt) -- with fp32 operands on the fp32 MFMA: a precision-for-time knob
   float* content_f32 = nullptr;      // ... their fp32 inputs: the content rows, SiLU(emb)
@@ -462,6 +466,17 @@ struct Packer {
         for (int t = 0; t < taps; ++t) rows[((size_t)n * taps + t) * CinP + (c - c_lo)] = w.data[((size_t)n * Cin + c) * taps + t];
     return rows;
   }
+  // rows [N][taps][C] -> [N][taps][3 C] for activations laid out [hi(x) | lo(x) | hi(x)]: (w, w, w - round(w)); pack() then rounds each -> (hi(w), hi(w), lo(w))
+  std::vector<float> pair_rows(const std::vector<float>& rows, int N, int taps, int C) {
+    std::vector<float> out((size_t)N * taps * 3 * C);
+    for (size_t nt = 0; nt < (size_t)N * taps; ++nt)
+      for (int c = 0; c < C; ++c) {
+        const float w = rows[nt * C + c];
+        out[nt * 3 * C + c] = out[nt * 3 * C + C + c] = w;
+        out[nt * 3 * C + 2 * C + c] = w - op16_bits_to_f32(f32_to_op16_bits(w, h->prec), h->prec);
+      }
+    return out;
+  }
   PackedW conv(const std::string& prefix, bool tile3 = false) {
     const HostTensor& w = T(prefix + ".weight");
     if (err) return {};
@@ -529,6 +544,11 @@ int pack_all(ns2vc_unet* h) {
     if (P.err) return 1;
     h->conv_in_x = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {}, false, CP, 0);
     h->conv_in_c = P.pack(P.conv_rows(w, lat, lat + c.content_channels, c.content_channels), c0, 3 * c.content_channels, P.T("conv_in.bias").data);
+    if (h->prec != PREC_F32) {
+      const int cc = c.content_channels;
+      h->conv_in_xp = P.pack(P.pair_rows(P.conv_rows(w, 0, lat, CP), c0, 3, CP), c0, 9 * CP, {}, false, 3 * CP, 0);
+      h->conv_in_cp = P.pack(P.pair_rows(P.conv_rows(w, lat, lat + cc, cc), c0, 3, cc), c0, 9 * cc, P.T("conv_in.bias").data, false, 3 * cc, 0);
+    }
     if (h->prec != PREC_F32) {
       P.prec_override = PREC_F32;
       h->conv_in_x32 = P.pack(P.conv_rows(w, 0, lat, CP), c0, 3 * CP, {}, false, CP, 0);
@@ -722,6 +742,7 @@ int pack_all(ns2vc_unet* h) {
     const HostTensor& w = P.T("conv_out.weight");
     if (P.err) return 1;
     h->conv_out = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data, false, c0, 0);
+    if (h->prec != PREC_F32) h->conv_outp = P.pack(P.pair_rows(P.conv_rows(w, 0, c0, c0), lat, 3, c0), lat, 9 * c0, P.T("conv_out.bias").data, false, 3 * c0, 0);
     if (h->prec != PREC_F32) { P.prec_override = PREC_F32; h->conv_out32 = P.pack(P.conv_rows(w, 0, c0, c0), lat, 3 * c0, P.T("conv_out.bias").data, false, c0, 0); P.prec_override = -1; }
   }
   return P.err;
@@ -1116,8 +1137,11 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   h->xe = P.alloc<float>((size_t)B * T * CP); h->xbar = P.alloc<float>((size_t)B * T * CP);
   h->d1 = P.alloc<float>((size_t)B * T * CP); h->mprev = P.alloc<float>((size_t)B * T * CP);
   h->x0 = P.alloc<float>((size_t)B * T * CP);
-  h->xe_op = P.alloc_op((size_t)B * T * CP);
-  h->content_op = P.alloc_op((size_t)B * T * c.content_channels);
+  // 16-bit engines keep the two inputs of conv_in as hi + lo operand pairs, rows [hi(C) | lo(C)] (common.h op_rest): the lo planes are read with split_io only
+  const int pw = prec != PREC_F32 ? 2 : 1;
+  h->xe_op = P.alloc_op((size_t)B * T * CP * pw);
+  h->content_op = P.alloc_op((size_t)B * T * c.content_channels * pw);
+  const bool pio = h->split_io && prec != PREC_F32 && !h->exact_io;
   const bool xio = h->exact_io && prec != PREC_F32;            // conv_in / conv_out / time_emb_proj with fp32 operands inside a 16-bit engine
   h->content_f32 = xio ? P.alloc<float>((size_t)B * T * c.content_channels) : nullptr;
   h->emb_act_f32 = xio ? P.alloc<float>((size_t)B * E) : nullptr;
@@ -1162,8 +1186,11 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     float *prompt = h->prompt, *seq = h->seq, *pq = h->pool_qkv_buf, *pooled = h->pooled, *aug = h->aug;
     void *prompt_op = h->prompt_op, *seq_op = h->seq_op;
     // content half of conv_in (+ conv_in bias)
-    GemmArgs g = xio ? P.base(h->content_f32, c.content_channels, c.content_channels, T, T, h->conv_in_c32, h->content_conv, nullptr, c0)
-                     : P.base(h->content_op, c.content_channels, c.content_channels, T, T, h->conv_in_c, h->content_conv, nullptr, c0);
+    const int cc = c.content_channels;
+    GemmArgs g = xio ? P.base(h->content_f32, cc, cc, T, T, h->conv_in_c32, h->content_conv, nullptr, c0)
+               : pio ? P.base(h->content_op, 2 * cc, 2 * cc, T, T, h->conv_in_cp, h->content_conv, nullptr, c0)
+                     : P.base(h->content_op, pw * cc, cc, T, T, h->conv_in_c, h->content_conv, nullptr, c0);
+    if (pio) { g.a1 = h->content_op; g.lda1 = 2 * cc; g.c1 = cc; }       // [hi | lo] then hi once more, against (hi(w) | hi(w) | lo(w))
     g.taps = 3;
     P.gemm("cond.conv_in.content", g, xio ? PREC_F32 : -1);
     if (!sizing) h->cond_split = h->cond_ops.size();
@@ -1238,7 +1265,9 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   {
     float* s0 = new_skip(0);
     GemmArgs g = xio ? P.base(h->xe, CP, CP, T, T, h->conv_in_x32, s0, nullptr, c0)          // (the fp32 solver state IS the fp32 operand: no copy involved)
-                     : P.base(h->xe_op, CP, CP, T, T, h->conv_in_x, s0, nullptr, c0);
+               : pio ? P.base(h->xe_op, 2 * CP, 2 * CP, T, T, h->conv_in_xp, s0, nullptr, c0)
+                     : P.base(h->xe_op, pw * CP, CP, T, T, h->conv_in_x, s0, nullptr, c0);
+    if (pio) { g.a1 = h->xe_op; g.lda1 = 2 * CP; g.c1 = CP; }
     g.taps = 3; g.res = h->content_conv; g.ldres = c0;
     g.stats = P.new_stats(s0, T, c0);
     P.gemm("conv_in", g, xio ? PREC_F32 : -1);
@@ -1318,9 +1347,17 @@ int build_plan(ns2vc_unet* h, bool sizing) {
     const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N, 3);
     // exact_io: only where the norm is the conv's prologue (it then writes fp32 operand rows: xn holds 2-byte elements of up to 3 x 128 channels per row, i.e. room for 128 fp32)
     const bool xo = xio && pno.x != nullptr && (size_t)curC * 4 <= (size_t)3 * c0 * P.opsz;
-    GemmArgs g = P.base(P.xn, curC, curC, T, T, xo ? h->conv_out32 : h->conv_out, h->x0, nullptr, CP);
-    g.taps = 3;
-    P.gn_fuse(g, pno);
+    // split_io: likewise only behind a fused prologue, which then writes the hi + lo pair (gnp_pair) into the 3 x 128 columns a row of xn has
+    const bool po = pio && pno.x != nullptr && 2 * curC <= 3 * c0;
+    GemmArgs g;
+    for (int pair = po ? 1 : 0; pair >= 0; --pair) {
+      g = pair ? P.base(P.xn, 2 * curC, 2 * curC, T, T, h->conv_outp, h->x0, nullptr, CP)
+               : P.base(P.xn, curC, curC, T, T, xo ? h->conv_out32 : h->conv_out, h->x0, nullptr, CP);
+      if (pair) { g.a1 = P.xn; g.lda1 = 2 * curC; g.c1 = curC; g.gnp_pair = 1; }
+      g.taps = 3;
+      P.gn_fuse(g, pno);
+      if (!pair || gemm_uses_convts(g, prec)) break;              // (the pair prologue exists in the tap-sharing kernel only)
+    }
     if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
     P.gemm("conv_out", g, xo ? PREC_F32 : -1);
     if (!sizing) { h->conv_out_g = g; h->conv_out_idx = (int)h->fwd_ops.size() - 1; h->conv_out_prec = xo ? PREC_F32 : prec; }
@@ -1401,6 +1438,7 @@ static bool* option_ptr(ns2vc_unet* h, const char* name) {
   if (!strcmp(name, "fuse_xattn")) return &h->fuse_xattn;
   if (!strcmp(name, "fork_temb")) return &h->fork_temb;
   if (!strcmp(name, "exact_io")) return &h->exact_io;
+  if (!strcmp(name, "split_io")) return &h->split_io;
   return nullptr;
 }
 
@@ -1489,7 +1527,7 @@ int ns2vc_unet_create(const ns2vc_unet_cfg* cfg, ns2vc_unet** out) {
       {"NS2VC_LN_LINEAR", "ln_linear"}, {"NS2VC_FOLD_FF", "fold_ff"}, {"NS2VC_FUSE_FFN", "fuse_ffn"}, {"NS2VC_FUSE_ROWS", "fuse_rows"},
       {"NS2VC_FUSE_ROWS_GN", "fuse_rows_gn"}, {"NS2VC_FUSE_GN_GEMM", "fuse_gn_gemm"}, {"NS2VC_GN_COOP", "gn_coop"}, {"NS2VC_FUSE_GN_CAT", "fuse_gn_cat"},
       {"NS2VC_SLICE_ROWS", "slice_rows"}, {"NS2VC_FUSE_FFN_PRE", "fuse_ffn_pre"}, {"NS2VC_FUSE_GEGLU", "fuse_geglu"}, {"NS2VC_ATTN_FP8", "attn_fp8"}, {"NS2VC_ATTN_OPTIMISTIC", "attn_optimistic"},
-      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}, {"NS2VC_FORK_TEMB", "fork_temb"}, {"NS2VC_EXACT_IO", "exact_io"}};
+      {"NS2VC_CONV_TS", "conv_ts"}, {"NS2VC_CONV_WTILED", "conv_wtiled"}, {"NS2VC_GN_INLOOP", "gn_inloop"}, {"NS2VC_FUSE_SOLVER", "fuse_solver"}, {"NS2VC_FUSE_XATTN", "fuse_xattn"}, {"NS2VC_FORK_TEMB", "fork_temb"}, {"NS2VC_EXACT_IO", "exact_io"}, {"NS2VC_SPLIT_IO", "split_io"}};
     for (const auto& s : sw)
       if (const char* v = getenv(s.env)) {
         if (bool* o = option_ptr(h, s.opt)) *o = atoi(v) != 0;
@@ -1574,7 +1612,7 @@ int ns2vc_unet_set_option(ns2vc_unet* h, const char* name, int value) {
   if (!h || !name) return fail("null argument");
   if (bind_device(h)) return 1;
   bool* opt = option_ptr(h, name);
-  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn, fork_temb, exact_io)", name);
+  if (!opt) return fail("unknown option '%s' (ln_linear, fold_ff, fuse_ffn, fuse_ffn_pre, fuse_geglu, fuse_rows, fuse_rows_gn, fuse_gn_gemm, fuse_gn_cat, gn_coop, slice_rows, attn_fp8, attn_optimistic, conv_ts, conv_wtiled, gn_inloop, fuse_solver, fuse_xattn, fork_temb, exact_io, split_io)", name);
   // the cooperative GroupNorm prologue only where the placement probe of this device came back positive (r5)
   if (opt == &h->gn_coop && value != 0 && h->xcd_probe != 1) return fail("gn_coop needs workgroup ids 8 apart on one XCD; the placement probe of this device returned %d", h->xcd_probe);
   if (*opt != (value != 0)) { *opt = value != 0; drop_plan(h); }
@@ -1649,7 +1687,9 @@ int ns2vc_unet_set_content(ns2vc_unet* h, const float* content_bct, void* stream
   if (!content_bct) return fail("null condition tensor");
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
-  HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, h->content_f32, h->content_op, h->prec, c.content_channels, c.content_channels, s));
+  { const int pw = h->prec != PREC_F32 ? 2 : 1;      // (16-bit: the hi + lo pair, see prepare)
+    HIPCHK(launch_nct_to_btc(content_bct, c.content_channels, h->T, h->B, h->content_f32, h->content_op, h->prec, c.content_channels, c.content_channels, s,
+                             pw * c.content_channels, pw == 2 ? c.content_channels : 0)); }
   return run_ops(h->cond_ops, s, 0, h->cond_split);
 }
 
@@ -1691,7 +1731,7 @@ int ns2vc_unet_forward(ns2vc_unet* h, const float* x_bct, const float* t_b, floa
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
   h->use_step_table = false;
-  HIPCHK(launch_nct_to_btc(x_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
+  HIPCHK(launch_nct_to_btc(x_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s, h->prec != PREC_F32 ? 2 * h->CP : h->CP, h->prec != PREC_F32 ? h->CP : 0));
   HIPCHK(hipMemcpyAsync(h->t_dev, t_b, (size_t)h->B * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (run_ops(h->fwd_ops, s)) return 1;
   HIPCHK(launch_btc_to_nct(h->x0, h->CP, c.latent_channels, h->T, h->B, out_bct, s));
@@ -1725,7 +1765,7 @@ static bool solver_in_conv_out(ns2vc_unet* h, GemmArgs& g) {
   g = h->conv_out_g;
   g.out_f32 = nullptr;
   g.sol_coef = h->coef_dev; g.sol_step = h->step_dev; g.sol_ncoef = NS2VC_NCOEF;
-  g.sol_xe = h->xe; g.sol_xe_op = h->xe_op; g.sol_xbar = h->xbar; g.sol_d1 = h->d1; g.sol_mprev = h->mprev; g.sol_ld = h->CP;
+  g.sol_xe = h->xe; g.sol_xe_op = h->xe_op; g.sol_xbar = h->xbar; g.sol_d1 = h->d1; g.sol_mprev = h->mprev; g.sol_ld = h->CP; g.sol_op_pair = h->prec != PREC_F32;
   return gemm_uses_convts(g, h->conv_out_prec);
 }
 static int run_step(ns2vc_unet* h, hipStream_t s, bool capturing = false) {
@@ -1754,7 +1794,7 @@ static int run_step(ns2vc_unet* h, hipStream_t s, bool capturing = false) {
     return 0;
   }
   const size_t n = (size_t)h->B * h->T * h->CP;
-  HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xe_op, h->prec, h->xbar, h->d1, h->mprev, n, s));
+  HIPCHK(launch_solver_update(h->coef_dev, h->step_dev, NS2VC_NCOEF, h->x0, h->xe, h->xe_op, h->prec, h->xbar, h->d1, h->mprev, n, s, h->prec != PREC_F32 ? h->CP : 0));
   return 0;
 }
 
@@ -1767,7 +1807,7 @@ int ns2vc_sampler_begin(ns2vc_unet* h, const float* x_T_bct, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const auto& c = h->cfg;
   const size_t n = (size_t)h->B * h->T * h->CP;
-  HIPCHK(launch_nct_to_btc(x_T_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s));
+  HIPCHK(launch_nct_to_btc(x_T_bct, c.latent_channels, h->T, h->B, h->xe, h->xe_op, h->prec, h->CP, h->CP, s, h->prec != PREC_F32 ? 2 * h->CP : h->CP, h->prec != PREC_F32 ? h->CP : 0));
   HIPCHK(launch_copy16(h->xe, h->xbar, n * sizeof(float), s));
   HIPCHK(launch_zero(h->d1, n * sizeof(float), s));
   HIPCHK(launch_zero(h->mprev, n * sizeof(float), s));
@@ -1838,7 +1878,7 @@ int ns2vc_sampler_handoff(ns2vc_unet* dst, ns2vc_unet* src, void* stream) {
   HIPCHK(launch_copy16(src->xbar, dst->xbar, n * sizeof(float), s));
   HIPCHK(launch_copy16(src->d1, dst->d1, n * sizeof(float), s));
   HIPCHK(launch_copy16(src->mprev, dst->mprev, n * sizeof(float), s));
-  HIPCHK(launch_cast_op(dst->xe, n, dst->xe_op, dst->prec, s));
+  HIPCHK(launch_cast_op(dst->xe, n, dst->xe_op, dst->prec, s, dst->prec != PREC_F32 ? dst->CP : 0));
   HIPCHK(launch_fill_i32(dst->step_dev, src->next_step - 1, s));
   dst->next_step = src->next_step;
   src->next_step = -1;

@@ -1088,14 +1088,17 @@ hipError_t launch_gemm(const GemmArgs& g_, int prec, hipStream_t s) {
   if (g.rowstats && (g.N & 127)) return gemm_invalid(__LINE__);
   if ((g.out_f32 && (g.ldo_f32 & 3)) || (g.out_op && (g.ldo_op & 3)) || (g.res && (g.ldres & 3))) return gemm_invalid(__LINE__);   // 16-B row segments
   if (g.gnp_x) {     // GroupNorm-apply prologue: one or two (concatenated) sources, same-length rows, whole 16-channel blocks per group, <= 3 batch items per tile + halo
-    if (g.c1 || g.ln_stats || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 1024 || (g.c0 & 3) || !g.gnp_stats || !g.gnp_gamma ||
-        !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (g.c0 % g.gnp_G) || ((g.c0 / g.gnp_G) & 15) || g.Tin < 66 || (g.gnp_ldx & 3) || (g.lda0 & 3))
+    // (gnp_pair: a0 holds the hi + lo planes of c0 / 2 normalised channels; the hi plane may be read once more through a1 = a0)
+    const int cn = g.gnp_pair ? g.c0 >> 1 : g.c0;
+    if (g.gnp_pair ? (prec == PREC_F32 || (g.c0 & 7) || (g.c1 && (g.a1 != g.a0 || g.c1 != cn || g.lda1 != g.lda0))) : g.c1 != 0) return gemm_invalid(__LINE__);
+    if (g.ln_stats || g.tmode != TMODE_SAME || g.Tin != g.Tout || g.geglu || (g.N & 127) || g.c0 > 1024 || (cn & 3) || !g.gnp_stats || !g.gnp_gamma ||
+        !g.gnp_beta || g.gnp_G < 1 || g.gnp_G > 8 || (cn % g.gnp_G) || ((cn / g.gnp_G) & 15) || g.Tin < 66 || (g.gnp_ldx & 3) || (g.lda0 & 3))
       return gemm_invalid(__LINE__);
     // cooperative form: rows written by other CUs are read back without an L1 invalidate, which is only sound while no cache line holds
     // rows of two row blocks -- whole 128-byte lines per row
     if (g.gnp_sync && ((reinterpret_cast<uintptr_t>(g.a0) & 127) || (((size_t)g.lda0 * operand_bytes(prec)) & 127) || (reinterpret_cast<uintptr_t>(g.gnp_sync) & 7)))
       return gemm_invalid(__LINE__);
-    if (g.gnp_c1 && (g.gnp_c1 < 0 || g.gnp_c1 >= g.c0 || (g.gnp_c1 & 15) || ((g.c0 - g.gnp_c1) & 15) || !g.gnp_x1 || !g.gnp_stats1 || (g.gnp_ldx1 & 3)))
+    if (g.gnp_c1 && (g.gnp_c1 < 0 || g.gnp_c1 >= cn || (g.gnp_c1 & 15) || ((cn - g.gnp_c1) & 15) || !g.gnp_x1 || !g.gnp_stats1 || (g.gnp_ldx1 & 3)))
       return gemm_invalid(__LINE__);                         // a concat of two sources: whole 16-channel blocks from each
   }
   {   // the DMA addresses rows by 32-bit byte offsets from each tensor's base: every operand must stay below 4 GB
@@ -1116,6 +1119,7 @@ hipError_t launch_gemm(const GemmArgs& g_, int prec, hipStream_t s) {
     if (forced_ts) return gemm_invalid(__LINE__);
   }
   if (g.sol_coef) return gemm_invalid(__LINE__);             // the solver epilogue exists in the tap-sharing kernel only
+  if (g.gnp_pair) return gemm_invalid(__LINE__);             // ... and so does the prologue that writes hi + lo operand pairs
   switch (prec) {
     case PREC_BF16: return launch_typed<bf16_t>(g, s);
     case PREC_F16: return launch_typed<f16_t>(g, s);

@@ -26,7 +26,9 @@ namespace ns2vc {
 // In two halves: `begin` issues EVERY load of the prologue -- the first batch of fp32 rows, the int64 statistics of the (item, group)
 // pairs this tile touches, gamma / beta and the time scale / shift rows --, `finish` does the arithmetic and the stores.  (They run back to
 // back: hoisting `begin` above the kernel's row-offset set-up was measured and lost, see NS2VC_GNP_SPLIT.)
-template <typename TM, int XB_> struct GnPrologue {
+// PAIR: the rows are written as a hi + lo operand pair (GemmArgs.gnp_pair; its own instantiation -- as a run-time test in the row loop it cost EVERY
+// prologue launch 1.5 - 1.8 %, through seven more spilled registers)
+template <typename TM, int XB_, bool PAIR = false> struct GnPrologue {
 #ifndef NS2VC_GNP_XB
 #define NS2VC_GNP_XB 6
 #endif
@@ -58,7 +60,7 @@ template <typename TM, int XB_> struct GnPrologue {
   __device__ __forceinline__ void load_temb(const GemmArgs& g, int bi) {
     t1 = t2 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (g.gnp_temb) {
-      const int C = g.c0;
+      const int C = PAIR ? g.c0 >> 1 : g.c0;
       const float* tp = g.gnp_temb + (size_t)(b_lo + bi) * g.gnp_ldtemb + cq;
       if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0 && (C & 3) == 0) {
         t1 = *reinterpret_cast<const float4*>(tp);
@@ -95,7 +97,7 @@ template <typename TM, int XB_> struct GnPrologue {
   }
   // rows [rlo_, rhi_) of the flattened (item, frame) index are what the tile reads; `blk` names the tile's row block (its arrival count)
   __device__ __forceinline__ void begin(const GemmArgs& g, int rlo_, int rhi_, int blk, int tid, int nth, int share, int nshare) {
-    const int C = g.c0, T = g.Tin;
+    const int C = PAIR ? g.c0 >> 1 : g.c0, T = g.Tin;
     Cg = C / g.gnp_G;
     rlo = rlo_; rhi = rhi_;
     b_lo = rlo / T;
@@ -163,8 +165,10 @@ template <typename TM, int XB_> struct GnPrologue {
           if (g.gnp_silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
 #if NS2VC_GNP_WT
           out_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
+          if (PAIR) out_op4<TM>(dst + (size_t)r * g.lda0 + (g.c0 >> 1) + c, op_rest<TM>(y0), op_rest<TM>(y1), op_rest<TM>(y2), op_rest<TM>(y3));   // the lo plane of a hi + lo pair
 #else
           store_op4<TM>(dst + (size_t)r * g.lda0 + c, y0, y1, y2, y3);
+          if (PAIR) store_op4<TM>(dst + (size_t)r * g.lda0 + (g.c0 >> 1) + c, op_rest<TM>(y0), op_rest<TM>(y1), op_rest<TM>(y2), op_rest<TM>(y3));
 #endif
           if (raw) out_op4<TM>(raw + (size_t)r * g.lda0 + c, w[k].x, w[k].y, w[k].z, w[k].w);   // the un-normalised operand copy a later 1x1 shortcut reads
         }
@@ -175,7 +179,7 @@ template <typename TM, int XB_> struct GnPrologue {
     const int T = g.Tin, G = g.gnp_G;
     float2* const gtab = reinterpret_cast<float2*>(smem);                   // (mean, rstd) of (item - b_lo, group): <= 3 x 8
     double2* const bsum = reinterpret_cast<double2*>(smem + OFF_BSUM);      // per (item - b_lo, 16-channel block): the scaled sums, exact in double
-    const int nblk = g.c0 >> 4;
+    const int nblk = (PAIR ? g.c0 >> 1 : g.c0) >> 4;
     if (tid < nbi * nblk) bsum[tid] = make_double2((double)sv[0] * (1.0 / GN_SUM_SCALE), (double)sv[1] * (1.0 / GN_SQ_SCALE));
     __syncthreads();
     if (tid < nbi * G) {                                                    // same finalisation as gn_apply_kernel (misc.hip); the sums are exact, their order is free

@@ -243,11 +243,17 @@ __global__ __launch_bounds__(256) void ln_apply_op_kernel(const float* __restric
 }
 
 template <typename TM>
-__global__ __launch_bounds__(256) void cast_op_kernel(const float* __restrict__ x, size_t n4, TM* __restrict__ out) {
+__global__ __launch_bounds__(256) void cast_op_kernel(const float* __restrict__ x, size_t n4, TM* __restrict__ out, int split) {
   op_mode_init<TM>();
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    store_op4<TM>(out + 4 * i, v.x, v.y, v.z, v.w);
+    if (split) {                                            // hi + lo operand pair: rows of 2 * split columns (see solver_update_kernel)
+      TM* const q = out + 4 * i + ((4 * i) / (size_t)split) * (size_t)split;
+      store_op4<TM>(q, v.x, v.y, v.z, v.w);
+      store_op4<TM>(q + split, op_rest<TM>(v.x), op_rest<TM>(v.y), op_rest<TM>(v.z), op_rest<TM>(v.w));
+    } else {
+      store_op4<TM>(out + 4 * i, v.x, v.y, v.z, v.w);
+    }
   }
 }
 
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256) void emb_from_table_kernel(const float* __rest
 // ---------------------------------------------------------------------------
 template <typename TM>
 __global__ __launch_bounds__(256) void nct_to_btc_kernel(const float* __restrict__ src, int C, int T, float* __restrict__ dst,
-                                                         TM* __restrict__ dst_op, int ldd, int cpad) {
+                                                         TM* __restrict__ dst_op, int ldd, int cpad, int ldd_op, int split) {
   op_mode_init<TM>();
   __shared__ float tile[32][33];
   const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -484,7 +490,11 @@ __global__ __launch_bounds__(256) void nct_to_btc_kernel(const float* __restrict
     const int t = t0 + i, c = c0 + tx;
     if (t < T && c < cpad) {
       if (dst) dst[((size_t)b * T + t) * ldd + c] = tile[tx][i];
-      if (dst_op) store_op<TM>(dst_op + ((size_t)b * T + t) * ldd + c, tile[tx][i]);
+      if (dst_op) {                                         // (split > 0: a hi + lo operand pair, the lo plane `split` columns further)
+        TM* const q = dst_op + ((size_t)b * T + t) * ldd_op + c;
+        store_op<TM>(q, tile[tx][i]);
+        if (split) store_op<TM>(q + split, op_rest<TM>(tile[tx][i]));
+      }
     }
   }
 }
@@ -519,7 +529,7 @@ template <typename TM>
 __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restrict__ coef, const int* __restrict__ step_ptr, int ncoef,
                                                             const float* __restrict__ x0, float* __restrict__ xe, TM* __restrict__ xe_op,
                                                             float* __restrict__ xbar, float* __restrict__ d1,
-                                                            float* __restrict__ mprev, size_t n4) {
+                                                            float* __restrict__ mprev, size_t n4, int split) {
   op_mode_init<TM>();
   const SolverCoef k = solver_coef(coef + (size_t)(*step_ptr) * ncoef);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -534,7 +544,14 @@ __global__ __launch_bounds__(256) void solver_update_kernel(const float* __restr
     solver_upd(k, vx0.z, vxe.z, vxb.z, vd1.z, vmp.z, oxe.z, oxb.z, od1.z, om.z);
     solver_upd(k, vx0.w, vxe.w, vxb.w, vd1.w, vmp.w, oxe.w, oxb.w, od1.w, om.w);
     out_f4(xe + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
-    out_op4<TM>(xe_op + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
+    if (split) {                                            // hi + lo operand pair: rows of 2 * split columns, the lo plane `split` columns further
+      const size_t r = (4 * i) / (size_t)split;
+      TM* const q = xe_op + 4 * i + r * (size_t)split;
+      out_op4<TM>(q, oxe.x, oxe.y, oxe.z, oxe.w);
+      out_op4<TM>(q + split, op_rest<TM>(oxe.x), op_rest<TM>(oxe.y), op_rest<TM>(oxe.z), op_rest<TM>(oxe.w));
+    } else {
+      out_op4<TM>(xe_op + 4 * i, oxe.x, oxe.y, oxe.z, oxe.w);
+    }
     out_f4(xbar + 4 * i, oxb.x, oxb.y, oxb.z, oxb.w);
     out_f4(d1 + 4 * i, od1.x, od1.y, od1.z, od1.w);
     out_f4(mprev + 4 * i, om.x, om.y, om.z, om.w);
@@ -597,11 +614,11 @@ hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, 
   NS2VC_BY_PREC(prec, return launch_ln_t<TMX>(x, ldx, M, C, eps, (TMX*)out_op, s));
   return hipSuccess;
 }
-hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s) {
-  if (n & 3) return hipErrorInvalidValue;
+hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s, int split) {
+  if ((n & 3) || (split && (prec == PREC_F32 || (split & 3) || n % (size_t)split))) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(cast_op_kernel<TMX>, dim3(blocks), dim3(256), 0, s, x, n4, (TMX*)out_op));
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(cast_op_kernel<TMX>, dim3(blocks), dim3(256), 0, s, x, n4, (TMX*)out_op, split));
   return hipGetLastError();
 }
 hipError_t launch_ln_apply(const float* x, int M, int C, float eps, const float* gamma, const float* beta, float* out, int L,
@@ -672,9 +689,11 @@ hipError_t launch_emb_from_table(const float* table, const int* step_ptr, const 
                                          (TMX*)emb_act_op, edim, n));
   return hipGetLastError();
 }
-hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s) {
+hipError_t launch_nct_to_btc(const float* src, int C, int T, int B, float* dst_f32, void* dst_op, int prec, int ldd, int cpad, hipStream_t s, int ldd_op, int split) {
   dim3 grid((T + 31) / 32, (cpad + 31) / 32, B);
-  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(nct_to_btc_kernel<TMX>, grid, dim3(256), 0, s, src, C, T, dst_f32, (TMX*)dst_op, ldd, cpad));
+  if (ldd_op <= 0) ldd_op = ldd;
+  if (split && (prec == PREC_F32 || split < cpad || ldd_op < split + cpad)) return hipErrorInvalidValue;
+  NS2VC_BY_PREC(prec, hipLaunchKernelGGL(nct_to_btc_kernel<TMX>, grid, dim3(256), 0, s, src, C, T, dst_f32, (TMX*)dst_op, ldd, cpad, ldd_op, split));
   return hipGetLastError();
 }
 hipError_t launch_btc_to_nct(const float* src, int lds_, int C, int T, int B, float* dst, hipStream_t s) {
@@ -686,12 +705,12 @@ hipError_t launch_mask_bias(const uint8_t* mask, int n, float* bias, hipStream_t
   return hipGetLastError();
 }
 hipError_t launch_solver_update(const float* coef, const int* step_ptr, int ncoef, const float* x0, float* xe, void* xe_op, int prec,
-                                float* xbar, float* d1, float* mprev, size_t n, hipStream_t s) {
-  if (n & 3) return hipErrorInvalidValue;
+                                float* xbar, float* d1, float* mprev, size_t n, hipStream_t s, int split) {
+  if ((n & 3) || (split && (prec == PREC_F32 || (split & 3) || n % (size_t)split))) return hipErrorInvalidValue;
   const size_t n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
   NS2VC_BY_PREC(prec, hipLaunchKernelGGL(solver_update_kernel<TMX>, dim3(blocks), dim3(256), 0, s, coef, step_ptr, ncoef, x0, xe, (TMX*)xe_op,
-                                         xbar, d1, mprev, n4));
+                                         xbar, d1, mprev, n4, split));
   return hipGetLastError();
 }
 // Plain kernels for clearing / copying workspace buffers.  The step loop is replayed from a captured hipGraph; memset /

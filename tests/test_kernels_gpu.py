@@ -591,6 +591,78 @@ def test_conv_groupnorm_in_loop(tile, prec, diag):
 
 
 
+@pytest.mark.parametrize("prec", [p for p in PRECS if p != 0], ids=[i for p, i in zip(PRECS, PREC_IDS) if p != 0])
+@pytest.mark.parametrize("tile", [(0, 0, 0), (128, 64, 58), (128, 128, 58)], ids=lambda t: f"{t[0]}x{t[1]}s{t[2]}")
+def test_conv_on_hi_lo_operand_pairs(tile, prec, diag):
+    """r6 (ns2vc_gemm_args.gnp_pair; the engine's split_io option): the GroupNorm prologue writes act(GN(x)) as a hi + lo operand pair -- hi = the operand type's rounding,
+    lo = the rounding of what that dropped -- and the k = 3 conv runs over [hi | lo] (a0, c0 = 2 C) then hi once more (a1 = a0, c1 = C) against weights packed
+    (hi(w) | hi(w) | lo(w)) per tap: x * w to ~2^-2p instead of 2^-p relative.  Checked: the hi plane equals the plain prologue's rows bit for bit, hi + lo
+    reproduces the fp64 rows to fp32 accuracy, and the result is >= 50x closer to the fp64 convolution of the UNROUNDED rows and weights than the plain launch.
+    The pair prologue is its own instantiation of the tap-sharing kernel (both column tiles); other kernels refuse the flag (algo = 1)."""
+    from ns2vc_amd._lib import GemmArgs, check
+    from ns2vc_amd.engine import DevBuf, sync
+    lib = _lib()
+    for (B, T, Cc, N, temb_on, silu) in [(2, 200, 128, 128, 0, 1), (3, 97, 128, 256, 1, 1), (2, 131, 256, 128, 1, 0)]:
+        rng = np.random.default_rng(B * 100 + T + Cc)
+        Gn, taps, M = 8, 3, B * T
+        x = (rng.standard_normal((B, T, Cc)) * (1.0 + rng.random((B, 1, Cc))) + rng.standard_normal((B, 1, Cc))).astype(np.float32)
+        gam, bet = (1.0 + 0.2 * rng.standard_normal(Cc)).astype(np.float32), (0.2 * rng.standard_normal(Cc)).astype(np.float32)
+        ldt = 2 * Cc
+        temb = (0.3 * rng.standard_normal((B, ldt))).astype(np.float32)
+        W = (rng.standard_normal((N, taps, Cc)) / np.sqrt(taps * Cc)).astype(np.float32)
+        Whi = rnd(W, prec)
+        Wp = np.concatenate([W, W, W - Whi], axis=2).reshape(N, taps * 3 * Cc)      # (the packer rounds each third)
+        bias = rng.standard_normal(N).astype(np.float32)
+        blk = x.astype(np.float64).reshape(B, T, Cc // 16, 16)
+        st = np.stack([np.rint(blk.sum(axis=(1, 3)) * 2.0 ** 28), np.rint((blk ** 2).sum(axis=(1, 3)) * 2.0 ** 16)], axis=-1).astype(np.int64)
+        d_x, d_g, d_b, d_t, d_s, d_bias = _dev(x.reshape(M, Cc)), _dev(gam), _dev(bet), _dev(temb), DevBuf.from_numpy(st), _dev(bias)
+        d_w, d_wp = _pack(W.reshape(N, taps * Cc), prec), _pack(Wp, prec)
+        outs, planes = [], []
+        for pair in (0, 1):
+            wd = 2 * Cc if pair else Cc
+            d_a = OpBuf(np.full((M, wd), np.nan, dtype=np.float32), prec)
+            d_o = DevBuf(M * N * 4)
+            d_o.upload(np.full((M, N), np.nan, dtype=np.float32))
+            g = GemmArgs()
+            g.a0 = d_a.ptr; g.lda0 = wd; g.c0 = wd
+            if pair:
+                g.a1 = d_a.ptr; g.lda1 = wd; g.c1 = Cc; g.gnp_pair = 1
+            g.B, g.Tin, g.Tout, g.M = B, T, T, M
+            g.taps, g.tmode = taps, 0
+            g.w = (d_wp if pair else d_w).value; g.K = taps * (3 if pair else 1) * Cc; g.N = N; g.bias = d_bias.ptr
+            g.out_f32 = d_o.ptr; g.ldo_f32 = N
+            g.algo = 2
+            g.gnp_x = d_x.ptr; g.gnp_ldx = Cc; g.gnp_stats = d_s.ptr; g.gnp_gamma = d_g.ptr; g.gnp_beta = d_b.ptr
+            g.gnp_temb = d_t.ptr if temb_on else None; g.gnp_ldtemb = ldt; g.gnp_eps = 1e-5; g.gnp_G = Gn; g.gnp_silu = silu
+            check(lib.ns2vc_debug_set_gemm_tile(*tile), "set tile")
+            try:
+                check(lib.ns2vc_k_gemm(C.byref(g), prec, None), "k_gemm")
+                sync()
+                if pair:
+                    g.algo = 1
+                    assert lib.ns2vc_k_gemm(C.byref(g), prec, None) != 0
+            finally:
+                lib.ns2vc_debug_set_gemm_tile(0, 0, 0)
+            outs.append(d_o.to_numpy((M, N))); planes.append(d_a.read())
+        lib.ns2vc_dev_free(d_w); lib.ns2vc_dev_free(d_wp)
+        xg = x.astype(np.float64).reshape(B, T, Gn, Cc // Gn)
+        mean, var = xg.mean(axis=(1, 3), keepdims=True), xg.var(axis=(1, 3), keepdims=True)
+        y = ((xg - mean) / np.sqrt(var + 1e-5)).reshape(B, T, Cc) * gam.astype(np.float64) + bet.astype(np.float64)
+        if temb_on:
+            y = y * (1.0 + temb[:, None, :Cc].astype(np.float64)) + temb[:, None, Cc:2 * Cc].astype(np.float64)
+        if silu:
+            y = y / (1.0 + np.exp(-y))
+        ref = gather_rows(y, B, T, T, taps, 0).reshape(M, taps * Cc) @ W.reshape(N, taps * Cc).astype(np.float64).T + bias
+        hi, lo = planes[1][:, :Cc], planes[1][:, Cc:]
+        same_hi = np.array_equal(hi, planes[0])
+        e_pair = rel_l2(hi.astype(np.float64) + lo.astype(np.float64), y.reshape(M, Cc))
+        e0, e1 = rel_l2(outs[0], ref), rel_l2(outs[1], ref)
+        diag(f"conv on hi + lo operand pairs tile={tile} prec={prec} B={B} T={T} C={Cc} N={N} temb={temb_on} silu={silu}: hi plane == plain rows {same_hi}; hi + lo vs fp64 rows {e_pair:.2e}; "
+             f"result vs the fp64 conv of unrounded rows and weights: plain {e0:.2e}, pair {e1:.2e}")
+        assert same_hi and np.isfinite(outs[1]).all()
+        assert e_pair < (2e-5 if prec == 1 else 1e-6) and e1 < 0.02 * e0
+
+
 @pytest.mark.parametrize("algo", [2, 0], ids=["prologue", "inloop"])
 @pytest.mark.parametrize("level", [(938, 128, 128), (235, 384, 384), (118, 512, 512)], ids=lambda l: f"T{l[0]}c{l[1]}")
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
