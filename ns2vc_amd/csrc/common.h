@@ -274,7 +274,7 @@ hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1,
 hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
                            const double* partial, int nchunk, const long long* st0, const long long* st1, const float* gamma,
                            const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, void* raw_op,
-                           int prec, hipStream_t s);
+                           int prec, hipStream_t s, int pair = 0);      // pair (16-bit): out_op rows are [hi(C) | lo(C)] (op_rest)
 hipError_t launch_ln_apply_op(const float* x, int ldx, int M, int C, float eps, void* out_op, int prec, hipStream_t s);
 hipError_t launch_cast_op(const float* x, size_t n, void* out_op, int prec, hipStream_t s, int split = 0);   // split: as launch_solver_update
 hipError_t launch_time_embed(const float* t_ptr, int t_stride, const int* step_ptr, int coef_stride,

@@ -866,7 +866,7 @@ struct Planner {
   }
   GnPro groupnorm(const std::string& name, const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int Tl, float eps,
                   const float* gamma, const float* beta, const float* temb, int temb_off, int cout, int silu, void* dst, void* raw,
-                  int consumer_n = 0, int consumer_taps = 1) {
+                  int consumer_n = 0, int consumer_taps = 1, int pair = 0) {
     (void)cout;
     const int nchunk = (Tl + gn_rows - 1) / gn_rows, rows = gn_rows, Bq = B, Gq = G, ldt = h->temb_all.N, pr = prec;
     double* part = gn_partial;
@@ -874,7 +874,9 @@ struct Planner {
     const long long* st0 = find_stats(a0);
     const long long* st1 = a1 ? find_stats(a1) : nullptr;
     const bool epi = st0 && (!a1 || st1) && (((c0 + c1) / Gq) % 16 == 0) && (c0 % 16 == 0);
+    // (pair: the prologue that writes hi + lo pairs exists in the tap-sharing conv kernel only)
     if (epi && h->fuse_gn_gemm && consumer_n > 0 && (consumer_n % 128) == 0 && (h->fuse_gn_cat || (!a1 && !raw)) && Tl >= 66 && c0 + c1 <= 1024 &&
+        (!pair || (h->conv_ts && consumer_taps == 3 && ((c0 + c1) % 64) == 0)) &&
         ((c0 + c1) % Gq) == 0 && Gq <= 8 && (lda0 & 3) == 0 && (!a1 || ((lda1 & 3) == 0 && (c1 & 15) == 0))) {
       GnPro p;
       p.x = a0; p.ldx = lda0; p.st = st0;
@@ -902,8 +904,8 @@ struct Planner {
     }
     add(name + ".gn_apply", [=](hipStream_t s) {
       return launch_gn_apply(a0, lda0, c0, a1, lda1, c1, Bq, Tl, Gq, eps, part, nchunk, st0, st1, gamma, beta, temb, ldt, temb_off, silu, dst,
-                             raw, pr, s);
-    }, 3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0)));
+                             raw, pr, s, pair);                  // (pair: the rows as a hi + lo operand pair, split_io's conv_out)
+    }, 3, 4.0 * n, n * (4.0 + opsz * (raw ? 2.0 : 1.0) + opsz * (pair ? 1.0 : 0.0)));
     return GnPro();
   }
 
@@ -1344,20 +1346,16 @@ int build_plan(ns2vc_unet* h, bool sizing) {
   }
   if (!skips.empty()) return fail("internal: %zu skips left over", skips.size());
   {
-    const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N, 3);
+    // split_io: conv_out reads a hi + lo operand pair -- written by its fused GroupNorm prologue (gnp_pair) or by the gn_apply launch, the same bytes either way
+    const bool po = pio && 2 * curC <= 3 * c0 && h->conv_outp.w;
+    const auto pno = P.groupnorm("conv_norm_out", cur, curC, curC, nullptr, 0, 0, T, 1e-5f, h->out_ng, h->out_nb, nullptr, 0, 0, 1, P.xn, nullptr, h->conv_out.N, 3, po ? 1 : 0);
     // exact_io: only where the norm is the conv's prologue (it then writes fp32 operand rows: xn holds 2-byte elements of up to 3 x 128 channels per row, i.e. room for 128 fp32)
     const bool xo = xio && pno.x != nullptr && (size_t)curC * 4 <= (size_t)3 * c0 * P.opsz;
-    // split_io: likewise only behind a fused prologue, which then writes the hi + lo pair (gnp_pair) into the 3 x 128 columns a row of xn has
-    const bool po = pio && pno.x != nullptr && 2 * curC <= 3 * c0;
-    GemmArgs g;
-    for (int pair = po ? 1 : 0; pair >= 0; --pair) {
-      g = pair ? P.base(P.xn, 2 * curC, 2 * curC, T, T, h->conv_outp, h->x0, nullptr, CP)
-               : P.base(P.xn, curC, curC, T, T, xo ? h->conv_out32 : h->conv_out, h->x0, nullptr, CP);
-      if (pair) { g.a1 = P.xn; g.lda1 = 2 * curC; g.c1 = curC; g.gnp_pair = 1; }
-      g.taps = 3;
-      P.gn_fuse(g, pno);
-      if (!pair || gemm_uses_convts(g, prec)) break;              // (the pair prologue exists in the tap-sharing kernel only)
-    }
+    GemmArgs g = po ? P.base(P.xn, 2 * curC, 2 * curC, T, T, h->conv_outp, h->x0, nullptr, CP)
+                    : P.base(P.xn, curC, curC, T, T, xo ? h->conv_out32 : h->conv_out, h->x0, nullptr, CP);
+    if (po) { g.a1 = P.xn; g.lda1 = 2 * curC; g.c1 = curC; g.gnp_pair = pno.x ? 1 : 0; }       // [hi | lo] then hi once more (3 x 128 columns: what a row of xn holds)
+    g.taps = 3;
+    P.gn_fuse(g, pno);
     if (h->conv_out.N != CP) return fail("internal: conv_out padded width %d != %d", h->conv_out.N, CP);
     P.gemm("conv_out", g, xo ? PREC_F32 : -1);
     if (!sizing) { h->conv_out_g = g; h->conv_out_idx = (int)h->fwd_ops.size() - 1; h->conv_out_prec = xo ? PREC_F32 : prec; }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        int nchunk, const long long* __restrict__ st0, const long long* __restrict__ st1,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ temb, int ldtemb, int temb_off, int silu,
-                                                       TM* __restrict__ out, TM* __restrict__ raw, int rows) {
+                                                       TM* __restrict__ out, TM* __restrict__ raw, int rows, int pair) {
   op_mode_init<TM>();
   __shared__ float s_mean[8], s_rstd[8];
   const int tid = threadIdx.x, b = blockIdx.y, lane = tid & 63, wave = tid >> 6;
@@ -183,7 +183,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const size_t row = (size_t)b * T + r;
         float y0 = w[k].x * sc[0] + sh[0], y1 = w[k].y * sc[1] + sh[1], y2 = w[k].z * sc[2] + sh[2], y3 = w[k].w * sc[3] + sh[3];
         if (silu) { y0 = silu_f(y0); y1 = silu_f(y1); y2 = silu_f(y2); y3 = silu_f(y3); }
-        out_op4<TM>(out + row * C + c, y0, y1, y2, y3);
+        if (pair) {                                         // hi + lo operand pair (GemmArgs.gnp_pair writes the same): rows of 2 C columns
+          out_op4<TM>(out + row * 2 * C + c, y0, y1, y2, y3);
+          out_op4<TM>(out + row * 2 * C + C + c, op_rest<TM>(y0), op_rest<TM>(y1), op_rest<TM>(y2), op_rest<TM>(y3));
+        } else {
+          out_op4<TM>(out + row * C + c, y0, y1, y2, y3);
+        }
         if (raw) out_op4<TM>(raw + row * C + c, w[k].x, w[k].y, w[k].z, w[k].w);
       }
     }
@@ -583,9 +588,9 @@ hipError_t launch_gn_partial(const float* a0, int lda0, int c0, const float* a1,
 hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, int lda1, int c1, int B, int T, int G, float eps,
                            const double* partial, int nchunk, const long long* st0, const long long* st1, const float* gamma,
                            const float* beta, const float* temb, int ldtemb, int temb_off, int silu, void* out_op, void* raw_op,
-                           int prec, hipStream_t s) {
+                           int prec, hipStream_t s, int pair) {
   const int C = c0 + c1;
-  if (C > 1024 || (C & 3) || (c0 & 3) || G > 8) return hipErrorInvalidValue;
+  if (C > 1024 || (C & 3) || (c0 & 3) || G > 8 || (pair && prec == PREC_F32)) return hipErrorInvalidValue;
   if (st0 && (((C / G) & 15) || (c0 & 15) || (c1 && !st1))) return hipErrorInvalidValue;
   // rows per block: at least one full batch of loads per thread (4 * rl), at most 32, sized so that the grid has >= ~1500
   // blocks -- at the coarse levels (T = 118 / 235) 32-row blocks left most of the chip without a wave to hide latency
@@ -595,7 +600,7 @@ hipError_t launch_gn_apply(const float* a0, int lda0, int c0, const float* a1, i
   if (rows < 4 * rl) rows = 4 * rl;
   dim3 grid((T + rows - 1) / rows, B);
   NS2VC_BY_PREC(prec, hipLaunchKernelGGL(gn_apply_kernel<TMX>, grid, dim3(256), 0, s, a0, lda0, c0, a1, lda1, c1, T, G, eps, partial, nchunk,
-                                         st0, st1, gamma, beta, temb, ldtemb, temb_off, silu, (TMX*)out_op, (TMX*)raw_op, rows));
+                                         st0, st1, gamma, beta, temb, ldtemb, temb_off, silu, (TMX*)out_op, (TMX*)raw_op, rows, pair));
   return hipGetLastError();
 }
 template <typename TM> static hipError_t launch_ln_t(const float* x, int ldx, int M, int C, float eps, TM* out, hipStream_t s) {
