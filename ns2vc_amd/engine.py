@@ -17,7 +17,7 @@ from .schedule import NCOEF, SolverTable, build_table
 from .spec import UNetConfig, param_spec
 
 # operand precision of the MFMAs (include/ns2vc_hip.h): fp16 is the default 16-bit mode -- same speed and bytes as bf16,
-# 8e-4 end-to-end error (inside the 1e-3 parity gate) instead of 6.5e-3
+# 7e-4 end-to-end error (inside the 1e-3 parity gate) instead of 5.7e-3
 PRECISIONS = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "f16": PREC_F16}
 DEFAULT_PRECISION = "fp16"
 

@@ -30,8 +30,8 @@ LN_GUARD_DEFAULT = {"fp16": 8.0, "bf16": 8.0, "fp32": 32.0}
 
 
 class Denoiser:
-    """``precision``: "fp16" (default: 16-bit MFMA operands, 8e-4 vs the reference fp32 path -- inside the 1e-3 parity
-    bar), "fp32" (exact-fp32 MFMA, 1e-6) or "bf16" (same speed as fp16, 6.5e-3; kept for range-critical checkpoints).
+    """``precision``: "fp16" (default: 16-bit MFMA operands, 7e-4 vs the reference fp32 path -- inside the 1e-3 parity
+    bar), "fp32" (exact-fp32 MFMA, 1e-6) or "bf16" (same speed as fp16, 5.7e-3; kept for range-critical checkpoints).
 
     ``tail_fp32``: evaluations at the END of every sampling loop that run on a second, fp32 engine (the solver state is
     handed over on the device, ``Engine.sample(tail=...)``).  None = ``DEFAULT_TAIL_FP32[solver]`` for the 16-bit
@@ -47,7 +47,7 @@ class Denoiser:
     the plan for all following calls and warns that the previous result was computed above the threshold.
     ``None`` disables the check; a float sets the threshold (default 8 for the 16-bit modes, 32 for fp32).
 
-    ``precision_check``: the 8e-4 of the fp16 mode was measured on procedural weights; a trained checkpoint with a few hot
+    ``precision_check``: the 7e-4 of the fp16 mode was measured on procedural weights; a trained checkpoint with a few hot
     channels can land on either side of the 1e-3 bar (or saturate fp16 operands outright).  So a 16-bit Denoiser MEASURES
     itself ONCE PER SET OF WEIGHTS (the first call; ``recheck_precision()`` forces another): evaluations are run on the 16-bit
     engine and on the exact-fp32 engine (pinned to the reference at 1e-6) on the caller's own inputs.  ``sample`` checks at

@@ -25,7 +25,7 @@ prompt storage unmodified (``(data_ptr, _version, shape, stride)``; the keyed te
 kept alive, so its address cannot be recycled by the allocator while it is the key);
 the tiny mask -> bias conversion is refreshed on every call.
 Engine precision: ``engine_precision=`` / env ``NS2VC_PRECISION`` (auto | fp32 | fp16 | bf16).  Default since round 4: ``auto`` -- the
-fp16 engine (8e-4 from the reference's fp32 arithmetic on one evaluation, 3.6x faster than the exact-fp32 engine), MEASURED once per
+fp16 engine (7e-4 from the reference's fp32 arithmetic on one evaluation, 3.6x faster than the exact-fp32 engine), MEASURED once per
 set of weights against the exact-fp32 engine on the caller's own first inputs (relative L2 over the batch and of the worst utterance,
 ``precision_error_seen`` / ``precision_error_worst_item``); above ``precision_check`` (1e-3, the parity bar) the module warns and
 serves from the fp32 engine from then on.  So the zero-change drop-in is the fast engine where that is inside the bar and the exact one
