@@ -821,12 +821,16 @@ struct Planner {
     const int pr = pr_override >= 0 ? pr_override : prec;
     const double osz = (double)opsz;
     const double nout = g.geglu ? g.N / 2 : g.N;
-    const double flops = 2.0 * g.M * (double)g.N * g.K;
+    // the ALGORITHMIC figures of the op (what the roofline fractions are priced on): a launch on hi + lo operand pairs (split_io: [hi | lo] + hi again against
+    // (hi(w) | hi(w) | lo(w)), three times the K) counts as the plain convolution it computes, not as the MFMA work and bytes it spends on it
+    const bool pair = g.c1 && g.a1 == g.a0 && g.c0 == 2 * g.c1 && g.c2 == 0;
+    const double Kalg = pair ? g.K / 3.0 : (double)g.K, cin = pair ? g.c1 : g.c0 + g.c1 + g.c2, cgn = pair ? g.c1 : g.c0;
+    const double flops = 2.0 * g.M * (double)g.N * Kalg;
     const double in_rows = (double)g.B * g.Tin;
-    const double bytes = in_rows * (g.c0 + g.c1 + g.c2) * osz + (double)g.N * g.K * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
+    const double bytes = in_rows * cin * osz + (double)g.N * Kalg * osz + (g.out_f32 ? g.M * nout * 4.0 : 0.0) +
                          (g.out_op ? g.M * nout * osz : 0.0) + (g.res ? g.M * nout * 4.0 : 0.0);
     // (a GroupNorm prologue reads the fp32 rows and writes + re-reads the operand rows it builds)
-    const double pro = g.gnp_x ? in_rows * g.c0 * (4.0 + osz * (g.gnp_raw ? 2.0 : 1.0)) : 0.0;
+    const double pro = g.gnp_x ? in_rows * cgn * (4.0 + osz * (g.gnp_raw ? 2.0 : 1.0)) : 0.0;
     if (g.taps == 3 && g.tmode == TMODE_SAME && !g.conv_bn) g.conv_bn = convts_bn_for(g, h->bn128_min);     // the column tile is a PLAN decision (this engine's device)
     if (!sizing && g.gnp_temb && ops == &h->fwd_ops && h->temb_join < 0) h->temb_join = (int)ops->size();    // first launch that reads the time scale / shift rows
     add(g.gnp_x ? name + "[+norm]" : name, [=](hipStream_t s) { return launch_gemm(g, pr, s); }, 1, flops, bytes + pro);
