@@ -74,6 +74,9 @@ void set_ts_trace(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #ifndef NS2VC_TS_NL_DEFAULT
 #define NS2VC_TS_NL_DEFAULT 8    // loader waves (r5 session 6, tap-granular loop, same box: 3.564 ms/step with 8, 3.576 with 4)
 #endif
+#ifndef NS2VC_TS_GNP_XB
+#define NS2VC_TS_GNP_XB 4        // fp32 rows in flight per thread in the GroupNorm prologue of this kernel (gemm4 keeps gnpro.h's 6).  r6, same box, four runs each, after the
+#endif                           // spilled registers were gone: 6 / 5: 3.557-3.568 ms/step, 4: 3.542-3.549 (-0.45 %), 3: 3.540-3.560 (profiles/r06_ab_split_io.txt)
 #ifndef NS2VC_TS_NLD4
 #define NS2VC_TS_NLD4 0          // four DMA waves in the chunk-granular loop of the eight-loader kernels: faster isolated (L2-warm operands), 0.8 % SLOWER in the step
 #endif                           // (3.645 vs 3.617 ms/step same box, profiles/r06_ab_chunk_loop.txt) -- off
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64 * (NL + 4)) void conv3ts_kernel(const GemmArgs g
       // the real rows behind padded rows [q0 - 1, q0 + 127): f(q) = number of real rows with a padded index below q
       auto real_below = [&](int q) __attribute__((always_inline)) { const int b = q / P; return b * T + min(q - b * P, T); };
       const int rlo = real_below(max(q0 - 1, 0)), rhi = real_below(min(q0 + TS_BM - 1, MP));
-      GnPrologue<TM, NS2VC_GNP_XB, GNP == 3> gpro;
+      GnPrologue<TM, NS2VC_TS_GNP_XB, GNP == 3> gpro;
       gpro.begin(g, rlo, rhi, tm, tid, 64 * NW, coop ? tn : 0, coop ? nb_n : 1);
       gpro.finish(g, tid, aring);                                // (its table lives in the activation ring: nothing has been issued into it yet)
     }
