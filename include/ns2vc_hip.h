@@ -271,7 +271,8 @@ typedef struct ns2vc_gemm_args {  /* implicit GEMM: conv1d k3/k1 (stride 1, stri
    * over [hi | lo | hi] activation columns against [hi(w) | hi(w) | lo(w)] weight columns (the caller packs them so) gives x * w to ~2^-21 relative instead of
    * 2^-11 for 3x the K -- the engine's `split_io` option uses it for conv_in and conv_out (23 % of the fp16 forward error's energy, profiles/r06_error_budget.txt).
    *   gnp_pair = 1: the GroupNorm prologue normalises c0 / 2 channels and writes the pair: hi at a0[r][c], lo at a0[r][c0 / 2 + c]; the launch may then
-   *                  carry a1 = a0, c1 = c0 / 2 (the hi plane once more) -- the one case where c1 != 0 goes with gnp_x.  Materialising prologue only.
+   *                  carry a1 = a0, c1 = c0 / 2 (the hi plane once more) -- the one case where c1 != 0 goes with gnp_x.  Tap-sharing kernel with the materialising
+   *                  prologue only (its own instantiation; other kernels refuse the flag).  Without gnp_x a pair is just a wider operand tensor: any kernel takes it.
    *   sol_op_pair = 1: sol_xe_op rows hold such a pair, [hi(sol_ld) | lo(sol_ld)], row stride 2 * sol_ld (what ns2vc_k_solver_update writes for the engine). */
   int32_t gnp_pair, sol_op_pair;
 } ns2vc_gemm_args;
