@@ -213,6 +213,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
   }
   float m_ref = 0.f;                       // softmax reference of this lane's query (operand-representable)
   u32x4_t qaux = hi == 0 ? aux_chunk<TM>(-m_ref, 1.0f) : u32x4_t{0, 0, 0, 0};
+  // r6, hd 16 without a mask bias (the level-0 self-attention: a quarter of this kernel's MFMAs is the aux slab, which then only carries -m_ref): the
+  // reference enters as the score MFMA's C operand instead -- sixteen registers that hold -m_ref, rewritten when the reference moves (once per pass in the
+  // optimistic form) -- and the aux slab, its LDS read and its MFMA are left to the one tile that needs the tail keys' -inf.  Same sum in the same order:
+  // the aux product was the first addend of every score already.  (hd 32: the sixteen registers would cost a wave per SIMD; with a bias the C operand
+  // would have to be rebuilt per tile, 16 VALU adds against one MFMA.)
+  constexpr bool CINIT = HD == 16 && SZ == 2 && !P8;
+  f32x16_t cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
 
   const TM* kbase = reinterpret_cast<const TM*>(a.k) + (size_t)b * a.Lk * a.ldk + h * HD;
   const TM* vbase = reinterpret_cast<const TM*>(a.v) + (size_t)b * a.Lk * a.ldv + h * HD;
@@ -299,6 +308,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
       for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     m_ref = 0.f;
     qaux = hi == 0 ? aux_chunk<TM>(-m_ref, 1.0f) : u32x4_t{0, 0, 0, 0};
+    if constexpr (CINIT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    }
   }
   load_tile(0);
   __syncthreads();          // constants written (first pass) / everybody is done with the stages (second pass)
@@ -313,12 +326,22 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
 
     // ---- S'^T[key][q] = sum_d K[key][d] * (Q[q][d]*scale*log2e) + 1*(-m_ref[q]) + bias[key]*1   (two 32-key sub-tiles)
     f32x16_t s[NSUB];
+    if (CINIT && !bias && (t + 1 < ntile || a.Lk % KEYS == 0)) {       // (wave-uniform) the reference through the C operand, no aux slab
+#pragma unroll
+      for (int k2 = 0; k2 < NSUB; ++k2) {
+        const char* kr = Ks + (k2 * 32 + l31) * KROWB + hi * 16;
+        s[k2] = cinit;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + sl * 32), qf[sl]);
+      }
+    } else {
 #pragma unroll
     for (int k2 = 0; k2 < NSUB; ++k2) {
       const char* kr = Ks + (k2 * 32 + l31) * KROWB + hi * 16;
       s[k2] = AMma<TM>::mma0(*reinterpret_cast<const u32x4_t*>(kr + NS * 32), qaux);      // aux slab first: no zero-init movs
 #pragma unroll
       for (int sl = 0; sl < NS; ++sl) AMma<TM>::mma(s[k2], *reinterpret_cast<const u32x4_t*>(kr + sl * 32), qf[sl]);
+    }
     }
     // ---- reference check (per query = per lane; both lane halves agree): lane's keys are k2*32 + 8*g + 4*hi + i
     if (!O || t == 0) {
@@ -347,6 +370,10 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs a) {
           for (int r = 0; r < 16; ++r) s[k2][r] -= dsh;
         m_ref = m_new;
         if (hi == 0) qaux = aux_chunk<TM>(-m_ref, 1.0f);
+        if constexpr (CINIT) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cinit[r] = -m_ref;
+        }
       }
     }
 #pragma unroll
