@@ -383,6 +383,35 @@ def test_no_packed_fp32_of_the_failing_form_under_outstanding_lds_reads():
     assert any("rowchain" in x[1] or "ffn" in x[1] for x in sites)
 
 
+def test_default_conv_kernels_use_no_scratch():
+    """r6: an epilogue of the OFF option fuse_solver, compiled into every tap-sharing conv kernel behind a run-time test, had cost all 128-column tiles 26 spilled VGPRs and
+    108 B of scratch per lane -- a scratch reload is an `s_waitcnt vmcnt(0)` beside hand-counted LDS-DMA -- and 0.4 % of the step (profiles/r06_ab_split_io.txt).  Epilogue
+    and pair prologue are separate instantiations now (template parameters SOL, GNP = 3); this pins it: hipcc's kernel-resource-usage remarks for convts.hip must show no
+    scratch and no spilled VGPR in any kernel of the default path (SOL = false).  The whole library: tools/kernel_resources.sh -> profiles/r06_kernel_resources.txt."""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(ROOT, "ns2vc_amd", "csrc")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I../../include", "-Rpass-analysis=kernel-resource-usage", "-c", "convts.hip",
+                        "-o", os.devnull], cwd=src, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, seen, bad = None, 0, []
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill): (\d+)", line)
+        if m and name and "conv3ts_kernel" in name:
+            seen += 1
+            # mangled template tail: ...ELi<GNP>ELb<KS>ELb<SOL>EE
+            sol = re.search(r"ELb[01]ELb([01])EE", name)
+            if sol and sol.group(1) == "0" and int(m.group(2)) != 0:
+                bad.append((name, m.group(1), int(m.group(2))))
+    assert seen >= 40, f"only {seen} resource lines parsed"
+    assert not bad, bad
+
+
 def test_host_operand_rounding_matches_ieee():
     """The weight-packing conversions (csrc/common.h f32_to_f16_bits / f32_to_bf16_bits) against numpy's IEEE binary16
     and the bit-level bf16 reference: random values over the whole exponent range, subnormals, ties, overflow, inf/nan."""
